@@ -1,0 +1,71 @@
+"""ctypes binding of libxq_ops.so — the C-ABI declared in include/xq_ops.h.
+
+There is NO fallback: if the shared library is missing, `lib()` raises.  The library itself only
+contains gfx950 code objects, so calling any op without an MI355X fails loudly in HIP.
+PyTorch is used for device memory and streams only: ops receive raw `data_ptr()`s and the current
+HIP stream handle.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxq_ops.so")
+
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/xq_ops.h declares (tests check this)
+SIGNATURES = {
+    "xq_abi_version": (ctypes.c_int, []),
+    "xq_last_error": (ctypes.c_char_p, []),
+    "xq_assign_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "xq_assign": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp,
+                                 vp, ctypes.c_size_t, vp]),
+    "xq_vq_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "xq_vq_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp,
+                                      vp, vp, vp, ctypes.c_float, vp, vp, vp]),
+    "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
+    "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+}
+
+_lib = None
+
+
+class XqError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads libxq_ops.so (built by `__graft_entry__.build()` / `make -C imagefolder_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise XqError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback for the quantizer ops.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().xq_last_error()
+        raise XqError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """raw device pointer of a tensor (or None)"""
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def current_stream_handle(device=None):
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)

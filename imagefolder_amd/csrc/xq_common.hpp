@@ -1,0 +1,59 @@
+// xq_common.hpp — shared helpers for the gfx950 quantizer kernels (device + host side).
+//
+// ARITHMETIC CONTRACT (identical to oracle/xq_oracle.c, which is the parity checker):
+//   (A1) channel-axis dot products / sums of squares are sequential fp32 fmaf chains, ascending
+//        channel, starting from +0.0f — exactly what a v_mfma_f32_32x32x2_f32 K-loop computes;
+//   (A2) l2-normalise(x) = x / max(sqrtf(chain(x,x)), 1e-12f) with IEEE-rounded sqrt and division
+//        (built with -fhip-fp32-correctly-rounded-divide-sqrt);
+//   (A3) d = fl(fl(|z|^2 + |e|^2) - 2*dot);  (A4) lowest index wins ties.
+// The translation unit is compiled with -ffp-contract=off so only explicit fmaf() fuses.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define XQ_EPS 1e-12f
+
+namespace xq {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// float -> uint32 whose unsigned order equals the float order (NaN sorts last).
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t u) {
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+
+// (A1)+(A2) on a register-resident row; returns the clamped norm.
+template <int C>
+__device__ __forceinline__ float l2norm_row(const float (&x)[C], float (&y)[C]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) s = __builtin_fmaf(x[k], x[k], s);
+    float n = __builtin_sqrtf(s);
+    n = (n > XQ_EPS) ? n : XQ_EPS;
+#pragma unroll
+    for (int k = 0; k < C; ++k) y[k] = x[k] / n;
+    return n;
+}
+
+template <int C>
+__device__ __forceinline__ float chain_sq(const float (&x)[C]) {
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) s = __builtin_fmaf(x[k], x[k], s);
+    return s;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace xq

@@ -1,0 +1,590 @@
+// xq_vq.hip — single-scale vector quantizer on gfx950 (MI355X): fused l2-normalise + distance +
+// argmin (fp32 MFMA), gather/straight-through/loss/histogram epilogue, hand-written backward.
+//
+// Replaces (reference file:line, lxa9867/ImageFolder):
+//   VectorQuantizer.forward            tokenizer/tokenizer_image/xqgan_model.py:745-801
+//   VectorQuantizer.f_to_idxBl_or_fhat tokenizer/tokenizer_image/xqgan_model.py:803-833
+//   the distance/argmin of add_perturbation and VectorQuantizer2 (latent_perturbation.py:9-18,
+//   quant.py:93-101) through xq_assign.
+//
+// Kernel plan (one forward = 3 launches + 1 memset, no N x V matrix ever reaches HBM):
+//   K0 prep_codebook : E[V][C] -> ehat in MFMA B-fragment order + |ehat|^2 (once per forward; 1-2 MB, L2-resident)
+//   K1 assign        : 512-thread blocks = 8 waves x 32 tokens; A fragments (zhat) stay in VGPRs for the
+//                      whole kernel, codebook chunks stream through double-buffered LDS, one
+//                      v_mfma_f32_32x32x2_f32 chain of C/2 instructions per 32x32 (token x code) tile,
+//                      running (min, tile) per accumulator register, wave-shuffle reduction, 64-bit
+//                      atomicMin of (ordered(d) << 32 | code) so the V axis can be split across blocks
+//                      (fills 256 CUs even at N = 32k tokens) with exact lowest-index tie-breaking.
+//   K2 vq_finish     : per token: gather E[idx], renormalise, straight-through form, NCHW store,
+//                      loss partials, histogram atomics.   (HBM-bound: 8C+8 bytes per token.)
+// Roofline: K1 is fp32-MFMA bound: 2*N*V*C flop; K2/backward are HBM bound.
+#include "xq_common.hpp"
+#include "../../include/xq_ops.h"
+
+#include <stdio.h>
+#include <string.h>
+
+using namespace xq;
+
+// ------------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+static int xq_set_error(int code, const char *fmt, const char *a = "", long b = 0, long c = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+    return code;
+}
+extern "C" const char *xq_last_error(void) { return g_err; }
+extern "C" int xq_abi_version(void) { return XQ_ABI_VERSION; }
+
+// ------------------------------------------------------------------------------------------------
+// measurement hooks: HIP events around assign_kernel on its launch stream (bench.py roofline leg)
+// ------------------------------------------------------------------------------------------------
+static bool g_prof_on = false;
+static constexpr int PROF_MAX = 8192;
+static hipEvent_t g_prof_ev[PROF_MAX][2];
+static int g_prof_n = 0, g_prof_created = 0;
+
+extern "C" int xq_prof_enable(int on) {
+    g_prof_on = on != 0;
+    g_prof_n = 0;
+    return XQ_OK;
+}
+extern "C" int xq_prof_collect(double *assign_ms_total, int *assign_launches) {
+    double tot = 0.0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipEventSynchronize failed");
+        if (hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipEventElapsedTime failed");
+        tot += ms;
+    }
+    if (assign_ms_total) *assign_ms_total = tot;
+    if (assign_launches) *assign_launches = g_prof_n;
+    g_prof_n = 0;
+    return XQ_OK;
+}
+static inline int prof_slot() {
+    if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
+    if (g_prof_n >= g_prof_created) {
+        if (hipEventCreate(&g_prof_ev[g_prof_created][0]) != hipSuccess || hipEventCreate(&g_prof_ev[g_prof_created][1]) != hipSuccess) return -1;
+        ++g_prof_created;
+    }
+    return g_prof_n++;
+}
+
+// ------------------------------------------------------------------------------------------------
+// tiling constants
+// ------------------------------------------------------------------------------------------------
+template <int C> struct Tiling {
+    static constexpr int CH = (C == 8) ? 256 : ((C <= 64) ? 128 : 64);  // codes per LDS stage
+    static constexpr int TILES = CH / 32;            // 32-code MFMA tiles per stage
+    static constexpr int KQ = C / 8;                 // float4 B-fragment reads per tile per lane (4 k-pairs each)
+    static constexpr int STAGE_F4 = CH * C / 4;      // float4 per stage (codebook part)
+    static constexpr int BUF_BYTES = CH * C * 4 + CH * 4;
+};
+static constexpr int ASSIGN_THREADS = 512;
+static constexpr int TOK_PER_BLOCK = 256;  // 8 waves x 32 tokens
+
+static inline int chunk_codes(int C) { return C == 8 ? 256 : (C <= 64 ? 128 : 64); }
+
+struct AssignWs {
+    float *wb;                 // [Vpad/32][C/8][64 lanes][4]  fragment-ordered ehat
+    float *ee;                 // [Vpad]
+    unsigned long long *keys;  // [N]
+    float *partials;           // [4096]
+    int Vpad;
+};
+static constexpr int MAX_PARTIALS = 4096;
+
+static size_t assign_ws_layout(int64_t N, int C, int V, char *base, AssignWs *ws) {
+    const int CH = chunk_codes(C);
+    const int Vpad = (V + CH - 1) / CH * CH;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    size_t o_wb = take((size_t)Vpad * C * 4);
+    size_t o_ee = take((size_t)Vpad * 4);
+    size_t o_keys = take((size_t)N * 8);
+    size_t o_part = take((size_t)MAX_PARTIALS * 4);
+    if (ws) {
+        ws->wb = (float *)(base + o_wb);
+        ws->ee = (float *)(base + o_ee);
+        ws->keys = (unsigned long long *)(base + o_keys);
+        ws->partials = (float *)(base + o_part);
+        ws->Vpad = Vpad;
+    }
+    return off;
+}
+
+extern "C" size_t xq_assign_workspace_bytes(int64_t N, int C, int V) {
+    if (N < 0 || V < 1 || C < 1) return 0;
+    return assign_ws_layout(N, C, V, nullptr, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K0: codebook -> fragment-ordered (optionally l2-normalised) copy + squared norms
+//   element (code j, channel k) lands at float offset ((T*KQ + q)*64 + lane)*4 + ti with
+//   T = j/32, lane = (k&1)*32 + j%32, t = k/2, q = t/4, ti = t%4: lane l of MFMA step t then holds
+//   B[k = 2t + (l>>5)][col = l&31] — the v_mfma_f32_32x32x2_f32 operand layout — and 4 consecutive
+//   steps come from one ds_read_b128.  Padding codes (j >= V) get ehat = 0 and |e|^2 = +inf.
+// ------------------------------------------------------------------------------------------------
+template <int C, int MODE>
+__global__ __launch_bounds__(256) void prep_codebook_kernel(const float *__restrict__ E, int V, int Vpad,
+                                                            float *__restrict__ wb, float *__restrict__ ee) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= Vpad) return;
+    float e[C], eh[C];
+    float een;
+    if (j < V) {
+        const float4 *row = reinterpret_cast<const float4 *>(E + (size_t)j * C);
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            float4 v = row[q];
+            e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+        }
+        if (MODE == XQ_MODE_L2_RAW) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) eh[k] = e[k];
+        } else {
+            l2norm_row<C>(e, eh);
+        }
+        een = (MODE == XQ_MODE_COSINE) ? 0.0f : chain_sq<C>(eh);
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) eh[k] = 0.0f;
+        een = __builtin_inff();
+    }
+    ee[j] = een;
+    constexpr int KQ = C / 8;
+    const int T = j >> 5, jj = j & 31;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const int t = k >> 1, hh = k & 1, q = t >> 2, ti = t & 3;
+        wb[(((size_t)T * KQ + q) * 64 + hh * 32 + jj) * 4 + ti] = eh[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: fused normalise + distance + argmin
+// ------------------------------------------------------------------------------------------------
+template <int C, int MODE>
+__global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float *__restrict__ z, long N, int HW,
+                                                                const float *__restrict__ wb,
+                                                                const float *__restrict__ ee, int n_chunks,
+                                                                int chunks_per_split,
+                                                                unsigned long long *__restrict__ keys) {
+    using TL = Tiling<C>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, li = lane & 31;
+
+    // ---- prologue: this lane's token (both wave halves hold the same 32 tokens) ----
+    const long tok0 = (long)blockIdx.x * TOK_PER_BLOCK + wave * 32;
+    long n = tok0 + li;
+    if (n > N - 1) n = N - 1;
+    const long b = n / HW;
+    const int hw = (int)(n - b * HW);
+    const float *base = z + (size_t)b * C * HW + hw;
+    float a[C / 2];
+    float zzr[16];
+    {
+        float x[C], zh[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) x[k] = base[(size_t)k * HW];
+        if (MODE == XQ_MODE_L2_RAW) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) zh[k] = x[k];
+        } else {
+            l2norm_row<C>(x, zh);
+        }
+        float zz = (MODE == XQ_MODE_COSINE) ? 0.0f : chain_sq<C>(zh);
+#pragma unroll
+        for (int t = 0; t < C / 2; ++t) a[t] = h ? zh[2 * t + 1] : zh[2 * t];
+        // accumulator register r of this lane is token row (r&3) + 8*(r>>2) + 4*h of the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) zzr[r] = __shfl(zz, (r & 3) + 8 * (r >> 2) + 4 * h);
+    }
+
+    float best[16];
+    int bcode[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best[r] = __builtin_inff(); bcode[r] = 0; }
+
+    const int c0 = blockIdx.y * chunks_per_split;
+    int c1 = c0 + chunks_per_split;
+    if (c1 > n_chunks) c1 = n_chunks;
+
+    constexpr int NST = (TL::STAGE_F4 + ASSIGN_THREADS - 1) / ASSIGN_THREADS;
+    static_assert(TL::STAGE_F4 % ASSIGN_THREADS == 0, "stage size must be a multiple of the block");
+    float4 st[NST];
+    float st_e = 0.0f;
+    auto stage_load = [&](int chunk) {
+        const float4 *src = reinterpret_cast<const float4 *>(wb) + (size_t)chunk * TL::STAGE_F4;
+#pragma unroll
+        for (int i = 0; i < NST; ++i) st[i] = src[tid + i * ASSIGN_THREADS];
+        if (tid < TL::CH) st_e = ee[(size_t)chunk * TL::CH + tid];
+    };
+    auto stage_write = [&](int bufi) {
+        float4 *dst = reinterpret_cast<float4 *>(smem + (size_t)bufi * TL::BUF_BYTES);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) dst[tid + i * ASSIGN_THREADS] = st[i];
+        if (tid < TL::CH) reinterpret_cast<float *>(dst + TL::STAGE_F4)[tid] = st_e;
+    };
+
+    if (c0 < c1) {
+        stage_load(c0);
+        stage_write(0);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    for (int chunk = c0; chunk < c1; ++chunk) {
+        const bool has_next = (chunk + 1 < c1);
+        if (has_next) stage_load(chunk + 1);  // global -> VGPR, lands while the MFMAs below run
+
+        const float4 *bbuf = reinterpret_cast<const float4 *>(smem + (size_t)cur * TL::BUF_BYTES);
+        const float *ebuf = reinterpret_cast<const float *>(bbuf + TL::STAGE_F4);
+#pragma unroll
+        for (int tile = 0; tile < TL::TILES; ++tile) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+            const float4 *bt = bbuf + tile * (TL::KQ * 64) + lane;
+#pragma unroll
+            for (int q = 0; q < TL::KQ; ++q) {
+                const float4 bv = bt[q * 64];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 0], bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], bv.w, acc, 0, 0, 0);
+            }
+            const float e = ebuf[tile * 32 + li];
+            const int code0 = chunk * TL::CH + tile * 32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float d;
+                if (MODE == XQ_MODE_COSINE) d = e - acc[r];                      // e = 0 (real) / +inf (padding)
+                else d = __builtin_fmaf(-2.0f, acc[r], zzr[r] + e);              // (A3): 2*dot exact
+                const bool lt = d < best[r];                                       // strict: first tile wins ties
+                best[r] = lt ? d : best[r];
+                bcode[r] = lt ? code0 : bcode[r];
+            }
+        }
+        if (has_next) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- cross-lane reduction over the 32 code columns of each half, then one atomicMin per token ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        unsigned long long key = ((unsigned long long)f2ord(best[r]) << 32) | (unsigned)(bcode[r] + li);
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(key, o);
+            key = other < key ? other : key;
+        }
+        if (li == r) {
+            const long tn = tok0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (tn < N) atomicMin(keys + tn, key);
+        }
+    }
+}
+
+// keys -> idx (+ optional winning score)
+__global__ __launch_bounds__(256) void keys_to_idx_kernel(const unsigned long long *__restrict__ keys, long N,
+                                                          int64_t *__restrict__ idx, float *__restrict__ best) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const unsigned long long k = keys[n];
+    idx[n] = (int64_t)(k & 0xffffffffull);
+    if (best) best[n] = ord2f((uint32_t)(k >> 32));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: per-token epilogue of VectorQuantizer.forward (xqgan_model.py:769-799)
+// ------------------------------------------------------------------------------------------------
+template <int C, bool NORMED>
+__global__ __launch_bounds__(256) void vq_finish_kernel(const float *__restrict__ z, long N, int HW,
+                                                        const float *__restrict__ E,
+                                                        const unsigned long long *__restrict__ keys, int ste,
+                                                        float *__restrict__ zq, int64_t *__restrict__ idx_out,
+                                                        float *__restrict__ hist, float *__restrict__ partials) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    float lsum = 0.0f;
+    if (n < N) {
+        const unsigned idx = (unsigned)(keys[n] & 0xffffffffull);
+        idx_out[n] = (int64_t)idx;
+        const long b = n / HW;
+        const int hw = (int)(n - b * HW);
+        const size_t off = (size_t)b * C * HW + hw;
+        float x[C], zh[C], e[C], eh[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) x[k] = z[off + (size_t)k * HW];
+        const float4 *row = reinterpret_cast<const float4 *>(E + (size_t)idx * C);
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            float4 v = row[q];
+            e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+        }
+        if (NORMED) {
+            l2norm_row<C>(x, zh);
+            l2norm_row<C>(e, eh);
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) { zh[k] = x[k]; eh[k] = e[k]; }
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const float diff = eh[k] - zh[k];
+            lsum = __builtin_fmaf(diff, diff, lsum);
+            if (zq) zq[off + (size_t)k * HW] = ste ? (zh[k] + diff) : eh[k];
+        }
+        if (hist) atomicAdd(hist + idx, 1.0f);
+    }
+    if (partials) {
+        __shared__ float red[4];
+        lsum = wave_sum(lsum);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = lsum;
+        __syncthreads();
+        if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// fixed-order sum of per-block partials (double) -> out[0]
+__global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__restrict__ partials, int n,
+                                                              float *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)partials[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (float)red[0];
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward of VectorQuantizer.forward (SURVEY §8a "Backward structure")
+// ------------------------------------------------------------------------------------------------
+template <int C, bool NORMED>
+__global__ __launch_bounds__(256) void vq_backward_kernel(const float *__restrict__ z, long N, int HW,
+                                                          const float *__restrict__ E,
+                                                          const int64_t *__restrict__ idx_in,
+                                                          const float *__restrict__ g_out,
+                                                          const float *__restrict__ g_vq,
+                                                          const float *__restrict__ g_commit, float beta,
+                                                          float *__restrict__ g_z, float *__restrict__ g_E) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float inv = 1.0f / ((float)N * (float)C);
+    const float cc = (g_commit ? g_commit[0] : 0.0f) * beta * 2.0f * inv;  // commit: d/dzhat of beta*mean((sg(eh)-zh)^2)
+    const float cv = (g_vq ? g_vq[0] : 0.0f) * 2.0f * inv;                 // vq:     d/dehat of mean((eh-sg(zh))^2)
+    const long idx = idx_in[n];
+    const long b = n / HW;
+    const int hw = (int)(n - b * HW);
+    const size_t off = (size_t)b * C * HW + hw;
+    float x[C], zh[C], e[C], eh[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) x[k] = z[off + (size_t)k * HW];
+    const float4 *row = reinterpret_cast<const float4 *>(E + (size_t)idx * C);
+#pragma unroll
+    for (int q = 0; q < C / 4; ++q) {
+        float4 v = row[q];
+        e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+    }
+    float nz = 1.0f, ne = 1.0f;
+    if (NORMED) {
+        nz = l2norm_row<C>(x, zh);
+        ne = l2norm_row<C>(e, eh);
+    } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) { zh[k] = x[k]; eh[k] = e[k]; }
+    }
+    float gzh[C], geh[C];
+    float dz = 0.0f, de = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const float go = g_out ? g_out[off + (size_t)k * HW] : 0.0f;
+        const float diff = zh[k] - eh[k];
+        gzh[k] = __builtin_fmaf(cc, diff, go);
+        geh[k] = -cv * diff;
+        dz = __builtin_fmaf(gzh[k], zh[k], dz);
+        de = __builtin_fmaf(geh[k], eh[k], de);
+    }
+    float *ge_row = g_E + (size_t)idx * C;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const float gz = NORMED ? (gzh[k] - zh[k] * dz) / nz : gzh[k];
+        const float ge = NORMED ? (geh[k] - eh[k] * de) / ne : geh[k];
+        g_z[off + (size_t)k * HW] = gz;
+        if (cv != 0.0f) atomicAdd(ge_row + k, ge);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+static int g_num_cus = 0;
+static int num_cus() {
+    if (g_num_cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) g_num_cus = p.multiProcessorCount;
+        if (g_num_cus <= 0) g_num_cus = 256;
+    }
+    return g_num_cus;
+}
+
+template <int C, int MODE>
+static int launch_assign_t(const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s) {
+    using TL = Tiling<C>;
+    const int Vpad = ws.Vpad;
+    hipLaunchKernelGGL((prep_codebook_kernel<C, MODE>), dim3((Vpad + 255) / 256), dim3(256), 0, s, E, V, Vpad, ws.wb, ws.ee);
+    if (hipMemsetAsync(ws.keys, 0xFF, (size_t)N * 8, s) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipMemsetAsync(keys) failed");
+    const int n_chunks = Vpad / TL::CH;
+    const int tok_blocks = (int)((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK);
+    // split the code axis so that the grid covers the chip (>= 2 blocks per CU when possible)
+    int want = (2 * num_cus() + tok_blocks - 1) / tok_blocks;
+    if (want < 1) want = 1;
+    if (want > n_chunks) want = n_chunks;
+    const int cps = (n_chunks + want - 1) / want;
+    const int splits = (n_chunks + cps - 1) / cps;
+    const size_t lds = 2 * (size_t)TL::BUF_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    const int pslot = prof_slot();
+    if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][0], s);
+    hipLaunchKernelGGL((assign_kernel<C, MODE>), dim3(tok_blocks, splits), dim3(ASSIGN_THREADS), lds, s, z, N, HW, ws.wb, ws.ee,
+                       n_chunks, cps, ws.keys);
+    if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][1], s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "assign_kernel<C=%d>: %s", C, hipGetErrorString(e)); return XQ_ELAUNCH; }
+    return XQ_OK;
+}
+
+template <int C>
+static int launch_assign_c(int mode, const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s) {
+    switch (mode) {
+        case XQ_MODE_L2_NORMED: return launch_assign_t<C, XQ_MODE_L2_NORMED>(z, N, HW, E, V, ws, s);
+        case XQ_MODE_L2_RAW: return launch_assign_t<C, XQ_MODE_L2_RAW>(z, N, HW, E, V, ws, s);
+        case XQ_MODE_COSINE: return launch_assign_t<C, XQ_MODE_COSINE>(z, N, HW, E, V, ws, s);
+    }
+    return xq_set_error(XQ_EINVAL, "%s: unknown mode %ld", "xq_assign", mode);
+}
+
+static int launch_assign(int mode, int C, const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s) {
+    switch (C) {
+        case 8: return launch_assign_c<8>(mode, z, N, HW, E, V, ws, s);
+        case 16: return launch_assign_c<16>(mode, z, N, HW, E, V, ws, s);
+        case 32: return launch_assign_c<32>(mode, z, N, HW, E, V, ws, s);
+        case 64: return launch_assign_c<64>(mode, z, N, HW, E, V, ws, s);
+    }
+    return xq_set_error(XQ_EINVAL, "%s: unsupported channel count C=%ld (supported: 8,16,32,64)", "xq_assign", C);
+}
+
+static int check_common(const char *fn, const void *z, int B, int C, int HW, const void *E, int V) {
+    if (!z || !E) return xq_set_error(XQ_EINVAL, "%s: null input pointer", fn);
+    if (B < 0 || HW < 1 || V < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape (B=%ld, HW=%ld)", fn, B, HW);
+    if (C != 8 && C != 16 && C != 32 && C != 64)
+        return xq_set_error(XQ_EINVAL, "%s: unsupported channel count C=%ld (supported: 8,16,32,64)", fn, C);
+    if ((long)V > 0x7fffff00L) return xq_set_error(XQ_EINVAL, "%s: V=%ld too large", fn, V);
+    return XQ_OK;
+}
+
+extern "C" int xq_assign(const float *z, int B, int C, int HW, const float *E, int V, int mode, int64_t *idx, float *best,
+                         void *workspace, size_t workspace_bytes, xq_stream_t stream) {
+    int rc = check_common("xq_assign", z, B, C, HW, E, V);
+    if (rc) return rc;
+    if (!idx) return xq_set_error(XQ_EINVAL, "%s: idx is null", "xq_assign");
+    const long N = (long)B * HW;
+    if (N == 0) return XQ_OK;
+    AssignWs ws;
+    const size_t need = assign_ws_layout(N, C, V, (char *)workspace, &ws);
+    if (!workspace || workspace_bytes < need)
+        return xq_set_error(XQ_ENOSPACE, "%s: workspace %ld < %ld bytes", "xq_assign", (long)workspace_bytes, (long)need);
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_assign(mode, C, z, N, HW, E, V, ws, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(keys_to_idx_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, ws.keys, N, idx, best);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "keys_to_idx_kernel: %s", hipGetErrorString(e)); return XQ_ELAUNCH; }
+    return XQ_OK;
+}
+
+template <int C>
+static void launch_finish(bool normed, const float *z, long N, int HW, const float *E, const unsigned long long *keys, int ste,
+                          float *zq, int64_t *idx, float *hist, float *partials, int blocks, hipStream_t s) {
+    if (normed)
+        hipLaunchKernelGGL((vq_finish_kernel<C, true>), dim3(blocks), dim3(256), 0, s, z, N, HW, E, keys, ste, zq, idx, hist, partials);
+    else
+        hipLaunchKernelGGL((vq_finish_kernel<C, false>), dim3(blocks), dim3(256), 0, s, z, N, HW, E, keys, ste, zq, idx, hist, partials);
+}
+
+extern "C" int xq_vq_forward(const float *z, int B, int C, int HW, const float *E, int V, int codebook_norm, int ste,
+                             float *zq, int64_t *idx, float *hist, float *loss_sq, void *workspace, size_t workspace_bytes,
+                             xq_stream_t stream) {
+    int rc = check_common("xq_vq_forward", z, B, C, HW, E, V);
+    if (rc) return rc;
+    if (!idx) return xq_set_error(XQ_EINVAL, "%s: idx is null", "xq_vq_forward");
+    const long N = (long)B * HW;
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        if (loss_sq) (void)hipMemsetAsync(loss_sq, 0, 4, s);
+        return XQ_OK;
+    }
+    AssignWs ws;
+    const size_t need = assign_ws_layout(N, C, V, (char *)workspace, &ws);
+    if (!workspace || workspace_bytes < need)
+        return xq_set_error(XQ_ENOSPACE, "%s: workspace %ld < %ld bytes", "xq_vq_forward", (long)workspace_bytes, (long)need);
+    const int blocks = (int)((N + 255) / 256);
+    if (loss_sq && blocks > MAX_PARTIALS)
+        return xq_set_error(XQ_EINVAL, "%s: N=%ld exceeds the loss-partials capacity (%ld tokens)", "xq_vq_forward", N, (long)MAX_PARTIALS * 256);
+    rc = launch_assign(codebook_norm ? XQ_MODE_L2_NORMED : XQ_MODE_L2_RAW, C, z, N, HW, E, V, ws, s);
+    if (rc) return rc;
+    float *partials = loss_sq ? ws.partials : nullptr;
+    switch (C) {
+        case 8: launch_finish<8>(codebook_norm != 0, z, N, HW, E, ws.keys, ste, zq, idx, hist, partials, blocks, s); break;
+        case 16: launch_finish<16>(codebook_norm != 0, z, N, HW, E, ws.keys, ste, zq, idx, hist, partials, blocks, s); break;
+        case 32: launch_finish<32>(codebook_norm != 0, z, N, HW, E, ws.keys, ste, zq, idx, hist, partials, blocks, s); break;
+        case 64: launch_finish<64>(codebook_norm != 0, z, N, HW, E, ws.keys, ste, zq, idx, hist, partials, blocks, s); break;
+    }
+    if (loss_sq) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, ws.partials, blocks, loss_sq);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "vq_finish_kernel: %s", hipGetErrorString(e)); return XQ_ELAUNCH; }
+    return XQ_OK;
+}
+
+template <int C>
+static void launch_bwd(bool normed, const float *z, long N, int HW, const float *E, const int64_t *idx, const float *g_out,
+                       const float *g_vq, const float *g_commit, float beta, float *g_z, float *g_E, hipStream_t s) {
+    const int blocks = (int)((N + 255) / 256);
+    if (normed)
+        hipLaunchKernelGGL((vq_backward_kernel<C, true>), dim3(blocks), dim3(256), 0, s, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E);
+    else
+        hipLaunchKernelGGL((vq_backward_kernel<C, false>), dim3(blocks), dim3(256), 0, s, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E);
+}
+
+extern "C" int xq_vq_backward(const float *z, int B, int C, int HW, const float *E, int V, int codebook_norm,
+                              const int64_t *idx, const float *g_out, const float *g_vq, const float *g_commit, float beta,
+                              float *g_z, float *g_E, xq_stream_t stream) {
+    int rc = check_common("xq_vq_backward", z, B, C, HW, E, V);
+    if (rc) return rc;
+    if (!idx || !g_z || !g_E) return xq_set_error(XQ_EINVAL, "%s: null idx/g_z/g_E", "xq_vq_backward");
+    const long N = (long)B * HW;
+    if (N == 0) return XQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    switch (C) {
+        case 8: launch_bwd<8>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
+        case 16: launch_bwd<16>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
+        case 32: launch_bwd<32>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
+        case 64: launch_bwd<64>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "vq_backward_kernel: %s", hipGetErrorString(e)); return XQ_ELAUNCH; }
+    return XQ_OK;
+}
