@@ -26,6 +26,9 @@
 
 using namespace xq;
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
@@ -82,8 +85,11 @@ template <int C> struct Tiling {
     static constexpr int STAGE_F4 = CH * C / 4;      // float4 per stage (codebook part)
     static constexpr int BUF_BYTES = CH * C * 4 + CH * 4;
 };
-static constexpr int ASSIGN_THREADS = 512;
-static constexpr int TOK_PER_BLOCK = 256;  // 8 waves x 32 tokens
+#ifndef XQ_LDS_BPC
+#define XQ_LDS_BPC 1
+#endif
+static constexpr int ASSIGN_THREADS = 512;                 // 8 waves = 2 anti-phase wave groups x 4 SIMDs
+static constexpr int TOK_PER_BLOCK = ASSIGN_THREADS / 2;   // one 32-token MFMA row tile per wave
 
 static inline int chunk_codes(int C) { return C == 8 ? 256 : (C <= 64 ? 128 : 64); }
 
@@ -165,116 +171,72 @@ __global__ __launch_bounds__(256) void prep_codebook_kernel(const float *__restr
 
 // ------------------------------------------------------------------------------------------------
 // K1: fused normalise + distance + argmin
+//   512-thread block = 8 waves = two wave groups (waves 0-3 / 4-7: one wave of each group per SIMD).
+//   The groups run in anti-phase, separated by one s_barrier per phase:
+//       phase p   : group X runs the v_mfma_f32_32x32x2_f32 chains of one LDS stage (TILES x C/2 MFMAs),
+//                   group Y retires the accumulators of ITS previous stage (VALU: add, fma, cmp, 2 cndmask
+//                   per accumulator register);
+//       phase p+1 : roles swap.
+//   Measured on MI355X (tools/ubench/mfma_valu_overlap.hip, profiles/r01_mfma_valu_overlap.txt): the f32-input
+//   MFMA does NOT run beside fp32 VALU work on the same SIMD — an MFMA-only wave and a VALU-only wave sharing
+//   a SIMD take ~the SUM of their solo times (64 -> 77 cycles per MFMA, 67 -> 272 cycles per 32 v_fma), and
+//   interleaving VALU between dependent MFMAs of one wave is worse than running them back to back.  So the
+//   ceiling of this kernel is MFMA/(MFMA+VALU) cycles: ~75 % (C=32) / ~86 % (C=64) of the 157 TFLOP/s fp32
+//   matrix peak with the 5-op epilogue; the in-loop efficiency measured with s_memtime is 72 % / 83 %.
+//   What the phase structure buys is order: each wave issues its MFMAs as one uninterrupted dependent chain
+//   (hipcc otherwise interleaves VALU into the chain, the slow case above) and the epilogues run as dense VALU.
+//   Stages (CH codes in fragment order + |e|^2) arrive by LDS-DMA (global_load_lds) into a 2-deep ring.
 // ------------------------------------------------------------------------------------------------
-template <int C, int MODE>
-__global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float *__restrict__ z, long N, int HW,
-                                                                const float *__restrict__ wb,
-                                                                const float *__restrict__ ee, int n_chunks,
-                                                                int chunks_per_split,
-                                                                unsigned long long *__restrict__ keys) {
-    using TL = Tiling<C>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, li = lane & 31;
+template <int MODE>
+__device__ __forceinline__ void epi_reg(float accv, float zz, float e, int code0, float &best, int &bcode) {
+#ifdef XQ_NOEPI
+    asm volatile("" ::"v"(accv)); (void)zz; (void)e; (void)code0; (void)best; (void)bcode;
+    return;
+#endif
+    float d;
+    if (MODE == XQ_MODE_COSINE) d = e - accv;                    // e = 0 (real code) / +inf (padding)
+    else d = __builtin_fmaf(-2.0f, accv, zz + e);                // (A3): 2*dot is exact
+    const bool lt = d < best;                                    // strict: the earlier tile wins ties
+    best = lt ? d : best;
+    bcode = lt ? code0 : bcode;
+}
 
-    // ---- prologue: this lane's token (both wave halves hold the same 32 tokens) ----
-    const long tok0 = (long)blockIdx.x * TOK_PER_BLOCK + wave * 32;
+// prologue shared by the assign kernels: loads this lane's token (both wave halves hold the same 32 tokens),
+// normalises it (A2), leaves the MFMA A fragments in a[] and |zhat|^2 per accumulator row in zzr[].
+template <int C, int MODE>
+__device__ __forceinline__ void load_tokens(const float *__restrict__ z, long N, int HW, long tok0, int lane,
+                                            float (&a)[C / 2], float (&zzr)[16]) {
+    const int h = lane >> 5, li = lane & 31;
     long n = tok0 + li;
     if (n > N - 1) n = N - 1;
     const long b = n / HW;
     const int hw = (int)(n - b * HW);
     const float *base = z + (size_t)b * C * HW + hw;
-    float a[C / 2];
-    float zzr[16];
-    {
-        float x[C], zh[C];
+    // two streaming passes keep register pressure at C/2: pass 1 = norm chain, pass 2 = zhat, |zhat|^2 chain
+    float s = 0.0f;
 #pragma unroll
-        for (int k = 0; k < C; ++k) x[k] = base[(size_t)k * HW];
-        if (MODE == XQ_MODE_L2_RAW) {
+    for (int k = 0; k < C; ++k) { const float x = base[(size_t)k * HW]; s = __builtin_fmaf(x, x, s); }
+    float nrm = __builtin_sqrtf(s);
+    nrm = (nrm > XQ_EPS) ? nrm : XQ_EPS;
+    float zz = 0.0f;
 #pragma unroll
-            for (int k = 0; k < C; ++k) zh[k] = x[k];
-        } else {
-            l2norm_row<C>(x, zh);
-        }
-        float zz = (MODE == XQ_MODE_COSINE) ? 0.0f : chain_sq<C>(zh);
-#pragma unroll
-        for (int t = 0; t < C / 2; ++t) a[t] = h ? zh[2 * t + 1] : zh[2 * t];
-        // accumulator register r of this lane is token row (r&3) + 8*(r>>2) + 4*h of the tile
-#pragma unroll
-        for (int r = 0; r < 16; ++r) zzr[r] = __shfl(zz, (r & 3) + 8 * (r >> 2) + 4 * h);
+    for (int k = 0; k < C; ++k) {
+        const float x = base[(size_t)k * HW];
+        const float zh = (MODE == XQ_MODE_L2_RAW) ? x : x / nrm;
+        zz = __builtin_fmaf(zh, zh, zz);
+        if ((k & 1) == 0) a[k >> 1] = zh;                // even channel: kept by the lower half
+        else a[k >> 1] = h ? zh : a[k >> 1];             // odd channel: kept by the upper half
     }
-
-    float best[16];
-    int bcode[16];
+    if (MODE == XQ_MODE_COSINE) zz = 0.0f;
+    // accumulator register r of this lane is token row (r&3) + 8*(r>>2) + 4*h of the tile
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { best[r] = __builtin_inff(); bcode[r] = 0; }
+    for (int r = 0; r < 16; ++r) zzr[r] = __shfl(zz, (r & 3) + 8 * (r >> 2) + 4 * h);
+}
 
-    const int c0 = blockIdx.y * chunks_per_split;
-    int c1 = c0 + chunks_per_split;
-    if (c1 > n_chunks) c1 = n_chunks;
-
-    constexpr int NST = (TL::STAGE_F4 + ASSIGN_THREADS - 1) / ASSIGN_THREADS;
-    static_assert(TL::STAGE_F4 % ASSIGN_THREADS == 0, "stage size must be a multiple of the block");
-    float4 st[NST];
-    float st_e = 0.0f;
-    auto stage_load = [&](int chunk) {
-        const float4 *src = reinterpret_cast<const float4 *>(wb) + (size_t)chunk * TL::STAGE_F4;
-#pragma unroll
-        for (int i = 0; i < NST; ++i) st[i] = src[tid + i * ASSIGN_THREADS];
-        if (tid < TL::CH) st_e = ee[(size_t)chunk * TL::CH + tid];
-    };
-    auto stage_write = [&](int bufi) {
-        float4 *dst = reinterpret_cast<float4 *>(smem + (size_t)bufi * TL::BUF_BYTES);
-#pragma unroll
-        for (int i = 0; i < NST; ++i) dst[tid + i * ASSIGN_THREADS] = st[i];
-        if (tid < TL::CH) reinterpret_cast<float *>(dst + TL::STAGE_F4)[tid] = st_e;
-    };
-
-    if (c0 < c1) {
-        stage_load(c0);
-        stage_write(0);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    for (int chunk = c0; chunk < c1; ++chunk) {
-        const bool has_next = (chunk + 1 < c1);
-        if (has_next) stage_load(chunk + 1);  // global -> VGPR, lands while the MFMAs below run
-
-        const float4 *bbuf = reinterpret_cast<const float4 *>(smem + (size_t)cur * TL::BUF_BYTES);
-        const float *ebuf = reinterpret_cast<const float *>(bbuf + TL::STAGE_F4);
-#pragma unroll
-        for (int tile = 0; tile < TL::TILES; ++tile) {
-            f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-            const float4 *bt = bbuf + tile * (TL::KQ * 64) + lane;
-#pragma unroll
-            for (int q = 0; q < TL::KQ; ++q) {
-                const float4 bv = bt[q * 64];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 0], bv.x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], bv.y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], bv.z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], bv.w, acc, 0, 0, 0);
-            }
-            const float e = ebuf[tile * 32 + li];
-            const int code0 = chunk * TL::CH + tile * 32;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float d;
-                if (MODE == XQ_MODE_COSINE) d = e - acc[r];                      // e = 0 (real) / +inf (padding)
-                else d = __builtin_fmaf(-2.0f, acc[r], zzr[r] + e);              // (A3): 2*dot exact
-                const bool lt = d < best[r];                                       // strict: first tile wins ties
-                best[r] = lt ? d : best[r];
-                bcode[r] = lt ? code0 : bcode[r];
-            }
-        }
-        if (has_next) stage_write(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    // ---- cross-lane reduction over the 32 code columns of each half, then one atomicMin per token ----
+// cross-lane reduction over the 32 code columns of each half, then one 64-bit atomicMin per token
+__device__ __forceinline__ void publish_best(const float (&best)[16], const int (&bcode)[16], long tok0, long N, int lane,
+                                             unsigned long long *__restrict__ keys) {
+    const int h = lane >> 5, li = lane & 31;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         unsigned long long key = ((unsigned long long)f2ord(best[r]) << 32) | (unsigned)(bcode[r] + li);
@@ -288,6 +250,125 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float *__r
             if (tn < N) atomicMin(keys + tn, key);
         }
     }
+}
+
+#ifdef XQ_DEBUG_STAMPS
+__device__ unsigned long long xq_dbg_stamps[4096 * 8];
+#define XQ_STAMP(i) do { if (threadIdx.x == 0) { xq_dbg_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (i)] = wall_clock64(); \
+    if ((i) == 2) xq_dbg_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + 6] = __builtin_readcyclecounter(); \
+    if ((i) == 3) xq_dbg_stamps[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + 7] = __builtin_readcyclecounter(); } } while (0)
+extern "C" int xq_debug_read_stamps(unsigned long long *host_out) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(xq_dbg_stamps), sizeof(unsigned long long) * 4096 * 8) == hipSuccess ? 0 : -1;
+}
+#else
+#define XQ_STAMP(i)
+#endif
+
+template <int C, int MODE>
+__global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float *__restrict__ z, long N, int HW,
+                                                                const float *__restrict__ wb,
+                                                                const float *__restrict__ ee, int n_chunks,
+                                                                int chunks_per_split,
+                                                                unsigned long long *__restrict__ keys) {
+    using TL = Tiling<C>;
+    constexpr int T = TL::TILES, KQ = TL::KQ;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2;  // wave group: 0 = waves 0-3, 1 = waves 4-7
+    const int li = lane & 31;
+
+    XQ_STAMP(0);
+    const long tok0 = (long)blockIdx.x * TOK_PER_BLOCK + wave * 32;
+    float a[C / 2];
+    float zzr[16];
+    load_tokens<C, MODE>(z, N, HW, tok0, lane, a, zzr);
+    XQ_STAMP(1);
+
+    float best[16];
+    int bcode[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { best[r] = __builtin_inff(); bcode[r] = 0; }
+
+    const int c0 = blockIdx.y * chunks_per_split;
+    int c1 = c0 + chunks_per_split;
+    if (c1 > n_chunks) c1 = n_chunks;
+    const int S = c1 - c0;  // stages of this block
+
+    constexpr int NST = TL::STAGE_F4 / ASSIGN_THREADS;
+    static_assert(TL::STAGE_F4 % ASSIGN_THREADS == 0, "stage size must be a multiple of the block");
+    // LDS-DMA: destination = wave-uniform base + lane*16 — exactly the fragment order of the workspace.
+    auto stage_dma = [&](int chunk, int bufi) {
+        const float4 *src = reinterpret_cast<const float4 *>(wb) + (size_t)chunk * TL::STAGE_F4;
+        float4 *dst = reinterpret_cast<float4 *>(smem + (size_t)bufi * TL::BUF_BYTES);
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int o = i * ASSIGN_THREADS + wave * 64;
+            __builtin_amdgcn_global_load_lds((gbl_void *)(src + o + lane), (lds_void *)(dst + o), 16, 0, 0);
+        }
+        // |e|^2: CH floats; waves beyond CH/64 re-copy an existing 64-float segment (same bytes)
+        const int eo = (wave * 64) & (TL::CH - 1);
+        __builtin_amdgcn_global_load_lds((gbl_void *)(ee + (size_t)chunk * TL::CH + eo + lane),
+                                         (lds_void *)(reinterpret_cast<float *>(dst + TL::STAGE_F4) + eo), 4, 0, 0);
+    };
+
+    if (S > 0) stage_dma(c0, 0);
+    __syncthreads();  // (vmcnt is drained before the barrier: the DMA has landed)
+    XQ_STAMP(2);
+
+    f32x16 acc[T];
+    float pe[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        pe[t] = __builtin_inff();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    }
+
+    // phases 0 .. 2S: group g computes stage s in phase 2s+g and retires it in phase 2s+g+1
+    for (int p = 0; p <= 2 * S; ++p) {
+        const int q = p - grp;
+        if ((p & 1) == 0) {  // even phase: everybody helps to prefetch stage p/2+1 (its buffer was released in phase p-1)
+            const int s_next = (p >> 1) + 1;
+            if (s_next < S) stage_dma(c0 + s_next, s_next & 1);
+        }
+        if (q >= 0 && (q & 1) == 0 && (q >> 1) < S) {
+            // ---- MFMA phase ----
+            const int s_cur = q >> 1;
+            const float4 *bl = reinterpret_cast<const float4 *>(smem + (size_t)(s_cur & 1) * TL::BUF_BYTES) + lane;
+            const float *el = reinterpret_cast<const float *>(bl - lane + TL::STAGE_F4) + li;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                pe[t] = el[t * 32];
+#pragma unroll
+                for (int g = 0; g < KQ; ++g) {
+                    const float4 bv = bl[(t * KQ + g) * 64];
+                    if (g == 0) {
+                        const f32x16 zero = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[0], bv.x, zero, 0, 0, 0);
+                    } else {
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 0], bv.x, acc[t], 0, 0, 0);
+                    }
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 1], bv.y, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 2], bv.z, acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * g + 3], bv.w, acc[t], 0, 0, 0);
+                }
+            }
+        } else if (q >= 1 && (q & 1) == 1) {
+            // ---- epilogue phase: retire stage (q-1)/2 ----
+            const int code_base = (c0 + ((q - 1) >> 1)) * TL::CH;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) epi_reg<MODE>(acc[t][r], zzr[r], pe[t], code_base + t * 32, best[r], bcode[r]);
+            }
+        }
+        __syncthreads();
+    }
+    XQ_STAMP(3);
+    XQ_STAMP(4);
+    publish_best(best, bcode, tok0, N, lane, keys);
+    XQ_STAMP(5);
 }
 
 // keys -> idx (+ optional winning score)
@@ -443,25 +524,27 @@ static int launch_assign_t(const float *z, long N, int HW, const float *E, int V
     const int Vpad = ws.Vpad;
     hipLaunchKernelGGL((prep_codebook_kernel<C, MODE>), dim3((Vpad + 255) / 256), dim3(256), 0, s, E, V, Vpad, ws.wb, ws.ee);
     if (hipMemsetAsync(ws.keys, 0xFF, (size_t)N * 8, s) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipMemsetAsync(keys) failed");
-    const int n_chunks = Vpad / TL::CH;
-    const int tok_blocks = (int)((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK);
-    // split the code axis so that the grid covers the chip (>= 2 blocks per CU when possible)
-    int want = (2 * num_cus() + tok_blocks - 1) / tok_blocks;
-    if (want < 1) want = 1;
-    if (want > n_chunks) want = n_chunks;
-    const int cps = (n_chunks + want - 1) / want;
-    const int splits = (n_chunks + cps - 1) / cps;
-    const size_t lds = 2 * (size_t)TL::BUF_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
     const int pslot = prof_slot();
-    if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][0], s);
-    hipLaunchKernelGGL((assign_kernel<C, MODE>), dim3(tok_blocks, splits), dim3(ASSIGN_THREADS), lds, s, z, N, HW, ws.wb, ws.ee,
-                       n_chunks, cps, ws.keys);
-    if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][1], s);
+    {
+        const int n_chunks = Vpad / TL::CH;
+        const int tok_blocks = (int)((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK);
+        // split the code axis so that the grid covers the chip once (1 block of 8 waves per CU)
+        int want = (XQ_LDS_BPC * num_cus() + tok_blocks - 1) / tok_blocks;
+        if (want < 1) want = 1;
+        if (want > n_chunks) want = n_chunks;
+        const int cps = (n_chunks + want - 1) / want;
+        const int splits = (n_chunks + cps - 1) / cps;
+        const size_t lds = 2 * (size_t)TL::BUF_BYTES;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+        if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][0], s);
+        hipLaunchKernelGGL((assign_kernel<C, MODE>), dim3(tok_blocks, splits), dim3(ASSIGN_THREADS), lds, s, z, N, HW, ws.wb, ws.ee,
+                           n_chunks, cps, ws.keys);
+        if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][1], s);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "assign_kernel<C=%d>: %s", C, hipGetErrorString(e)); return XQ_ELAUNCH; }
     return XQ_OK;
@@ -488,6 +571,7 @@ static int launch_assign(int mode, int C, const float *z, long N, int HW, const 
 }
 
 static int check_common(const char *fn, const void *z, int B, int C, int HW, const void *E, int V) {
+    if (B == 0) return XQ_OK; /* empty batch: nothing to validate against, callers return early */
     if (!z || !E) return xq_set_error(XQ_EINVAL, "%s: null input pointer", fn);
     if (B < 0 || HW < 1 || V < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape (B=%ld, HW=%ld)", fn, B, HW);
     if (C != 8 && C != 16 && C != 32 && C != 64)

@@ -50,6 +50,8 @@ def assign(z: torch.Tensor, codebook: torch.Tensor, mode: int, return_best: bool
     N = B * HW
     idx = torch.empty(N, dtype=torch.int64, device=z.device)
     best = torch.empty(N, dtype=torch.float32, device=z.device) if return_best else None
+    if N == 0:
+        return (idx, best) if return_best else idx
     ws = _workspace(N, C, V, z.device)
     with torch.cuda.device(z.device):
         rc = _lib.lib().xq_assign(ptr(z), B, C, HW, ptr(E), V, mode, ptr(idx), ptr(best), ptr(ws), ws.numel(), _stream(z))
@@ -72,7 +74,9 @@ def vq_forward_raw(z: torch.Tensor, codebook: torch.Tensor, codebook_norm: bool,
     zq = torch.empty_like(z) if want_zq else None
     idx = torch.empty(N, dtype=torch.int64, device=dev)
     hist = torch.zeros(V, dtype=torch.float32, device=dev) if want_hist else None
-    loss = torch.empty(1, dtype=torch.float32, device=dev) if want_loss else None
+    loss = torch.zeros(1, dtype=torch.float32, device=dev) if want_loss else None
+    if N == 0:
+        return zq, idx, hist, loss
     ws = _workspace(N, C, V, dev)
     with torch.cuda.device(dev):
         rc = _lib.lib().xq_vq_forward(ptr(z), B, C, HW, ptr(E), V, int(bool(codebook_norm)), int(bool(ste)), ptr(zq),
