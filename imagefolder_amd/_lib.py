@@ -27,6 +27,19 @@ SIGNATURES = {
                                      ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
     "xq_vq_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp,
                                       vp, vp, vp, ctypes.c_float, vp, vp, vp]),
+    "xq_perturb_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
+    "xq_perturb_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "xq_perturb_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp,
+                                           vp, vp]),
+    "xq_msvq_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "xq_msvq_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int,
+                                       c_i32p, ctypes.c_int, c_i32p, vp, vp, ctypes.c_float, ctypes.c_int, vp, ctypes.c_int,
+                                       vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "xq_msvq_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int] * 5),
+    "xq_msvq_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p,
+                                        ctypes.c_int, c_i32p, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
+                                        vp, vp, vp, vp, ctypes.c_size_t, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }

@@ -54,6 +54,41 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// nearest-code search modes (same values as include/xq_ops.h)
+enum { MODE_L2_NORMED = 0, MODE_L2_RAW = 1, MODE_COSINE = 2 };
+
+// prologue shared by the assign kernels: loads this lane's token (both wave halves hold the same 32 tokens),
+// normalises it (A2), leaves the MFMA A fragments in a[] and |zhat|^2 per accumulator row in zzr[].
+template <int C, int MODE>
+__device__ __forceinline__ void load_tokens(const float *__restrict__ z, long N, int HW, long tok0, int lane,
+                                            float (&a)[C / 2], float (&zzr)[16]) {
+    const int h = lane >> 5, li = lane & 31;
+    long n = tok0 + li;
+    if (n > N - 1) n = N - 1;
+    const long b = n / HW;
+    const int hw = (int)(n - b * HW);
+    const float *base = z + (size_t)b * C * HW + hw;
+    // two streaming passes keep register pressure at C/2: pass 1 = norm chain, pass 2 = zhat, |zhat|^2 chain
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) { const float x = base[(size_t)k * HW]; s = __builtin_fmaf(x, x, s); }
+    float nrm = __builtin_sqrtf(s);
+    nrm = (nrm > XQ_EPS) ? nrm : XQ_EPS;
+    float zz = 0.0f;
+#pragma unroll
+    for (int k = 0; k < C; ++k) {
+        const float x = base[(size_t)k * HW];
+        const float zh = (MODE == MODE_L2_RAW) ? x : x / nrm;
+        zz = __builtin_fmaf(zh, zh, zz);
+        if ((k & 1) == 0) a[k >> 1] = zh;                // even channel: kept by the lower half
+        else a[k >> 1] = h ? zh : a[k >> 1];             // odd channel: kept by the upper half
+    }
+    if (MODE == MODE_COSINE) zz = 0.0f;
+    // accumulator register r of this lane is token row (r&3) + 8*(r>>2) + 4*h of the tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zzr[r] = __shfl(zz, (r & 3) + 8 * (r >> 2) + 4 * h);
+}
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace xq

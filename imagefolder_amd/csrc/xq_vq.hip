@@ -19,6 +19,7 @@
 //                      loss partials, histogram atomics.   (HBM-bound: 8C+8 bytes per token.)
 // Roofline: K1 is fp32-MFMA bound: 2*N*V*C flop; K2/backward are HBM bound.
 #include "xq_common.hpp"
+#include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
 
 #include <stdio.h>
@@ -32,10 +33,16 @@ typedef const __attribute__((address_space(1))) void gbl_void;
 // ------------------------------------------------------------------------------------------------
 // error plumbing
 // ------------------------------------------------------------------------------------------------
-static thread_local char g_err[512] = "";
-static int xq_set_error(int code, const char *fmt, const char *a = "", long b = 0, long c = 0) {
+thread_local char g_err[512] = "";
+int xq_set_error(int code, const char *fmt, const char *a, long b, long c) {
     snprintf(g_err, sizeof(g_err), fmt, a, b, c);
     return code;
+}
+int xq_check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return XQ_OK;
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return XQ_ELAUNCH;
 }
 extern "C" const char *xq_last_error(void) { return g_err; }
 extern "C" int xq_abi_version(void) { return XQ_ABI_VERSION; }
@@ -91,35 +98,6 @@ template <int C> struct Tiling {
 static constexpr int ASSIGN_THREADS = 512;                 // 8 waves = 2 anti-phase wave groups x 4 SIMDs
 static constexpr int TOK_PER_BLOCK = ASSIGN_THREADS / 2;   // one 32-token MFMA row tile per wave
 
-static inline int chunk_codes(int C) { return C == 8 ? 256 : (C <= 64 ? 128 : 64); }
-
-struct AssignWs {
-    float *wb;                 // [Vpad/32][C/8][64 lanes][4]  fragment-ordered ehat
-    float *ee;                 // [Vpad]
-    unsigned long long *keys;  // [N]
-    float *partials;           // [4096]
-    int Vpad;
-};
-static constexpr int MAX_PARTIALS = 4096;
-
-static size_t assign_ws_layout(int64_t N, int C, int V, char *base, AssignWs *ws) {
-    const int CH = chunk_codes(C);
-    const int Vpad = (V + CH - 1) / CH * CH;
-    size_t off = 0;
-    auto take = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    size_t o_wb = take((size_t)Vpad * C * 4);
-    size_t o_ee = take((size_t)Vpad * 4);
-    size_t o_keys = take((size_t)N * 8);
-    size_t o_part = take((size_t)MAX_PARTIALS * 4);
-    if (ws) {
-        ws->wb = (float *)(base + o_wb);
-        ws->ee = (float *)(base + o_ee);
-        ws->keys = (unsigned long long *)(base + o_keys);
-        ws->partials = (float *)(base + o_part);
-        ws->Vpad = Vpad;
-    }
-    return off;
-}
 
 extern "C" size_t xq_assign_workspace_bytes(int64_t N, int C, int V) {
     if (N < 0 || V < 1 || C < 1) return 0;
@@ -199,38 +177,6 @@ __device__ __forceinline__ void epi_reg(float accv, float zz, float e, int code0
     const bool lt = d < best;                                    // strict: the earlier tile wins ties
     best = lt ? d : best;
     bcode = lt ? code0 : bcode;
-}
-
-// prologue shared by the assign kernels: loads this lane's token (both wave halves hold the same 32 tokens),
-// normalises it (A2), leaves the MFMA A fragments in a[] and |zhat|^2 per accumulator row in zzr[].
-template <int C, int MODE>
-__device__ __forceinline__ void load_tokens(const float *__restrict__ z, long N, int HW, long tok0, int lane,
-                                            float (&a)[C / 2], float (&zzr)[16]) {
-    const int h = lane >> 5, li = lane & 31;
-    long n = tok0 + li;
-    if (n > N - 1) n = N - 1;
-    const long b = n / HW;
-    const int hw = (int)(n - b * HW);
-    const float *base = z + (size_t)b * C * HW + hw;
-    // two streaming passes keep register pressure at C/2: pass 1 = norm chain, pass 2 = zhat, |zhat|^2 chain
-    float s = 0.0f;
-#pragma unroll
-    for (int k = 0; k < C; ++k) { const float x = base[(size_t)k * HW]; s = __builtin_fmaf(x, x, s); }
-    float nrm = __builtin_sqrtf(s);
-    nrm = (nrm > XQ_EPS) ? nrm : XQ_EPS;
-    float zz = 0.0f;
-#pragma unroll
-    for (int k = 0; k < C; ++k) {
-        const float x = base[(size_t)k * HW];
-        const float zh = (MODE == XQ_MODE_L2_RAW) ? x : x / nrm;
-        zz = __builtin_fmaf(zh, zh, zz);
-        if ((k & 1) == 0) a[k >> 1] = zh;                // even channel: kept by the lower half
-        else a[k >> 1] = h ? zh : a[k >> 1];             // odd channel: kept by the upper half
-    }
-    if (MODE == XQ_MODE_COSINE) zz = 0.0f;
-    // accumulator register r of this lane is token row (r&3) + 8*(r>>2) + 4*h of the tile
-#pragma unroll
-    for (int r = 0; r < 16; ++r) zzr[r] = __shfl(zz, (r & 3) + 8 * (r >> 2) + 4 * h);
 }
 
 // cross-lane reduction over the 32 code columns of each half, then one 64-bit atomicMin per token
@@ -372,7 +318,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void assign_kernel(const float *__r
 }
 
 // keys -> idx (+ optional winning score)
-__global__ __launch_bounds__(256) void keys_to_idx_kernel(const unsigned long long *__restrict__ keys, long N,
+__global__ __launch_bounds__(256) void keys_to_idx_kernel_(const unsigned long long *__restrict__ keys, long N,
                                                           int64_t *__restrict__ idx, float *__restrict__ best) {
     const long n = (long)blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
@@ -508,7 +454,7 @@ __global__ __launch_bounds__(256) void vq_backward_kernel(const float *__restric
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
 static int g_num_cus = 0;
-static int num_cus() {
+int num_cus() {
     if (g_num_cus == 0) {
         int dev = 0;
         hipDeviceProp_t p;
@@ -519,10 +465,12 @@ static int num_cus() {
 }
 
 template <int C, int MODE>
-static int launch_assign_t(const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s) {
+static int launch_assign_t(const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s, int what) {
     using TL = Tiling<C>;
     const int Vpad = ws.Vpad;
-    hipLaunchKernelGGL((prep_codebook_kernel<C, MODE>), dim3((Vpad + 255) / 256), dim3(256), 0, s, E, V, Vpad, ws.wb, ws.ee);
+    if (what & XQI_PREP)
+        hipLaunchKernelGGL((prep_codebook_kernel<C, MODE>), dim3((Vpad + 255) / 256), dim3(256), 0, s, E, V, Vpad, ws.wb, ws.ee);
+    if (!(what & XQI_SEARCH)) return xq_check_launch("prep_codebook_kernel");
     if (hipMemsetAsync(ws.keys, 0xFF, (size_t)N * 8, s) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipMemsetAsync(keys) failed");
     const int pslot = prof_slot();
     {
@@ -551,26 +499,26 @@ static int launch_assign_t(const float *z, long N, int HW, const float *E, int V
 }
 
 template <int C>
-static int launch_assign_c(int mode, const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s) {
+static int launch_assign_c(int mode, const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s, int what) {
     switch (mode) {
-        case XQ_MODE_L2_NORMED: return launch_assign_t<C, XQ_MODE_L2_NORMED>(z, N, HW, E, V, ws, s);
-        case XQ_MODE_L2_RAW: return launch_assign_t<C, XQ_MODE_L2_RAW>(z, N, HW, E, V, ws, s);
-        case XQ_MODE_COSINE: return launch_assign_t<C, XQ_MODE_COSINE>(z, N, HW, E, V, ws, s);
+        case XQ_MODE_L2_NORMED: return launch_assign_t<C, XQ_MODE_L2_NORMED>(z, N, HW, E, V, ws, s, what);
+        case XQ_MODE_L2_RAW: return launch_assign_t<C, XQ_MODE_L2_RAW>(z, N, HW, E, V, ws, s, what);
+        case XQ_MODE_COSINE: return launch_assign_t<C, XQ_MODE_COSINE>(z, N, HW, E, V, ws, s, what);
     }
     return xq_set_error(XQ_EINVAL, "%s: unknown mode %ld", "xq_assign", mode);
 }
 
-static int launch_assign(int mode, int C, const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s) {
+int launch_assign(int mode, int C, const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s, int what) {
     switch (C) {
-        case 8: return launch_assign_c<8>(mode, z, N, HW, E, V, ws, s);
-        case 16: return launch_assign_c<16>(mode, z, N, HW, E, V, ws, s);
-        case 32: return launch_assign_c<32>(mode, z, N, HW, E, V, ws, s);
-        case 64: return launch_assign_c<64>(mode, z, N, HW, E, V, ws, s);
+        case 8: return launch_assign_c<8>(mode, z, N, HW, E, V, ws, s, what);
+        case 16: return launch_assign_c<16>(mode, z, N, HW, E, V, ws, s, what);
+        case 32: return launch_assign_c<32>(mode, z, N, HW, E, V, ws, s, what);
+        case 64: return launch_assign_c<64>(mode, z, N, HW, E, V, ws, s, what);
     }
     return xq_set_error(XQ_EINVAL, "%s: unsupported channel count C=%ld (supported: 8,16,32,64)", "xq_assign", C);
 }
 
-static int check_common(const char *fn, const void *z, int B, int C, int HW, const void *E, int V) {
+int check_common(const char *fn, const void *z, int B, int C, int HW, const void *E, int V) {
     if (B == 0) return XQ_OK; /* empty batch: nothing to validate against, callers return early */
     if (!z || !E) return xq_set_error(XQ_EINVAL, "%s: null input pointer", fn);
     if (B < 0 || HW < 1 || V < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape (B=%ld, HW=%ld)", fn, B, HW);
@@ -594,7 +542,7 @@ extern "C" int xq_assign(const float *z, int B, int C, int HW, const float *E, i
     hipStream_t s = (hipStream_t)stream;
     rc = launch_assign(mode, C, z, N, HW, E, V, ws, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(keys_to_idx_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, ws.keys, N, idx, best);
+    hipLaunchKernelGGL(keys_to_idx_kernel_, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, ws.keys, N, idx, best);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "keys_to_idx_kernel: %s", hipGetErrorString(e)); return XQ_ELAUNCH; }
     return XQ_OK;

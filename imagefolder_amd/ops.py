@@ -125,3 +125,164 @@ class VQStraightThrough(torch.autograd.Function):
                                            ptr(gv), ptr(gc), ctypes.c_float(ctx.beta), ptr(g_z), ptr(g_E), _stream(z32))
         check(rc, "xq_vq_backward")
         return g_z.to(ctx.in_dtype), g_E.to(weight.dtype), None, None
+
+
+def perturb_forward_raw(z, z_q, codebook, codebook_norm: bool, n_pert: int, rank):
+    """xq_perturb_forward on detached inputs -> (out, sel_idx|None). rank: int32 (>= n_pert*HW,) device tensor."""
+    _require_gpu(z, "z"); _require_gpu(z_q, "z_q"); _require_gpu(codebook, "codebook")
+    zf = z.detach().float().contiguous()
+    zq = z_q.detach().float().contiguous()
+    E = codebook.detach().float().contiguous()
+    B, C, HW = _as_bc_hw(zf)
+    V = E.shape[0]
+    if zq.shape != zf.shape:
+        raise XqError(f"z {tuple(zf.shape)} and z_q {tuple(zq.shape)} differ")
+    n_pert = int(n_pert)
+    Tp = n_pert * HW
+    out = torch.empty_like(zf)
+    sel = torch.empty(Tp, dtype=torch.int64, device=zf.device) if Tp > 0 else None
+    rk = None
+    if Tp > 0:
+        rk = rank[:Tp].to(torch.int32).contiguous()
+    nbytes = _lib.lib().xq_perturb_workspace_bytes(Tp, C, V)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=zf.device)
+    if B * HW > 0:
+        with torch.cuda.device(zf.device):
+            rc = _lib.lib().xq_perturb_forward(ptr(zf), ptr(zq), ptr(E), B, C, HW, V, int(bool(codebook_norm)), n_pert, ptr(rk),
+                                               ptr(out), ptr(sel), ptr(ws), ws.numel(), _stream(zf))
+        check(rc, "xq_perturb_forward")
+    return out, sel
+
+
+class PerturbStraightThrough(torch.autograd.Function):
+    """add_perturbation (latent_perturbation.py:4-35) with the rank draws passed in."""
+
+    @staticmethod
+    def forward(ctx, z, z_q, weight, codebook_norm: bool, n_pert: int, rank):
+        out, sel = perturb_forward_raw(z, z_q, weight, codebook_norm, n_pert, rank)
+        ctx.save_for_backward(z.detach().float().contiguous())
+        ctx.codebook_norm = bool(codebook_norm)
+        ctx.n_pert = int(n_pert)
+        ctx.dtypes = (z.dtype, z_q.dtype)
+        ctx.sel = sel
+        return out.view(z.shape)
+
+    @staticmethod
+    def backward(ctx, g_out):
+        (z32,) = ctx.saved_tensors
+        B, C, HW = _as_bc_hw(z32)
+        g = g_out.float().contiguous()
+        g_z = torch.empty_like(z32)
+        g_zq = torch.empty_like(z32)
+        if B * HW > 0:
+            with torch.cuda.device(z32.device):
+                rc = _lib.lib().xq_perturb_backward(ptr(z32), B, C, HW, int(ctx.codebook_norm), ctx.n_pert, ptr(g), ptr(g_z),
+                                                    ptr(g_zq), _stream(z32))
+            check(rc, "xq_perturb_backward")
+        return g_z.to(ctx.dtypes[0]), g_zq.to(ctx.dtypes[1]), None, None, None, None
+
+
+def _i32_array(vals):
+    arr = (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+    return arr
+
+
+def msvq_forward_raw(f, codebook, patch_nums, phi_sel, phi_w, phi_b, phi_ratio, using_znorm, n_quant, skip_last_pool,
+                     want_ste=True, want_saved=False, want_sq=True, want_hist=False, want_scales=False):
+    """xq_msvq_forward on detached inputs. Returns dict(idx_all, f_hat, f_hat_ste, h_scales, u_scales, sq_sum, hist,
+    f_hat_scales) (entries not requested are None)."""
+    _require_gpu(f, "f"); _require_gpu(codebook, "codebook")
+    f32 = f.detach().float().contiguous()
+    E = codebook.detach().float().contiguous()
+    if f32.dim() != 4:
+        raise XqError(f"expected (B,C,H,W), got {tuple(f32.shape)}")
+    B, C, H, W = f32.shape
+    V = E.shape[0]
+    SN = len(patch_nums)
+    dev = f32.device
+    n_tok = B * sum(int(p) * int(p) for p in patch_nums)
+    n_phi = 0 if phi_w is None else int(phi_w.shape[0])
+    out = dict(idx_all=torch.empty(n_tok, dtype=torch.int64, device=dev), f_hat=torch.empty_like(f32),
+               f_hat_ste=torch.empty_like(f32) if want_ste else None,
+               h_scales=torch.empty((SN,) + f32.shape, device=dev) if want_saved else None,
+               u_scales=torch.empty((SN,) + f32.shape, device=dev) if (want_saved and n_phi > 0) else None,
+               sq_sum=torch.zeros(SN, device=dev) if want_sq else None,
+               hist=torch.zeros(SN, V, device=dev) if want_hist else None,
+               f_hat_scales=torch.empty((SN,) + f32.shape, device=dev) if want_scales else None)
+    if B == 0:
+        return out
+    pw = None if n_phi == 0 else phi_w.detach().float().contiguous()
+    pb = None if n_phi == 0 else phi_b.detach().float().contiguous()
+    nq = None if n_quant is None else n_quant.detach().float().contiguous().to(dev)
+    nbytes = _lib.lib().xq_msvq_workspace_bytes(B, C, H, W, V)
+    ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().xq_msvq_forward(ptr(f32), B, C, H, W, ptr(E), V, int(bool(using_znorm)), _i32_array(patch_nums), SN,
+                                        _i32_array(phi_sel if n_phi else [0] * SN), ptr(pw), ptr(pb),
+                                        ctypes.c_float(float(phi_ratio)), n_phi, ptr(nq), int(bool(skip_last_pool)),
+                                        ptr(out["idx_all"]), ptr(out["f_hat"]), ptr(out["f_hat_ste"]), ptr(out["h_scales"]),
+                                        ptr(out["u_scales"]), ptr(out["sq_sum"]), ptr(out["hist"]), ptr(out["f_hat_scales"]),
+                                        ptr(ws), ws.numel(), _stream(f32))
+    check(rc, "xq_msvq_forward")
+    return out
+
+
+class MSVQLadder(torch.autograd.Function):
+    """VectorQuantizer2.forward ladder (quant.py:64-135) as one differentiable op.
+
+    forward(f, weight, phi_w, phi_b, n_quant, cfg) -> (f_hat_ste, sq_vq (SN,), sq_commit (SN,), idx_all, hist)
+    sq_vq and sq_commit hold the same numbers (sum mask*(f_hat_s - f)^2) but route gradients differently:
+    sq_vq -> f_hat_s (codebook + Phi), sq_commit -> f.  cfg = dict(patch_nums, phi_sel, phi_ratio, using_znorm,
+    skip_last_pool).
+    """
+
+    @staticmethod
+    def forward(ctx, f, weight, phi_w, phi_b, n_quant, cfg):
+        r = msvq_forward_raw(f, weight, cfg["patch_nums"], cfg["phi_sel"], phi_w, phi_b, cfg["phi_ratio"], cfg["using_znorm"],
+                             n_quant, cfg["skip_last_pool"], want_ste=True, want_saved=True, want_sq=True, want_hist=True)
+        ctx.cfg = cfg
+        ctx.in_dtype = f.dtype
+        ctx.n_phi = 0 if phi_w is None else int(phi_w.shape[0])
+        saved = [f.detach().float().contiguous(), weight.detach(), r["idx_all"], r["h_scales"]]
+        if ctx.n_phi:
+            saved += [r["u_scales"], phi_w.detach().float().contiguous()]
+        ctx.has_nq = n_quant is not None
+        if ctx.has_nq:
+            saved.append(n_quant.detach().float().contiguous().to(f.device))
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(r["idx_all"], r["hist"])
+        return r["f_hat_ste"], r["sq_sum"], r["sq_sum"].clone(), r["idx_all"], r["hist"]
+
+    @staticmethod
+    def backward(ctx, g_out, g_sq_vq, g_sq_commit, _gi, _gh):
+        saved = list(ctx.saved_tensors)
+        f32, weight, idx_all, h_scales = saved[:4]
+        pos = 4
+        u_scales = phi_w = None
+        if ctx.n_phi:
+            u_scales, phi_w = saved[4], saved[5]
+            pos = 6
+        nq = saved[pos] if ctx.has_nq else None
+        cfg = ctx.cfg
+        B, C, H, W = f32.shape
+        V = weight.shape[0]
+        SN = len(cfg["patch_nums"])
+        dev = f32.device
+        g_f = torch.empty_like(f32)
+        g_E = torch.zeros(V, C, dtype=torch.float32, device=dev)
+        g_pw = torch.zeros_like(phi_w) if ctx.n_phi else None
+        g_pb = torch.zeros(ctx.n_phi, C, dtype=torch.float32, device=dev) if ctx.n_phi else None
+        go = None if g_out is None else g_out.float().contiguous()
+        gv = None if g_sq_vq is None else g_sq_vq.float().contiguous()
+        gc = None if g_sq_commit is None else g_sq_commit.float().contiguous()
+        nbytes = _lib.lib().xq_msvq_backward_workspace_bytes(B, C, H, W, SN)
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        if B > 0:
+            with torch.cuda.device(dev):
+                rc = _lib.lib().xq_msvq_backward(ptr(f32), B, C, H, W, V, _i32_array(cfg["patch_nums"]), SN,
+                                                 _i32_array(cfg["phi_sel"] if ctx.n_phi else [0] * SN), ptr(phi_w),
+                                                 ctypes.c_float(float(cfg["phi_ratio"])), ctx.n_phi, ptr(nq), ptr(idx_all),
+                                                 ptr(h_scales), ptr(u_scales), ptr(go), ptr(gv), ptr(gc), ptr(g_f), ptr(g_E),
+                                                 ptr(g_pw), ptr(g_pb), ptr(ws), ws.numel(), _stream(f32))
+            check(rc, "xq_msvq_backward")
+        return g_f.to(ctx.in_dtype), g_E.to(weight.dtype), g_pw, g_pb, None, None

@@ -80,6 +80,65 @@ int xq_vq_backward(const float *z, int B, int C, int HW, const float *E, int V, 
                    const int64_t *idx, const float *g_out, const float *g_vq, const float *g_commit, float beta,
                    float *g_z, float *g_E, xq_stream_t stream);
 
+/* ---- RobustTok latent perturbation (latent_perturbation.py:4-35) --------------------------------------- */
+
+size_t xq_perturb_workspace_bytes(int64_t n_pert_tokens, int C, int V);
+
+/*
+ * out = where(sample < n_pert, zhat + sg(norm(E[pick]) - zhat), zq_in)     (latent_perturbation.py:26-35)
+ *   pick_n = the code with the rank[n]-th smallest distance to token n (0-based; ties -> lower index), i.e.
+ *   topk(d, delta, largest=False)[rank[n]] (:20-24).  The caller draws rank (:21-23:
+ *   rank = rand > alpha ? 0 : randint(0, delta)) — device int32 [n_pert*HW]; n_pert = int(B*beta) (:32).
+ *   z (= encoder latent h), zq_in (= quantizer output), out: [B][C][HW]; sel_idx (nullable) int64 [n_pert*HW].
+ */
+int xq_perturb_forward(const float *z, const float *zq_in, const float *E, int B, int C, int HW, int V,
+                       int codebook_norm, int n_pert, const int32_t *rank, float *out, int64_t *sel_idx,
+                       void *workspace, size_t workspace_bytes, xq_stream_t stream);
+
+/* backward of the above: g_z = normalise-Jacobian(g_out) for perturbed samples (else 0); g_zq = g_out for the
+ * others (else 0).  No gradient reaches the codebook. */
+int xq_perturb_backward(const float *z, int B, int C, int HW, int codebook_norm, int n_pert, const float *g_out,
+                        float *g_z, float *g_zq, xq_stream_t stream);
+
+/* ---- VectorQuantizer2: multi-scale residual ladder (tokenizer_image/quant.py:13-258; models/quant.py) ------ */
+
+size_t xq_msvq_workspace_bytes(int B, int C, int H, int W, int V);
+
+/*
+ * Forward ladder of VectorQuantizer2.forward (quant.py:64-144) and f_to_idxBl_or_fhat (:182-223).
+ *   f [B][C][H][W] (H == W <= 16); E [V][C]; using_znorm -> cosine argmax (:93-94) else raw L2 argmin (:96-101).
+ *   patch_nums, phi_sel: HOST int32 arrays [SN] (SN <= 16): scale sizes and, per scale, which of the n_phi residual
+ *     convs applies (the reference picks it with numpy in PhiPartiallyShared.__getitem__, quant.py:285-288; that
+ *     selection stays in the host mirror).  phi_w [n_phi][C][C][3][3], phi_b [n_phi][C]: device; n_phi = 0 -> identity.
+ *   n_quant (nullable) device fp32 [B]: scale si contributes to sample b iff si < n_quant[b] (:79-86,115).
+ *   skip_last_pool: the caller's evaluation of "last scale reads f_rest directly" (:91-92 vs the hard-coded 16 at :201).
+ * Outputs (device): idx_all int64 [B*sum(pn^2)] (scale-major, then sample, then position); f_hat = masked sum (:116);
+ *   f_hat_ste (nullable) = (f_hat - f) + f (:135); h_scales / u_scales (nullable) [SN][B][C][H][W] = per-scale
+ *   post-/pre-Phi maps kept for the backward; sq_sum (nullable) [SN] = sum mask*(f_hat_s - f)^2 (:131-132 numerators);
+ *   hist (nullable) [SN][V] ACCUMULATES bincounts (:102); f_hat_scales (nullable) [SN][B][C][H][W] cumulative f_hat (:221).
+ */
+int xq_msvq_forward(const float *f, int B, int C, int H, int W, const float *E, int V, int using_znorm,
+                    const int32_t *patch_nums, int SN, const int32_t *phi_sel, const float *phi_w, const float *phi_b,
+                    float phi_ratio, int n_phi, const float *n_quant, int skip_last_pool, int64_t *idx_all, float *f_hat,
+                    float *f_hat_ste, float *h_scales, float *u_scales, float *sq_sum, float *hist, float *f_hat_scales,
+                    void *workspace, size_t workspace_bytes, xq_stream_t stream);
+
+size_t xq_msvq_backward_workspace_bytes(int B, int C, int H, int W, int SN);
+
+/*
+ * Backward of VectorQuantizer2.forward (formulas: SURVEY.md §8a).  The forward returns the loss NUMERATORS
+ * sq_sum[s]; the host forms mean_vq_loss / mean_commit_loss from them (quant.py:129-134; models/quant.py:95), so the
+ * upstream grads arrive per scale: g_sq_vq[s] = dL/d(sum m (f_hat_s - sg f)^2) flows into f_hat_s (hence into
+ * E and Phi), g_sq_commit[s] = dL/d(sum m (sg f_hat_s - f)^2) flows into f.  Both are DEVICE fp32 [SN], nullable.
+ * g_out (nullable): grad of the returned f_hat (identity to f, :135).  g_f is overwritten; g_E [V][C], g_phi_w,
+ * g_phi_b are ACCUMULATED into (caller zeroes them).
+ */
+int xq_msvq_backward(const float *f, int B, int C, int H, int W, int V, const int32_t *patch_nums, int SN,
+                     const int32_t *phi_sel, const float *phi_w, float phi_ratio, int n_phi, const float *n_quant,
+                     const int64_t *idx_all, const float *h_scales, const float *u_scales, const float *g_out,
+                     const float *g_sq_vq, const float *g_sq_commit, float *g_f, float *g_E, float *g_phi_w,
+                     float *g_phi_b, void *workspace, size_t workspace_bytes, xq_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
  *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the
  *      recorded events and returns the summed duration and launch count since arming. ------------------ */

@@ -52,8 +52,92 @@ def gen_vq(name, V, C, B, H, W, seed, codebook_norm=True, beta=0.25, z_scale=1.0
     print("wrote", name, "usage", usage[0], "vq", vq.item())
 
 
+def gen_perturb(name, V, C, B, H, W, seed, alpha, beta, delta, codebook_norm=True):
+    """add_perturbation (latent_perturbation.py:4-35), with the RNG draws recorded."""
+    R = load_reference()
+    torch.manual_seed(seed)
+    q = R["VectorQuantizer"](V, C, 0.25, codebook_norm).train()
+    z = (torch.randn(B, C, H, W) * (1.0 if codebook_norm else 0.02)).requires_grad_(True)
+    with torch.no_grad():
+        zq0 = q.f_to_idxBl_or_fhat(z.detach(), to_fhat=True, v_patch_nums=None)[0]
+    zq_in = (zq0 + 0.01 * torch.randn_like(zq0)).requires_grad_(True)  # any tensor may arrive as z_q
+    N = B * H * W
+    torch.manual_seed(seed + 1000)
+    out = R["add_perturbation"](z, zq_in, C, codebook_norm, q.embedding, alpha, beta, delta)
+    torch.manual_seed(seed + 1000)  # replay the two draws (latent_perturbation.py:21-22)
+    random_prob = torch.rand(N)
+    random_idx = torch.randint(0, delta, (N,))
+    rank = torch.where(random_prob > alpha, torch.zeros_like(random_idx), random_idx)
+    g_out = torch.randn_like(out) * 0.1
+    (out * g_out).sum().backward()
+    np.savez(os.path.join(OUT, name + ".npz"), z=z.detach().numpy(), zq_in=zq_in.detach().numpy(),
+             E=q.embedding.weight.detach().numpy(), codebook_norm=np.int32(codebook_norm), alpha=np.float32(alpha),
+             beta=np.float32(beta), delta=np.int32(delta), rank=rank.numpy().astype(np.int32), out=out.detach().numpy(),
+             g_out=g_out.numpy(), g_z=z.grad.numpy(), g_zq=zq_in.grad.numpy(), meta=np.array(str(meta())))
+    print("wrote", name, "n_pert", int(B * beta), "ranks>0:", int((rank[: int(B * beta) * H * W] > 0).sum()))
+
+
+def gen_msvq(name, V, C, B, pns, seed, codebook_drop=0.1, start_drop=3, using_znorm=True, share=4, var_variant=False):
+    """VectorQuantizer2.forward/backward + f_to_idxBl_or_fhat (tokenizer_image/quant.py:64-223) or, with
+    var_variant, the original models/quant.py quantizer."""
+    R = load_reference()
+    torch.manual_seed(seed)
+    H = W = pns[-1]
+    if var_variant:
+        q = R["var_quant"].VectorQuantizer2(V, C, using_znorm, beta=0.25, v_patch_nums=tuple(pns), share_quant_resi=share).train()
+    else:
+        q = R["VectorQuantizer2"](V, C, using_znorm=using_znorm, v_patch_nums=list(pns), num_latent_tokens=H * W,
+                                  share_quant_resi=share, codebook_drop=codebook_drop).train()
+    if not using_znorm:
+        q.embedding.weight.data.mul_(30.0)  # raw-L2 path: codebook and latents on comparable scales
+    f = (torch.randn(B, C, H, W) * 0.6).requires_grad_(True)
+    dropout = torch.randint(start_drop, len(pns) + 1, (B,))
+    if var_variant:
+        f_hat, usages, vq = q(f, ret_usages=True)
+        commit = torch.zeros(())
+    else:
+        f_hat, usages, vq, commit, _ = q(f, ret_usages=True, dropout=dropout)
+    g_out = torch.randn_like(f_hat) * 0.05
+    g_vq, g_commit = 1.3, 0.7
+    ((f_hat * g_out).sum() + vq * g_vq + commit * g_commit).backward()
+    with torch.no_grad():
+        idx_list = q.f_to_idxBl_or_fhat(f.detach(), to_fhat=False, v_patch_nums=None)
+        fhat_list = q.f_to_idxBl_or_fhat(f.detach(), to_fhat=True, v_patch_nums=None)
+    convs = list(q.quant_resi.qresi_ls) if share > 1 else [q.quant_resi.qresi]
+    SN = len(pns)
+    phi_sel = [int(np.argmin(np.abs(q.quant_resi.ticks - si / (SN - 1)))) for si in range(SN)] if share > 1 else [0] * SN
+    np.savez(os.path.join(OUT, name + ".npz"), f=f.detach().numpy(), E=q.embedding.weight.detach().numpy(),
+             pns=np.array(pns, np.int32), using_znorm=np.int32(using_znorm), codebook_drop=np.float32(codebook_drop),
+             dropout=dropout.numpy().astype(np.int32), var_variant=np.int32(var_variant),
+             phi_w=np.stack([c.weight.detach().numpy() for c in convs]), phi_b=np.stack([c.bias.detach().numpy() for c in convs]),
+             phi_sel=np.array(phi_sel, np.int32), f_hat=f_hat.detach().numpy(), vq_loss=np.float32(vq.item()),
+             commit_loss=np.float32(commit.item()), usages=np.array(usages, np.float32), ema_hit=q.ema_vocab_hit_SV.numpy(),
+             idx=np.concatenate([i.reshape(-1).numpy() for i in idx_list]), fhat_last=fhat_list[-1].numpy(),
+             fhat_scale3=fhat_list[min(3, SN - 1)].numpy(), g_out=g_out.numpy(), g_vq=np.float32(g_vq),
+             g_commit=np.float32(g_commit), g_f=f.grad.numpy(), g_E=q.embedding.weight.grad.numpy(),
+             g_phi_w=np.stack([c.weight.grad.numpy() for c in convs]), g_phi_b=np.stack([c.bias.grad.numpy() for c in convs]),
+             meta=np.array(str(meta())))
+    print("wrote", name, "vq", vq.item(), "commit", float(commit), "usages", [round(u, 2) for u in usages][:4])
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("msvq", ""):
+        # BASELINE config 4 ladder (MSVR10P2: 1x1 -> 11x11, C=32, codebook_drop 0.1, start_drop 3); V reduced to keep the
+        # fixture small (V=4096 full-size runs are oracle-vs-HIP tests)
+        gen_msvq("msvq_cfg4_ladder_v1024_c32_b12", 1024, 32, 12, [1, 1, 2, 3, 3, 4, 5, 6, 8, 11], seed=20)
+        gen_msvq("msvq_16grid_v512_c16_b4", 512, 16, 4, [1, 2, 3, 4, 5, 6, 8, 10, 13, 16], seed=21, codebook_drop=0.5, start_drop=1)
+        gen_msvq("msvq_rawl2_v256_c8_b3", 256, 8, 3, [1, 2, 4, 7], seed=22, using_znorm=False, codebook_drop=0.4, start_drop=2)
+        gen_msvq("msvq_var_models_quant_v512_c32_b4", 512, 32, 4, [1, 2, 3, 4, 5, 6, 8, 10], seed=23, var_variant=True)
+        if only:
+            return
+    if only == "perturb":
+        gen_perturb("perturb_v1024_c64_b8", 1024, 64, 8, 8, 8, seed=5, alpha=0.5, beta=0.25, delta=100)
+        gen_perturb("perturb_alpha1_v512_c32_b4", 512, 32, 4, 4, 4, seed=6, alpha=1.0, beta=0.5, delta=50)
+        gen_perturb("perturb_identity_v256_c16_b4", 256, 16, 4, 4, 4, seed=7, alpha=0.5, beta=0.1, delta=100)
+        gen_perturb("perturb_raw_v300_c8_b3", 300, 8, 3, 5, 5, seed=8, alpha=0.7, beta=0.7, delta=20, codebook_norm=False)
+        return
     # BASELINE config 1 shape (VQ-4096, C=64, B=4, 16x16) — the reference's own CPU-runnable case
     gen_vq("vq_cfg1_v4096_c64_b4", 4096, 64, 4, 16, 16, seed=0)
     # config 2 codebook geometry at a fixture-sized batch (VQ-8192, C=32)
@@ -64,6 +148,12 @@ def main():
     gen_vq("vq_raw_v512_c16_b2", 512, 16, 2, 8, 8, seed=3, codebook_norm=False, z_scale=0.02)
     # clustered latents: many near-duplicates -> histogram contention + near ties
     gen_vq("vq_clustered_v2048_c32_b2", 2048, 32, 2, 16, 16, seed=4, clustered=True)
+    # RobustTok (config 5 geometry V=4096,C=64 is 1 MB of codebook; use V=1024 here, full size is covered
+    # by oracle-vs-HIP tests): beta=0.25 of B=8 -> 2 perturbed samples, alpha=0.5, delta=100
+    gen_perturb("perturb_v1024_c64_b8", 1024, 64, 8, 8, 8, seed=5, alpha=0.5, beta=0.25, delta=100)
+    gen_perturb("perturb_alpha1_v512_c32_b4", 512, 32, 4, 4, 4, seed=6, alpha=1.0, beta=0.5, delta=50)
+    gen_perturb("perturb_identity_v256_c16_b4", 256, 16, 4, 4, 4, seed=7, alpha=0.5, beta=0.1, delta=100)  # int(4*0.1)=0
+    gen_perturb("perturb_raw_v300_c8_b3", 300, 8, 3, 5, 5, seed=8, alpha=0.7, beta=0.7, delta=20, codebook_norm=False)
 
 
 if __name__ == "__main__":

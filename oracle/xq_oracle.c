@@ -266,20 +266,22 @@ void xqo_area_pool(const float *in, long BC, int H, int W, int ph, int pw, float
 }
 
 /* bicubic (A=-0.75, align_corners=False, border-clamped taps) 1-D tap table for in_size -> out_size:
- * taps[o][0..3] weights, i0[o] = floor(src)-1 (unclamped).  quant.py:107  (ATen upsample_bicubic2d) */
+ * w[o][0..3] weights, i0[o] = floor(src)-1 (unclamped); src = (in/out)*(o+0.5)-0.5   (quant.py:107, ATen
+ * upsample_bicubic2d: cubic_convolution1/2 with A=-0.75).  The table is evaluated in double and rounded once
+ * to fp32 (ATen evaluates it in fp32 with its own association; both are within 1 ulp of the exact taps). */
 void xqo_bicubic_taps(int in_size, int out_size, float *w /*[out][4]*/, int32_t *i0 /*[out]*/) {
-    const float A = -0.75f;
-    const float scale = (float)in_size / (float)out_size;
+    const double A = -0.75;
+    const double scale = (double)in_size / (double)out_size;
     for (int o = 0; o < out_size; ++o) {
-        float src = scale * ((float)o + 0.5f) - 0.5f;
-        float fl = floorf(src);
-        float t = src - fl;
+        double src = scale * ((double)o + 0.5) - 0.5;
+        double fl = floor(src);
+        double t = src - fl;
         i0[o] = (int32_t)fl - 1;
-        float x;
-        x = t + 1.0f; w[o * 4 + 0] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
-        x = t;        w[o * 4 + 1] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
-        x = 1.0f - t; w[o * 4 + 2] = ((A + 2.0f) * x - (A + 3.0f)) * x * x + 1.0f;
-        x = (1.0f - t) + 1.0f; w[o * 4 + 3] = ((A * x - 5.0f * A) * x + 8.0f * A) * x - 4.0f * A;
+        double x;
+        x = t + 1.0; w[o * 4 + 0] = (float)(((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A);
+        x = t;       w[o * 4 + 1] = (float)(((A + 2.0) * x - (A + 3.0)) * x * x + 1.0);
+        x = 1.0 - t; w[o * 4 + 2] = (float)(((A + 2.0) * x - (A + 3.0)) * x * x + 1.0);
+        x = 2.0 - t; w[o * 4 + 3] = (float)(((A * x - 5.0 * A) * x + 8.0 * A) * x - 4.0 * A);
     }
 }
 

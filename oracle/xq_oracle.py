@@ -115,6 +115,24 @@ def vq_backward(z_bchw, E, idx, g_out, g_vq, g_commit, beta, normed=True):
     return gz, gE
 
 
+def perturb_forward(z_bchw, zq_in, E, codebook_norm, n_pert, rank):
+    """add_perturbation restated (latent_perturbation.py:4-35) with explicit rank draws.
+    returns (out (B,C,H,W), sel int64 (n_pert*HW,))."""
+    z = _f32(z_bchw)
+    out = _f32(zq_in).copy()
+    B = z.shape[0]
+    HW = int(np.prod(z.shape[2:]))
+    T = int(n_pert) * HW
+    if T == 0:
+        return out, np.zeros(0, np.int64)
+    mode = MODE_L2_NORMED if codebook_norm else MODE_L2_RAW
+    d = dist_rows(z, E, mode, np.arange(T, dtype=np.int64))                    # :16-18
+    sel = select_rank(d, np.asarray(rank)[:T])                                 # :20-24
+    zp, _, _ = vq_finish(z[:n_pert], E, sel, normed=codebook_norm, ste=True, want_hist=False)  # :26-30
+    out[:n_pert] = zp                                                          # :32-35
+    return out, sel
+
+
 def area_pool(x_bchw, ph, pw):
     x = _f32(x_bchw)
     B, C, H, W = x.shape

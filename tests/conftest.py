@@ -45,3 +45,29 @@ def oracle():
     from oracle import xq_oracle
     xq_oracle.build()
     return xq_oracle
+
+
+def msvq_n_quant(g):
+    """per-sample active-scale count as the reference builds it (quant.py:79-86)"""
+    B = g["f"].shape[0]
+    SN = len(g["pns"])
+    nq = np.full(B, SN + 1, np.float32)
+    if not int(g["var_variant"]):
+        nd = int(B * float(g["codebook_drop"]))
+        nq[:nd] = g["dropout"][:nd]
+    return nq
+
+
+def msvq_first_mismatch_mask(g, idx_all):
+    """(B,) bool: samples whose indices agree with the reference on EVERY scale (a flipped near-tie on one scale
+    legitimately changes f_rest and hence all later scales of that sample)."""
+    B = g["f"].shape[0]
+    ok = np.ones(B, bool)
+    off = 0
+    for pn in g["pns"]:
+        n = B * int(pn) * int(pn)
+        a = np.asarray(idx_all[off:off + n]).reshape(B, -1)
+        b = g["idx"][off:off + n].reshape(B, -1)
+        ok &= (a == b).all(axis=1)
+        off += n
+    return ok

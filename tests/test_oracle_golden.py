@@ -66,3 +66,77 @@ def test_select_rank_is_sorted_order(oracle):
         got = oracle.select_rank(d, np.full(7, r, np.int32))
         want = np.argsort(d, axis=1, kind="stable")[:, r]
         np.testing.assert_array_equal(got, want)
+
+
+PERT_CASES = golden_names("perturb_")
+
+
+@pytest.mark.parametrize("name", PERT_CASES)
+def test_perturb_matches_reference(oracle, name):
+    """add_perturbation (latent_perturbation.py:4-35): oracle vs the reference's output for the recorded draws."""
+    g = load_golden(name)
+    B = g["z"].shape[0]
+    n_pert = int(B * float(g["beta"]))
+    out, sel = oracle.perturb_forward(g["z"], g["zq_in"], g["E"], bool(g["codebook_norm"]), n_pert, g["rank"])
+    # torch.topk's order among exactly equal distances is unspecified upstream -> compare values, to 1e-6;
+    # a different pick at a near-tie would show up as an O(1) difference in that token's vector
+    diff = np.abs(out - g["out"]).reshape(B, g["z"].shape[1], -1).max(axis=1)  # (B, HW)
+    bad = diff > 1e-6
+    assert bad.mean() <= 0.002, f"{bad.sum()} tokens differ"
+    if bad.any():  # every differing token must be an fp64-verified near tie between the two picked codes
+        mode = oracle.MODE_L2_NORMED if bool(g["codebook_norm"]) else oracle.MODE_L2_RAW
+        toks = np.nonzero(bad.reshape(-1))[0]
+        d = oracle.fp64_scores(g["z"], g["E"], mode, toks)
+        srt = np.sort(d, axis=1)
+        r = g["rank"][toks]
+        assert np.abs(d[np.arange(len(toks)), sel[toks]] - srt[np.arange(len(toks)), r]).max() < 2e-6
+    np.testing.assert_array_equal(out[n_pert:], g["zq_in"][n_pert:])
+
+
+MSVQ_CASES = golden_names("msvq_")
+
+
+@pytest.mark.parametrize("name", MSVQ_CASES)
+def test_msvq_ladder_matches_reference(oracle, name):
+    """VectorQuantizer2 ladder (quant.py:64-223 / models/quant.py): oracle vs the reference's outputs."""
+    from conftest import msvq_n_quant, msvq_first_mismatch_mask
+    g = load_golden(name)
+    nq = msvq_n_quant(g)
+    o = oracle.msvq_forward(g["f"], g["E"], g["pns"], g["phi_sel"], g["phi_w"], g["phi_b"], 0.5,
+                            using_znorm=bool(g["using_znorm"]), n_quant=nq, skip_last_pool=True, want_scales=True)
+    idx_all = np.concatenate([i.reshape(-1) for i in o["idx"]])
+    ok = msvq_first_mismatch_mask(g, idx_all)
+    assert ok.mean() >= 0.9, f"only {ok.sum()}/{len(ok)} samples reproduce every scale's indices"
+    B = g["f"].shape[0]
+    SN = len(g["pns"])
+    # masked training f_hat (straight-through value) and the unmasked inference ladder
+    ste = (o["f_hat"] - g["f"]) + g["f"]
+    assert np.abs(ste - g["f_hat"])[ok].max() <= 2e-5
+    assert np.abs(o["f_hat_scales"][-1] - g["fhat_last"])[ok].max() <= 2e-5 or not np.allclose(nq, SN + 1)
+    if ok.all():
+        numel = g["f"].size
+        vq = sum(o["sq_sum"][s] / numel / o["ratio"][s] for s in range(SN)) / SN
+        if int(g["var_variant"]):
+            vq = sum(o["sq_sum"][s] * (0.25 + 1.0) / numel for s in range(SN)) / SN
+        else:
+            commit = sum(0.25 * o["sq_sum"][s] / numel / o["ratio"][s] for s in range(SN))
+            np.testing.assert_allclose(commit, g["commit_loss"], rtol=2e-5)
+        np.testing.assert_allclose(vq, g["vq_loss"], rtol=2e-5)
+
+
+def test_bicubic_area_phi_building_blocks_vs_aten(oracle):
+    """Building blocks vs ATen CPU (F.interpolate area/bicubic, conv2d): within fp32 rounding of each other."""
+    import torch
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    x = torch.randn(2, 8, 11, 11)
+    for pn in (1, 2, 3, 5, 8, 11):
+        assert np.abs(oracle.area_pool(x.numpy(), pn, pn) - F.interpolate(x, size=(pn, pn), mode="area").numpy()).max() < 5e-7
+    for pn in (1, 2, 3, 5, 8):
+        s = torch.randn(2, 8, pn, pn)
+        ref64 = F.interpolate(s.double(), size=(11, 11), mode="bicubic").numpy()
+        assert np.abs(oracle.bicubic_up(s.numpy(), 11, 11) - ref64).max() < 2e-6  # closer to fp64 than ATen's fp32 path
+    conv = torch.nn.Conv2d(8, 8, 3, padding=1)
+    h = torch.randn(2, 8, 11, 11)
+    ref = (h * 0.5 + conv(h) * 0.5).detach().numpy()
+    assert np.abs(oracle.phi(h.numpy(), conv.weight.detach().numpy(), conv.bias.detach().numpy(), 0.5) - ref).max() < 2e-6
