@@ -1,23 +1,25 @@
 #!/usr/bin/env python
-"""bench.py — hot-path throughput on MI355X (contract: one JSON line on rank 0).
+"""bench.py — tokenizer train-step throughput on MI355X (contract: ONE JSON line on rank 0).
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-Workload (BASELINE.json configs[1]): VQ-8192.yaml geometry — per-GPU batch B=128 images of 256x256,
-16x16 latent grid (N = 32768 tokens), codebook V=8192, C=32, product_quant=1.
-A "step" is one pass of the quantizer stage of the tokenizer train step over one synthetic batch:
-VectorQuantizer.forward (+ usage EMA) and its backward (reference xqgan_model.py:745-801), inputs
-already resident in HBM.  Stages of the train step that are not yet on hand-written kernels are
-listed in config["not_in_timed_region"] — the number is the quantizer-stage rate, not the end-to-end
-train-step rate, and is labelled as such.
+Workload (BASELINE.json configs[1]): VQ-8192.yaml — VQ-16 tokenizer, DINOv2 ViT-B encoder + decoder (random init: no
+checkpoints offline), codebook V=8192, C=32, product_quant=1, 256 latent tokens, frozen ViT-B semantic teacher,
+256x256 synthetic images in [-1, 1], per-GPU batch 128 (1024 / 8 as in the yaml; weak scaling: fixed per-GPU batch),
+bf16 autocast with fp32 master weights.
+A "step" = one tokenizer train step of xqgan_train.py:439-478 on one resident batch: encoder -> quant_conv ->
+VectorQuantizer (+ latent-perturbation call) -> post_quant_conv -> decoder -> semantic contrastive branch ->
+generator loss -> backward -> gradient all-reduce (RCCL, N > 1) -> fused AdamW + EMA.  What is NOT in the timed
+region yet is listed in config["not_in_timed_region"] (VQLoss's LPIPS / DinoDisc terms and the discriminator step:
+SURVEY.md §8f "next" #1).  config["op_impl"] says, per dense op, whether a hand-written HIP kernel or a
+PyTorch-ROCm library op ran.
 
-roofline: the dominant kernel is assign_kernel (fused normalise + distance + argmin on fp32 MFMA):
-algorithmic flops per launch = 2*N*V*C, timed live with HIP events on its launch
-stream inside libxq_ops.so (xq_prof_*), peak = 157.3 TFLOP/s fp32 MFMA (MI355X_MICROARCH.md).
-cpu_baseline: the reference's expressions restated with the same ATen CPU ops
-(oracle/torch_restatement.py, kind="port"; /root/reference does not exist on the GPU box), on a
-bounded sample, rank 0, N=1 only.
+roofline: the dominant HAND-WRITTEN kernel of the step, assign_kernel (fused normalise + distance + argmin on fp32
+MFMA): algorithmic flops per launch = 2*N*V*C, timed live with HIP events on its launch stream
+inside libxq_ops.so (xq_prof_*), peak = 157.3 TFLOP/s fp32 matrix (MI355X_MICROARCH.md).
+cpu_baseline: the same quantizer stage with the reference's expressions on ATen CPU ops (oracle/torch_restatement.py,
+kind="port": /root/reference does not exist on the GPU box), bounded sample, rank 0, N = 1 only.
 """
 import argparse
 import ctypes
@@ -33,26 +35,27 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
-CFG = dict(name="VQ-8192", B=128, C=32, V=8192, H=16, W=16, beta=0.25)
+CFG = dict(name="VQ-8192", B=128, C=32, V=8192, L=256, beta=0.25)
 
 
 def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=50)
-    p.add_argument("--warmup", type=int, default=10)
+    p.add_argument("--steps", type=int, default=10)
+    p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (images)")
+    p.add_argument("--workload", default="train_step", choices=["train_step", "quantizer"])
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
 
 def cpu_baseline(B_sample=16, iters=3):
-    """Reference CPU path (ATen fp32, all host cores) on a bounded sample of the same workload."""
+    """Reference CPU path of the quantizer stage (ATen fp32, all host cores) on a bounded sample of the workload."""
     from oracle import torch_restatement as tr
     torch.manual_seed(0)
     V, C = CFG["V"], CFG["C"]
     E = torch.nn.functional.normalize(torch.empty(V, C).uniform_(-1.0 / V, 1.0 / V), dim=-1).requires_grad_(True)
-    z = torch.randn(B_sample, C, CFG["H"], CFG["W"], requires_grad=True)
+    z = torch.randn(B_sample, C, 16, 16, requires_grad=True)
 
     def step():
         zq, idx, vq, commit, hist = tr.vq_forward(z, E, CFG["beta"], True)
@@ -64,8 +67,31 @@ def cpu_baseline(B_sample=16, iters=3):
         step()
     dt = (time.perf_counter() - t0) / iters
     return dict(value=B_sample / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample=f"{iters} iters of quantizer fwd+bwd on B={B_sample} images ({B_sample * 256} tokens x V={V} x C={C}), "
-                       f"ATen CPU fp32 restatement of xqgan_model.py:745-801")
+                sample=f"quantizer stage only (VectorQuantizer fwd+bwd, the part of the step the CPU restatement covers): "
+                       f"{iters} iters on B={B_sample} images ({B_sample * 256} tokens x V={V} x C={C}), ATen CPU fp32 "
+                       f"restatement of xqgan_model.py:745-801")
+
+
+def build_train_step(args, dev, world):
+    from imagefolder_amd.xqgan_model import VQ_models
+    from imagefolder_amd.train import TokenizerTrainStep
+    torch.manual_seed(0)  # identical weights on every rank (what DDP's construction-time broadcast guarantees)
+    model = VQ_models["VQ-16"](codebook_size=CFG["V"], codebook_embed_dim=CFG["C"], v_patch_nums=[16], enc_type="dinov2",
+                               dec_type="dinov2", semantic_guide="dinov2", detail_guide="none", num_latent_tokens=CFG["L"],
+                               encoder_model="vit_base_patch14_dinov2.lvd142m",
+                               decoder_model="vit_base_patch14_dinov2.lvd142m", abs_pos_embed=True, product_quant=1,
+                               share_quant_resi=4, codebook_drop=0.0, half_sem=False, start_drop=3, sem_loss_weight=0.1,
+                               guide_type_1="class").to(dev).train()
+
+    def gen_loss(out, imgs):
+        recons, (vq, commit, entropy, usages), sem, detail, dep = out
+        rec = torch.nn.functional.mse_loss(imgs, recons.float())  # VQLoss rec term (vq_loss.py:166), weight 1.0
+        return rec + vq + commit + entropy + (sem if sem is not None else 0.0)
+
+    # xqgan_train.py defaults: lr 1e-4 * global_batch/128 (yaml lr 3e-5), betas (0.9, 0.95), wd 0 (yaml), ema on
+    ts = TokenizerTrainStep(model, gen_loss, lr=3e-5 * args.batch * world / 128, betas=(0.9, 0.95), weight_decay=0.0,
+                            ema_decay=0.9999, use_ema=True, amp_dtype=torch.bfloat16)
+    return model, ts
 
 
 def main():
@@ -80,29 +106,36 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.backends.cuda.matmul.allow_tf32 = True  # xqgan_train.py:6-7 (no-op on gfx950: no TF32 path)
 
-    from imagefolder_amd import _lib
-    from imagefolder_amd.xqgan_model import VectorQuantizer
+    from imagefolder_amd import _lib, nn_ops
+    lib = _lib.lib()
+    B = args.batch
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank synthetic data (xqgan_train.py:189)
 
-    B, C, V, H, W = args.batch, CFG["C"], CFG["V"], CFG["H"], CFG["W"]
-    torch.manual_seed(0)  # identical codebook on every rank (DDP would broadcast it)
-    q = VectorQuantizer(V, C, CFG["beta"], True).to(dev).train()
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank synthetic latents
-    z = torch.randn(B, C, H, W, device=dev, generator=g).requires_grad_(True)
-    g_out = torch.randn(B, C, H, W, device=dev, generator=g) * 0.01
+    if args.workload == "train_step":
+        model, ts = build_train_step(args, dev, world)
+        imgs = torch.rand(B, 3, 256, 256, device=dev, generator=g) * 2 - 1
 
-    def step():
-        z.grad = None
-        q.embedding.weight.grad = None
-        zq, usage, vq, commit, _ = q(z)  # usage EMA + (world>1) histogram all-reduce inside
-        torch.autograd.backward([zq, vq, commit], [g_out, None, None])
-        if world > 1:  # data-parallel replicas: codebook gradient mean (DDP C1 for this stage)
-            dist.all_reduce(q.embedding.weight.grad)
-            q.embedding.weight.grad.div_(world)
+        def step():
+            ts.step(imgs, epoch=0, alpha=0.0, beta=0.0, delta=100)
+        n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+    else:
+        from imagefolder_amd.xqgan_model import VectorQuantizer
+        torch.manual_seed(0)
+        q = VectorQuantizer(CFG["V"], CFG["C"], CFG["beta"], True).to(dev).train()
+        z = torch.randn(B, CFG["C"], 16, 16, device=dev, generator=g).requires_grad_(True)
+        g_out = torch.randn(B, CFG["C"], 16, 16, device=dev, generator=g) * 0.01
+
+        def step():
+            z.grad = None
+            q.embedding.weight.grad = None
+            zq, usage, vq, commit, _ = q(z)
+            torch.autograd.backward([zq, vq, commit], [g_out, None, None])
+        n_params = q.embedding.weight.numel()
 
     for _ in range(args.warmup):
         step()
-    lib = _lib.lib()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -126,28 +159,36 @@ def main():
     dt = tmax.item()
 
     if rank == 0:
-        N = B * H * W
-        flops = 2.0 * N * V * C
+        N = B * CFG["L"]
+        flops = 2.0 * N * CFG["V"] * CFG["C"]
         k_ms = ms_tot.value / max(1, n_launch.value)
         achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        full = args.workload == "train_step"
         out = {
-            "metric": "images/sec (256x256) tokenizer train step, quantizer stage",
+            "metric": "images/sec (256x256) tokenizer train step" + ("" if full else ", quantizer stage only"),
             "value": B * world * args.steps / dt,
             "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16" if full else "f32", "data": "synthetic",
             "config": {
-                "workload": f"{CFG['name']}.yaml geometry: VectorQuantizer fwd+bwd, B={B}/GPU x 16x16 latents "
-                            f"(N={N} tokens), V={V}, C={C}, codebook_norm, usage EMA; inputs resident in HBM",
+                "workload": (f"{CFG['name']}.yaml: VQ-16 tokenizer, DINOv2 ViT-B encoder+decoder (random init), V={CFG['V']}, "
+                             f"C={CFG['C']}, 256 latent tokens, frozen ViT-B semantic teacher; B={B}/GPU x 256x256; fwd + bwd + "
+                             f"grad all-reduce + fused AdamW/EMA; bf16 autocast, fp32 master weights; inputs resident in HBM")
+                if full else f"{CFG['name']}.yaml geometry: VectorQuantizer fwd+bwd only, B={B}/GPU (N={N} tokens)",
                 "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                "not_in_timed_region": "ViT-B encoder/decoder, VQLoss (LPIPS/DinoDisc), AdamW/EMA — not yet on HIP kernels",
+                "trainable_params": n_params,
+                "op_impl": dict(nn_ops.IMPL, quantizer="hip", latent_perturbation="hip", adamw_ema="hip",
+                                grad_allreduce="rccl"),
+                "not_in_timed_region": ("VQLoss perceptual (LPIPS-VGG16) and adversarial (DinoDisc + DiffAug + LeCAM) terms and "
+                                        "the discriminator step (SURVEY §8f next #1)") if full else "everything but the quantizer",
             },
             "roofline": {"bound": "mfma", "kernel": "assign_kernel<C=32,L2_NORMED> (v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops, "avg_launch_ms": k_ms, "launches": n_launch.value},
+                         "flops_per_launch": flops, "avg_launch_ms": k_ms, "launches": n_launch.value,
+                         "note": "dominant hand-written kernel; the step's GEMM time is in library kernels (op_impl)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

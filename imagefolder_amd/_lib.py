@@ -40,6 +40,9 @@ SIGNATURES = {
     "xq_msvq_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p,
                                         ctypes.c_int, c_i32p, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "xq_adamw_ema_step": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_float, ctypes.c_float, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
+                                         ctypes.c_int, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }

@@ -1,0 +1,100 @@
+"""Dense-layer op table for the encoder/decoder (E1-E4 of SURVEY.md §8a).
+
+Every tensor op of the ViT / CNN encoder-decoder goes through one of these functions so that the
+implementation behind each can be swapped per op:
+  * "hip"  — hand-written gfx950 kernel from libxq_ops.so (through autograd Functions in ops_dense.py);
+  * "aten" — PyTorch-ROCm library op (hipBLASLt / MIOpen / CK); used for plain library GEMMs and as the
+             stand-in for ops whose HIP kernel has not landed yet.
+`IMPL[name]` says which one each op currently uses; `bench.py` reports the table in its config so a number is
+never quoted without saying which ops were hand-written.  The fp32 numerics reference for every HIP op here is the
+ATen implementation of the same op (tests/test_dense_ops_gpu.py).
+"""
+import torch
+import torch.nn.functional as F
+
+# op name -> "hip" | "aten"
+IMPL = {
+    "layer_norm": "aten",
+    "linear": "aten",            # plain GEMM (+bias): library GEMM (hipBLASLt) by design
+    "linear_gelu": "aten",
+    "attention": "aten",
+    "residual_scale_add": "aten",
+    "patch_embed": "aten",
+    "group_norm_silu": "aten",
+    "conv2d": "aten",
+}
+
+_HIP = {}
+
+
+def register_hip(name, fn):
+    """ops_dense.py registers its autograd Functions here when libxq_ops.so provides the kernel."""
+    _HIP[name] = fn
+    IMPL[name] = "hip"
+
+
+def use(name, impl):
+    if impl == "hip" and name not in _HIP:
+        raise RuntimeError(f"no HIP kernel registered for {name}")
+    IMPL[name] = impl
+
+
+def _hip(name):
+    return _HIP[name] if IMPL.get(name) == "hip" else None
+
+
+def layer_norm(x, weight, bias, eps):
+    f = _hip("layer_norm")
+    if f is not None and x.is_cuda:
+        return f(x, weight, bias, eps)
+    return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+
+
+def linear(x, weight, bias=None):
+    return F.linear(x, weight, bias)
+
+
+def linear_gelu(x, weight, bias=None):
+    f = _hip("linear_gelu")
+    if f is not None and x.is_cuda:
+        return f(x, weight, bias)
+    return F.gelu(F.linear(x, weight, bias))
+
+
+def attention_qkvpacked(qkv, num_heads):
+    """qkv: (B, N, 3*C) packed as [3][heads][head_dim] -> (B, N, C); softmax(q k^T / sqrt(d)) v, no mask, no dropout."""
+    f = _hip("attention")
+    if f is not None and qkv.is_cuda:
+        return f(qkv, num_heads)
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+    x = F.scaled_dot_product_attention(q, k, v)
+    return x.transpose(1, 2).reshape(B, N, C)
+
+
+def residual_scale_add(x, y, gamma=None, mask=None):
+    """x + drop_path_mask * (gamma * y)   (LayerScale + DropPath + residual of one transformer branch)"""
+    f = _hip("residual_scale_add")
+    if f is not None and x.is_cuda:
+        return f(x, y, gamma, mask)
+    if gamma is not None:
+        y = y * gamma
+    if mask is not None:
+        y = y * mask
+    return x + y
+
+
+def patch_embed(x, weight, bias, patch):
+    """Conv2d(kernel = stride = patch) + flatten(2).transpose(1, 2): (B,3,H,W) -> (B, (H/p)*(W/p), D)"""
+    y = F.conv2d(x, weight, bias, stride=patch)
+    return y.flatten(2).transpose(1, 2)
+
+
+def group_norm_silu(x, groups, weight, bias, eps, silu=True):
+    y = F.group_norm(x, groups, weight, bias, eps)
+    return y * torch.sigmoid(y) if silu else y
+
+
+def conv2d(x, weight, bias, stride=1, padding=0):
+    return F.conv2d(x, weight, bias, stride=stride, padding=padding)

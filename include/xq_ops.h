@@ -139,6 +139,18 @@ int xq_msvq_backward(const float *f, int B, int C, int H, int W, int V, const in
                      const float *g_sq_vq, const float *g_sq_commit, float *g_f, float *g_E, float *g_phi_w,
                      float *g_phi_b, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 
+/* ---- fused optimizer step over flat fp32 arenas (xqgan_train.py:344-347,447,459-462; utils/ema.py:5-14) ---------- */
+
+/*
+ * One pass over n parameters: AdamW (torch.optim.AdamW single-tensor semantics, amsgrad=False, maximize=False) on
+ * p with gradient g*grad_scale (grad_scale = 1/world_size folds DDP's mean), first/second moments m/v, bias
+ * correction for the 1-based `step`; then ema = ema*ema_decay + p*(1-ema_decay) (ema nullable); g is zeroed when
+ * zero_grad != 0.  All arenas: device fp32, 16-byte aligned, n elements.
+ */
+int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int64_t step, float ema_decay, float grad_scale, int zero_grad,
+                      xq_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
  *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the
  *      recorded events and returns the summed duration and launch count since arming. ------------------ */

@@ -38,12 +38,13 @@ def load_reference():
     saved_datasets = sys.modules.pop("datasets", None)
     sys.path.insert(0, os.path.join(REF_ROOT, "tokenizer", "tokenizer_image"))
     sys.path.insert(1, REF_ROOT)
-    for m in ["timm", "timm.models", "timm.layers", "timm.data", "timm.models._builder",
-              "timm.models._features", "timm.models._manipulate", "timm.models._registry",
-              "peft", "torchvision", "torchvision.datasets", "torchvision.transforms",
+    for m in ["peft", "torchvision", "torchvision.datasets", "torchvision.transforms",
               "torchvision.models", "torchvision.utils", "webdataset", "wandb"]:
         if m not in sys.modules:
             sys.modules[m] = MagicMock()
+    # timm: functional stand-in for the handful of layers the vendored ViT needs (oracle/timm_shim.py)
+    from oracle import timm_shim
+    timm_shim.install()
     import torch.distributed as tdist
     if not tdist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -62,6 +63,8 @@ def load_reference():
     _loaded.update(
         xqgan_model=ref_model, quant=ref_quant, latent_perturbation=ref_lp,
         var_quant=ref_var_quant,
+        dinov2=sys.modules["tokenizer.tokenizer_image.dino_enc.dinov2"],
+        DINOv2Encoder=ref_model.DINOv2Encoder, DINOv2Decoder=ref_model.DINOv2Decoder,
         VectorQuantizer=ref_model.VectorQuantizer, VectorQuantizer2=ref_quant.VectorQuantizer2,
         add_perturbation=ref_lp.add_perturbation, VQ_models=ref_model.VQ_models,
         Encoder=ref_model.Encoder, Decoder=ref_model.Decoder, VQModel=ref_model.VQModel,
