@@ -86,9 +86,20 @@ def residual_scale_add(x, y, gamma=None, mask=None):
 
 
 def patch_embed(x, weight, bias, patch):
-    """Conv2d(kernel = stride = patch) + flatten(2).transpose(1, 2): (B,3,H,W) -> (B, (H/p)*(W/p), D)"""
-    y = F.conv2d(x, weight, bias, stride=patch)
-    return y.flatten(2).transpose(1, 2)
+    """Conv2d(kernel = stride = patch) + flatten(2).transpose(1, 2): (B,3,H,W) -> (B, (H/p)*(W/p), D).
+    A non-overlapping conv is a GEMM over patchified pixels: (B*gh*gw, 3*p*p) @ W^T.  (MIOpen has no tuned bf16
+    solver for this shape on gfx950 and falls back to naive_conv_* kernels: 35 % of the step in profiles/r01.)"""
+    B, Cin, H, W = x.shape
+    gh, gw = H // patch, W // patch
+    cols = x.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cin * patch * patch)
+    return linear(cols, weight.reshape(weight.shape[0], -1), bias)
+
+
+def conv1x1(x, weight, bias=None):
+    """1x1 Conv2d on NCHW as a GEMM over the channel axis (quant_conv / post_quant_conv, xqgan_model.py:89-146).
+    The input is usually a permuted view of a channels-last token tensor, so the permute below is free."""
+    y = linear(x.permute(0, 2, 3, 1), weight.reshape(weight.shape[0], -1), bias)
+    return y.permute(0, 3, 1, 2)
 
 
 def group_norm_silu(x, groups, weight, bias, eps, silu=True):

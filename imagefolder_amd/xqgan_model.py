@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.distributed as tdist
 
-from . import ops
+from . import nn_ops, ops
 from .cliploss import ClipLoss
 from .cnn import Encoder, Decoder
 from .dino_enc.dinov2 import DINOv2Encoder, DINOv2Decoder
@@ -289,10 +289,10 @@ class VQModel(nn.Module):
 
     def encode(self, x):
         h = self._tokens_to_map(self.encoder(x))
-        return self.quant_conv(h)
+        return nn_ops.conv1x1(h, self.quant_conv.weight, self.quant_conv.bias)
 
     def decode(self, quant, return_quant=False):
-        quant = self.post_quant_conv(quant)
+        quant = nn_ops.conv1x1(quant, self.post_quant_conv.weight, self.post_quant_conv.bias)
         if self.dec_type == 'dinov2':
             quant = quant.flatten(2).permute(0, 2, 1)
         return self.decoder(quant)
@@ -345,7 +345,7 @@ class VQModel(nn.Module):
                 else:
                     z_s = self.semantic_model.forward_features(inp)[:, 1:, :].reshape(b, 768, 16, 16)
             if self.enc_type == 'dinov2':
-                z_s = self.quant_conv(z_s).contiguous()
+                z_s = nn_ops.conv1x1(z_s, self.quant_conv.weight, self.quant_conv.bias).contiguous()
                 z_s = torch.mean(z_s, dim=(2, 3)).contiguous()
                 z_q_ = torch.mean(quant_list[-1], dim=(2, 3)).contiguous()
             else:
@@ -368,7 +368,7 @@ class VQModel(nn.Module):
 
     # ---- :367-403 -------------------------------------------------------------------------------------------
     def img_to_reconstructed_img(self, x, last_one=True):
-        f = self.quant_conv(self._tokens_to_map(self.encoder(x)))
+        f = nn_ops.conv1x1(self._tokens_to_map(self.encoder(x)), self.quant_conv.weight, self.quant_conv.bias)
         multi = len(self.v_patch_nums) > 1
         if self.product_quant > 1:
             b, c, l, _ = f.shape
@@ -377,10 +377,11 @@ class VQModel(nn.Module):
             f_hats_list = [self.quantizes[i].f_to_idxBl_or_fhat(fi, to_fhat=True,
                                                                 v_patch_nums=self.v_patch_nums if multi else None)
                            for i, fi in enumerate(f_list)]
-            f_hats = [self.post_quant_conv(torch.cat(fh, dim=1)) for fh in zip(*f_hats_list)]
+            f_hats = [nn_ops.conv1x1(torch.cat(fh, dim=1), self.post_quant_conv.weight, self.post_quant_conv.bias)
+                      for fh in zip(*f_hats_list)]
         else:
             ls = self.quantize.f_to_idxBl_or_fhat(f, to_fhat=True, v_patch_nums=self.v_patch_nums if multi else None)
-            f_hats = [self.post_quant_conv(fh) for fh in ls]
+            f_hats = [nn_ops.conv1x1(fh, self.post_quant_conv.weight, self.post_quant_conv.bias) for fh in ls]
         if self.dec_type == 'dinov2':
             f_hats = [fh.flatten(2).permute(0, 2, 1) for fh in f_hats]
         if last_one:
@@ -390,7 +391,7 @@ class VQModel(nn.Module):
     def img_to_idx(self, x):
         """code indices of an image batch (the 'indices bit-exact' contract): list over product branches of the
         per-scale index tensors returned by f_to_idxBl_or_fhat(to_fhat=False)."""
-        f = self.quant_conv(self._tokens_to_map(self.encoder(x)))
+        f = nn_ops.conv1x1(self._tokens_to_map(self.encoder(x)), self.quant_conv.weight, self.quant_conv.bias)
         multi = len(self.v_patch_nums) > 1
         vp = self.v_patch_nums if multi else None
         if self.product_quant > 1:
@@ -401,7 +402,7 @@ class VQModel(nn.Module):
         return [self.quantize.f_to_idxBl_or_fhat(f, to_fhat=False, v_patch_nums=vp)]
 
     def fhat_to_img(self, f_hat: torch.Tensor):
-        f_hat = self.post_quant_conv(f_hat)
+        f_hat = nn_ops.conv1x1(f_hat, self.post_quant_conv.weight, self.post_quant_conv.bias)
         if self.dec_type == 'dinov2':
             f_hat = f_hat.flatten(2).permute(0, 2, 1)
         return self.decoder(f_hat).clamp_(-1, 1)

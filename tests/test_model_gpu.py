@@ -12,7 +12,7 @@ def tiny_model(P=1, pns=(4,), V=256, C=16, L=16, drop=0.0):
     args = ModelArgs(codebook_size=V, codebook_embed_dim=C, v_patch_nums=list(pns), enc_type='dinov2', dec_type='dinov2',
                      semantic_guide='dinov2', detail_guide='none', num_latent_tokens=L,
                      encoder_model='vit_base_patch14_dinov2.lvd142m', decoder_model='vit_base_patch14_dinov2.lvd142m',
-                     abs_pos_embed=True, product_quant=P, codebook_drop=drop, start_drop=1)
+                     abs_pos_embed=True, product_quant=P, codebook_drop=drop, start_drop=1, half_sem=(P > 1))
     args.vit_overrides = TINY_VIT
     torch.manual_seed(0)
     return VQModel(args)
