@@ -40,9 +40,17 @@ SIGNATURES = {
     "xq_msvq_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_i32p,
                                         ctypes.c_int, c_i32p, vp, ctypes.c_float, ctypes.c_int, vp, vp, vp, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, ctypes.c_size_t, vp]),
-    "xq_adamw_ema_step": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+    "xq_adamw_ema_step": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_float, ctypes.c_float, ctypes.c_int64, ctypes.c_float, ctypes.c_float,
                                          ctypes.c_int, vp]),
+    "xq_row_partials_blocks": (ctypes.c_int, [ctypes.c_int64]),
+    "xq_res_ln_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float,
+                                         ctypes.c_int, vp, vp, vp, vp, vp]),
+    "xq_res_ln_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp]),
+    "xq_gelu_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp]),
+    "xq_gelu_backward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]),
+    "xq_colsum": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }

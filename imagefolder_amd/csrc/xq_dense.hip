@@ -1,0 +1,387 @@
+// xq_dense.hip — HBM-bound fused row kernels of the ViT encoder/decoder blocks (gfx950).
+//
+// Replaces the unfused ATen elementwise/normalisation chain of the reference's timm blocks
+// (tokenizer/tokenizer_image/dino_enc/vision_transformer.py:295-339: LayerNorm -> ... -> LayerScale -> DropPath ->
+//  residual add; Mlp: fc1 bias -> GELU), which under bf16 autocast runs as ~20 separate kernels per block on an fp32
+// residual stream (profiles/r01_train_step_aten_v2_kernel_stats.txt: ~100 ms of a 236 ms step):
+//   res_ln_fwd : x_new = x + mask_b * (gamma * y)      (LayerScale :291, DropPath, residual :337-338)
+//                a     = LayerNorm(x_new) * w + b      (next norm1/norm2/final norm, eps 1e-6)
+//                one pass: reads x (fp32) + y (T), writes x_new (fp32) + a (T) + per-row mean/rstd
+//   res_ln_bwd : the transpose of the above in one pass + per-block column partial sums for d_gamma, d_w, d_b and the
+//                bias gradient of the Linear that produced y
+//   gelu_fwd / gelu_bwd : exact (erf) GELU on the fc1 output (+ column partials for the fc1 bias gradient)
+//   colsum_finalize : fixed-order reduction of the column partials into the parameter gradients
+// T = activation dtype (bf16 in training, fp32 for the fp32-parity tests); statistics and the residual stream are
+// fp32, as they are under the reference's autocast.  One wave per row, 16-byte (or 8-byte) lane accesses laid out so
+// that every wave instruction touches one contiguous 1 KB / 512 B segment.
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "../../include/xq_ops.h"
+
+#include <hip/hip_bf16.h>
+
+using namespace xq;
+
+typedef __hip_bfloat16 bf16;
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return __bfloat162float(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __float2bfloat16(v); }
+
+// vector of VEC elements of T, loaded/stored in one instruction
+template <typename T, int VEC> struct Pack { T v[VEC]; };
+
+template <typename T, int VEC>
+__device__ __forceinline__ void load_vec(const T *p, float (&out)[VEC]) {
+    const Pack<T, VEC> pk = *reinterpret_cast<const Pack<T, VEC> *>(p);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) out[j] = to_f<T>(pk.v[j]);
+}
+template <typename T, int VEC>
+__device__ __forceinline__ void store_vec(T *p, const float (&in)[VEC]) {
+    Pack<T, VEC> pk;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) pk.v[j] = from_f<T>(in[j]);
+    *reinterpret_cast<Pack<T, VEC> *>(p) = pk;
+}
+
+static constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows in flight per block
+static constexpr int MAX_ROW_BLOCKS = 1024;  // also the number of partial rows the finalize kernel reduces
+
+// element index of (chunk k, lane l, j): k*64*VEC + l*VEC + j  -> each wave instruction reads 64*VEC contiguous elements
+template <typename T, int NV, int VEC>
+__global__ __launch_bounds__(ROW_THREADS) void res_ln_fwd_kernel(const float *__restrict__ x, const T *__restrict__ y,
+                                                                 const float *__restrict__ gamma, const float *__restrict__ mask,
+                                                                 long rows, int rows_per_sample, const float *__restrict__ lnw,
+                                                                 const float *__restrict__ lnb, float eps, float *__restrict__ x_new,
+                                                                 T *__restrict__ a, float *__restrict__ mean_out,
+                                                                 float *__restrict__ rstd_out) {
+    constexpr int D = NV * VEC * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const float m = mask ? mask[r / rows_per_sample] : 1.0f;
+        float v[NV][VEC];
+        float s = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = k * 64 * VEC + lane * VEC;
+            load_vec<float, VEC>(x + r * D + c, v[k]);
+            if (y) {
+                float yy[VEC], gg[VEC];
+                load_vec<T, VEC>(y + r * D + c, yy);
+                if (gamma) load_vec<float, VEC>(gamma + c, gg);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) v[k][j] = v[k][j] + m * ((gamma ? gg[j] : 1.0f) * yy[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s += v[k][j];
+            if (x_new) store_vec<float, VEC>(x_new + r * D + c, v[k]);
+        }
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { const float d = v[k][j] - mean; q = __builtin_fmaf(d, d, q); }
+        const float var = wave_sum(q) * (1.0f / D);
+        const float rstd = 1.0f / __builtin_sqrtf(var + eps);
+        if (lane == 0) { mean_out[r] = mean; rstd_out[r] = rstd; }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = k * 64 * VEC + lane * VEC;
+            float ww[VEC], bb[VEC], o[VEC];
+            load_vec<float, VEC>(lnw + c, ww);
+            load_vec<float, VEC>(lnb + c, bb);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) o[j] = (v[k][j] - mean) * rstd * ww[j] + bb[j];
+            store_vec<T, VEC>(a + r * D + c, o);
+        }
+    }
+}
+
+// partials layout: [block][4 quantities][D]: 0 = d_lnw, 1 = d_lnb, 2 = d_gamma, 3 = d_bias(y)
+template <typename T, int NV, int VEC>
+__global__ __launch_bounds__(ROW_THREADS) void res_ln_bwd_kernel(const T *__restrict__ g_a, const float *__restrict__ g_xnew,
+                                                                 const float *__restrict__ x_new, const float *__restrict__ mean,
+                                                                 const float *__restrict__ rstd, const float *__restrict__ lnw,
+                                                                 const T *__restrict__ y, const float *__restrict__ gamma,
+                                                                 const float *__restrict__ mask, long rows, int rows_per_sample,
+                                                                 float *__restrict__ g_x, T *__restrict__ g_y,
+                                                                 float *__restrict__ partials) {
+    constexpr int D = NV * VEC * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float p_w[NV][VEC], p_b[NV][VEC], p_g[NV][VEC], p_y[NV][VEC];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { p_w[k][j] = 0.f; p_b[k][j] = 0.f; p_g[k][j] = 0.f; p_y[k][j] = 0.f; }
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const float m = mask ? mask[r / rows_per_sample] : 1.0f;
+        const float mu = mean[r], rs = rstd[r];
+        float xh[NV][VEC], gxh[NV][VEC];
+        float c1 = 0.0f, c2 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = k * 64 * VEC + lane * VEC;
+            float xv[VEC], ga[VEC], ww[VEC];
+            load_vec<float, VEC>(x_new + r * D + c, xv);
+            if (g_a) load_vec<T, VEC>(g_a + r * D + c, ga);
+            load_vec<float, VEC>(lnw + c, ww);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float g = g_a ? ga[j] : 0.0f;
+                xh[k][j] = (xv[j] - mu) * rs;
+                gxh[k][j] = g * ww[j];
+                p_w[k][j] = __builtin_fmaf(g, xh[k][j], p_w[k][j]);
+                p_b[k][j] += g;
+                c1 += gxh[k][j];
+                c2 = __builtin_fmaf(gxh[k][j], xh[k][j], c2);
+            }
+        }
+        c1 = wave_sum(c1) * (1.0f / D);
+        c2 = wave_sum(c2) * (1.0f / D);
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c = k * 64 * VEC + lane * VEC;
+            float gt[VEC], gx_in[VEC];
+            if (g_xnew) load_vec<float, VEC>(g_xnew + r * D + c, gx_in);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) gt[j] = (g_xnew ? gx_in[j] : 0.0f) + rs * (gxh[k][j] - c1 - xh[k][j] * c2);
+            store_vec<float, VEC>(g_x + r * D + c, gt);
+            if (y) {
+                float yy[VEC], gg[VEC], gy[VEC];
+                load_vec<T, VEC>(y + r * D + c, yy);
+                if (gamma) load_vec<float, VEC>(gamma + c, gg);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) {
+                    gy[j] = m * (gamma ? gg[j] : 1.0f) * gt[j];
+                    p_g[k][j] = __builtin_fmaf(m * yy[j], gt[j], p_g[k][j]);
+                    p_y[k][j] += to_f<T>(from_f<T>(gy[j]));  // the bias gradient sums the stored (rounded) g_y
+                }
+                store_vec<T, VEC>(g_y + r * D + c, gy);
+            }
+        }
+    }
+    // combine the 4 waves of the block, then one partial row per block
+    __shared__ float red[4][4][NV * VEC * 64];
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const int c = k * 64 * VEC + lane * VEC + j;
+            red[wave][0][c] = p_w[k][j]; red[wave][1][c] = p_b[k][j]; red[wave][2][c] = p_g[k][j]; red[wave][3][c] = p_y[k][j];
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 4 * D; i += ROW_THREADS) {
+        const int qn = i / D, c = i - qn * D;
+        partials[((size_t)blockIdx.x * 4 + qn) * D + c] = (red[0][qn][c] + red[1][qn][c]) + (red[2][qn][c] + red[3][qn][c]);
+    }
+}
+
+// out[q][c] (+)= sum over blocks of partials[block][q][c] in a fixed order.  One 256-thread block per 64 columns:
+// 4 row groups x 64 columns, each thread strides over the partial rows of its group (coalesced 256-byte reads),
+// then the 4 groups are combined through LDS.
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float *__restrict__ partials, int nblocks, int nq, int D,
+                                                              float *o0, float *o1, float *o2, float *o3, int accumulate) {
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + cx;  // flat (q, c) index
+    float s = 0.0f;
+    if (i < nq * D) {
+        const int qn = i / D, c = i - qn * D;
+        for (int b = ry; b < nblocks; b += 4) s += partials[((size_t)b * nq + qn) * D + c];
+    }
+    __shared__ float red[4][64];
+    red[ry][cx] = s;
+    __syncthreads();
+    if (ry == 0 && i < nq * D) {
+        const int qn = i / D, c = i - qn * D;
+        float *out = qn == 0 ? o0 : (qn == 1 ? o1 : (qn == 2 ? o2 : o3));
+        if (out) {
+            const float t = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+            out[c] = accumulate ? out[c] + t : t;
+        }
+    }
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ h, long n, T *__restrict__ out) {
+    constexpr int VEC = 16 / sizeof(T);
+    const long nv = n / VEC;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        float v[VEC];
+        load_vec<T, VEC>(h + i * VEC, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = gelu_exact(v[j]);
+        store_vec<T, VEC>(out + i * VEC, v);
+    }
+}
+
+// g_h = g_out * gelu'(h); column partial sums of g_h (fc1 bias gradient): partials[block][H]
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ h, long rows, int H,
+                                                       T *__restrict__ g_h, float *__restrict__ partials) {
+    constexpr int VEC = 16 / sizeof(T);
+    // thread t owns columns [t*VEC, t*VEC+VEC) + k*256*VEC; rows strided over blocks
+    for (int c0 = threadIdx.x * VEC; c0 < H; c0 += 256 * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+            float g[VEC], x[VEC], o[VEC];
+            load_vec<T, VEC>(g_out + r * H + c0, g);
+            load_vec<T, VEC>(h + r * H + c0, x);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                o[j] = g[j] * gelu_grad(x[j]);
+                acc[j] += to_f<T>(from_f<T>(o[j]));
+            }
+            store_vec<T, VEC>(g_h + r * H + c0, o);
+        }
+        if (partials) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) partials[(size_t)blockIdx.x * H + c0 + j] = acc[j];
+        }
+    }
+}
+
+// plain column sum of a [rows][H] matrix of T (qkv bias gradient): partials[block][H]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ g, long rows, int H, float *__restrict__ partials) {
+    constexpr int VEC = 16 / sizeof(T);
+    for (int c0 = threadIdx.x * VEC; c0 < H; c0 += 256 * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+            float v[VEC];
+            load_vec<T, VEC>(g + r * H + c0, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) partials[(size_t)blockIdx.x * H + c0 + j] = acc[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------------
+static int row_blocks(long rows) {
+    long b = (rows + 3) / 4;
+    const long cap = (long)num_cus() * 8;
+    if (b > cap) b = cap;
+    if (b > MAX_ROW_BLOCKS) b = MAX_ROW_BLOCKS;
+    return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" int xq_row_partials_blocks(int64_t rows) { return row_blocks((long)rows); }
+
+#define DISPATCH_D(D, F)                                                           \
+    switch (D) {                                                                   \
+        case 64: F(1, 1); break;                                                   \
+        case 128: F(1, 2); break;                                                  \
+        case 256: F(1, 4); break;                                                  \
+        case 384: F(3, 2); break;                                                  \
+        case 512: F(2, 4); break;                                                  \
+        case 768: F(3, 4); break;                                                  \
+        case 1024: F(4, 4); break;                                                 \
+        default: return xq_set_error(XQ_EINVAL, "%s: unsupported width D=%ld (64,128,256,384,512,768,1024)", fn, D); \
+    }
+
+extern "C" int xq_res_ln_forward(const float *x, const void *y, const float *gamma, const float *mask, int64_t rows, int D,
+                                 int rows_per_sample, const float *lnw, const float *lnb, float eps, int act_bf16, float *x_new,
+                                 void *a, float *mean, float *rstd, xq_stream_t stream) {
+    const char *fn = "xq_res_ln_forward";
+    if (rows == 0) return XQ_OK;
+    if (!x || !lnw || !lnb || !a || !mean || !rstd) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (rows < 0 || rows_per_sample < 1) return xq_set_error(XQ_EINVAL, "%s: bad rows", fn);
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = row_blocks(rows);
+#define FWD_BF16(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const bf16 *)y, \
+        gamma, mask, (long)rows, rows_per_sample, lnw, lnb, eps, x_new, (bf16 *)a, mean, rstd)
+#define FWD_F32(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const float *)y, \
+        gamma, mask, (long)rows, rows_per_sample, lnw, lnb, eps, x_new, (float *)a, mean, rstd)
+    if (act_bf16) { DISPATCH_D(D, FWD_BF16) } else { DISPATCH_D(D, FWD_F32) }
+#undef FWD_BF16
+#undef FWD_F32
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_res_ln_backward(const void *g_a, const float *g_xnew, const float *x_new, const float *mean, const float *rstd,
+                                  const float *lnw, const void *y, const float *gamma, const float *mask, int64_t rows, int D,
+                                  int rows_per_sample, int act_bf16, float *g_x, void *g_y, float *g_lnw, float *g_lnb,
+                                  float *g_gamma, float *g_ybias, int accumulate, float *partials, xq_stream_t stream) {
+    const char *fn = "xq_res_ln_backward";
+    if (rows == 0) return XQ_OK;
+    if (!x_new || !mean || !rstd || !lnw || !g_x || !partials) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (y && !g_y) return xq_set_error(XQ_EINVAL, "%s: g_y required when y is given", fn);
+    hipStream_t s = (hipStream_t)stream;
+    const int blocks = row_blocks(rows);
+#define BWD_BF16(NV, VEC) hipLaunchKernelGGL((res_ln_bwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const bf16 *)g_a, g_xnew, \
+        x_new, mean, rstd, lnw, (const bf16 *)y, gamma, mask, (long)rows, rows_per_sample, g_x, (bf16 *)g_y, partials)
+#define BWD_F32(NV, VEC) hipLaunchKernelGGL((res_ln_bwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const float *)g_a, g_xnew, \
+        x_new, mean, rstd, lnw, (const float *)y, gamma, mask, (long)rows, rows_per_sample, g_x, (float *)g_y, partials)
+    if (act_bf16) { DISPATCH_D(D, BWD_BF16) } else { DISPATCH_D(D, BWD_F32) }
+#undef BWD_BF16
+#undef BWD_F32
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((4 * D + 63) / 64), dim3(256), 0, s, partials, blocks, 4, D, g_lnw, g_lnb, g_gamma, g_ybias,
+                       accumulate);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_gelu_forward(const void *h, int64_t n, int act_bf16, void *out, xq_stream_t stream) {
+    const char *fn = "xq_gelu_forward";
+    if (n == 0) return XQ_OK;
+    if (!h || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const int vec = act_bf16 ? 8 : 4;
+    if (n % vec) return xq_set_error(XQ_EINVAL, "%s: n=%ld must be a multiple of the 16-byte vector", fn, (long)n);
+    long blocks = (n / vec + 255) / 256;
+    const long cap = (long)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16 *)h, (long)n, (bf16 *)out);
+    else hipLaunchKernelGGL((gelu_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)h, (long)n, (float *)out);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, int H, int act_bf16, void *g_h, float *g_bias,
+                                int accumulate, float *partials, xq_stream_t stream) {
+    const char *fn = "xq_gelu_backward";
+    if (rows == 0) return XQ_OK;
+    if (!g_out || !h || !g_h) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const int vec = act_bf16 ? 8 : 4;
+    if (H % vec) return xq_set_error(XQ_EINVAL, "%s: H=%ld must be a multiple of the 16-byte vector", fn, H);
+    if (g_bias && !partials) return xq_set_error(XQ_EINVAL, "%s: partials workspace required for the bias gradient", fn);
+    const int blocks = row_blocks(rows * 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16>), dim3(blocks), dim3(256), 0, s, (const bf16 *)g_out, (const bf16 *)h, (long)rows, H, (bf16 *)g_h, g_bias ? partials : nullptr);
+    else hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)g_out, (const float *)h, (long)rows, H, (float *)g_h, g_bias ? partials : nullptr);
+    if (g_bias)
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + 63) / 64), dim3(256), 0, s, partials, blocks, 1, H, g_bias, nullptr, nullptr, nullptr, accumulate);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_colsum(const void *g, int64_t rows, int H, int act_bf16, float *out, int accumulate, float *partials,
+                         xq_stream_t stream) {
+    const char *fn = "xq_colsum";
+    if (rows == 0) return XQ_OK;
+    if (!g || !out || !partials) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const int vec = act_bf16 ? 8 : 4;
+    if (H % vec) return xq_set_error(XQ_EINVAL, "%s: H=%ld must be a multiple of the 16-byte vector", fn, H);
+    const int blocks = row_blocks(rows * 4);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) hipLaunchKernelGGL((colsum_kernel<bf16>), dim3(blocks), dim3(256), 0, s, (const bf16 *)g, (long)rows, H, partials);
+    else hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)g, (long)rows, H, partials);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + 63) / 64), dim3(256), 0, s, partials, blocks, 1, H, out, nullptr, nullptr, nullptr, accumulate);
+    return xq_check_launch(fn);
+}

@@ -5,6 +5,7 @@
 //   update_ema(ema, model, decay=0.9999)   utils/ema.py:5-14, xqgan_train.py:461-462
 //   optimizer.zero_grad()                  xqgan_train.py:447
 //   the 1/world_size of DDP's gradient mean (folded in as grad_scale)
+// (+ optional bf16 shadow copy of p for the GEMMs)
 // One elementwise pass: reads p, g, m, v, ema (20 B/param), writes p, m, v, ema (+g = 0) (16-20 B/param):
 // HBM-bound, 36-40 algorithmic bytes per parameter.  float4 accesses, grid-stride.
 #include "xq_common.hpp"
@@ -12,6 +13,7 @@
 #include "../../include/xq_ops.h"
 
 #include <math.h>
+#include <hip/hip_bf16.h>
 
 struct AdamArgs {
     float lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, ema_decay, grad_scale;
@@ -30,7 +32,8 @@ __device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, fl
 }
 
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
-                                                        float *__restrict__ v, float *__restrict__ ema, long n, AdamArgs a) {
+                                                        float *__restrict__ v, float *__restrict__ ema,
+                                                        __hip_bfloat16 *__restrict__ p16, long n, AdamArgs a) {
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * 256;
     float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g), *m4 = reinterpret_cast<float4 *>(m),
@@ -43,6 +46,11 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, f
         adam1(pp.z, gg.z, mm.z, vv.z, ee.z, a);
         adam1(pp.w, gg.w, mm.w, vv.w, ee.w, a);
         p4[i] = pp; m4[i] = mm; v4[i] = vv;
+        if (p16) {  // bf16 shadow of the master weights: the GEMMs read it, no per-step cast kernels
+            struct alignas(8) B4 { __hip_bfloat16 x, y, z, w; } o = {__float2bfloat16(pp.x), __float2bfloat16(pp.y),
+                                                                     __float2bfloat16(pp.z), __float2bfloat16(pp.w)};
+            reinterpret_cast<B4 *>(p16)[i] = o;
+        }
         if (a.has_ema) e4[i] = ee;
         if (a.zero_grad) g4[i] = gg;
     }
@@ -51,13 +59,14 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, f
     if (blockIdx.x == 0 && t < n) {
         float ee = a.has_ema ? ema[t] : 0.0f;
         adam1(p[t], g[t], m[t], v[t], ee, a);
+        if (p16) p16[t] = __float2bfloat16(p[t]);
         if (a.has_ema) ema[t] = ee;
     }
 }
 
-extern "C" int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, int64_t n, float lr, float beta1,
-                                 float beta2, float eps, float weight_decay, int64_t step, float ema_decay, float grad_scale,
-                                 int zero_grad, xq_stream_t stream) {
+extern "C" int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int64_t step, float ema_decay,
+                                 float grad_scale, int zero_grad, xq_stream_t stream) {
     if (n == 0) return XQ_OK;
     if (!p || !g || !m || !v) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_adamw_ema_step");
     if (n < 0 || step < 1) return xq_set_error(XQ_EINVAL, "%s: bad n/step (%ld, %ld)", "xq_adamw_ema_step", (long)n, (long)step);
@@ -75,6 +84,7 @@ extern "C" int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *
     const long cap = (long)num_cus() * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (long)n, a);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (__hip_bfloat16 *)p_bf16,
+                       (long)n, a);
     return xq_check_launch("adamw_ema_kernel");
 }

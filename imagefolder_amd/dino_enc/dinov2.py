@@ -86,13 +86,12 @@ class DINOv2Encoder(nn.Module):
                     z_list = z.view(x.size(0), P * H, W, -1).chunk(chunks=P, dim=1)
                     z_list = [m._pos_embed(zz)[:, 1:, ] for zz in z_list]  # cls stripped (:164,171)
                     x = torch.cat([x, ] + z_list, dim=1)
-                    x = x + self.lvl_embed(self.lvl1LC.expand(x.size(0), -1))
+                    x = x + self.lvl_embed(self.lvl1LC)  # (1, L, D) broadcast over the batch (upstream expands the index first)
                 else:
                     x = torch.cat([x, z + self.latent_pos_embed], dim=1)
         if torch.is_autocast_enabled() and x.is_cuda:
-            x = x.to(torch.get_autocast_gpu_dtype())  # upstream probes the matmul dtype (:177-179)
-        x = m.blocks(x)
-        x = nn_ops.layer_norm(x, m.norm.weight, m.norm.bias, m.norm.eps)
+            x = x.to(torch.get_autocast_dtype('cuda'))  # upstream probes the matmul dtype (:177-179)
+        x = nn_ops.vit_blocks(m.blocks, x, m.norm)
         if self.num_latent_tokens:
             return x[:, -self.num_latent_tokens:]
         return x[:, self.num_prefix_tokens:]
@@ -161,10 +160,9 @@ class DINOv2Decoder(nn.Module):
                 z = z.float() + self.latent_pos_embed
             x = torch.cat([x, z], dim=1)
             if self.abs_pos_embed:
-                x = x + self.lvl_embed(self.lvl1LC.expand(x.size(0), -1))
+                x = x + self.lvl_embed(self.lvl1LC)  # (1, L, D) broadcast over the batch (upstream expands the index first)
         if torch.is_autocast_enabled() and x.is_cuda:
-            x = x.to(torch.get_autocast_gpu_dtype())
-        x = m.blocks(x)
-        x = nn_ops.layer_norm(x, m.norm.weight, m.norm.bias, m.norm.eps)
+            x = x.to(torch.get_autocast_dtype('cuda'))
+        x = nn_ops.vit_blocks(m.blocks, x, m.norm)
         x = x[:, self.num_prefix_tokens:self.num_img_tokens + self.num_prefix_tokens]
         return self.to_pixel(x)

@@ -93,7 +93,8 @@ class DropPath(nn.Module):
             return None
         keep_prob = 1 - self.drop_prob
         shape = (x.shape[0],) + (1,) * (x.ndim - 1)
-        m = x.new_empty(shape).bernoulli_(keep_prob)
+        # fp32 like upstream, where the masked tensor is the fp32 LayerScale output under autocast
+        m = torch.empty(shape, dtype=torch.float32, device=x.device).bernoulli_(keep_prob)
         if keep_prob > 0.0:
             m.div_(keep_prob)
         return m
@@ -221,8 +222,7 @@ class VisionTransformer(nn.Module):
     def forward_features(self, x):
         x = self.patch_embed(x)
         x = self._pos_embed(x)
-        x = self.blocks(x)
-        return nn_ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return nn_ops.vit_blocks(self.blocks, x, self.norm)
 
     def forward(self, x):
         x = self.forward_features(x)

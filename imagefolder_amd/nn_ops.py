@@ -26,6 +26,9 @@ IMPL = {
 
 _HIP = {}
 
+# ViT blocks as fused HIP row kernels + library GEMMs/SDPA (ops_dense.run_blocks) instead of per-op ATen calls
+FUSED_BLOCKS = True
+
 
 def register_hip(name, fn):
     """ops_dense.py registers its autograd Functions here when libxq_ops.so provides the kernel."""
@@ -41,6 +44,19 @@ def use(name, impl):
 
 def _hip(name):
     return _HIP[name] if IMPL.get(name) == "hip" else None
+
+
+def vit_blocks(blocks, x, final_norm):
+    """final_norm(blocks(x)) for a stack of pre-LN transformer blocks (dino_enc/vision_transformer.py:295-339,:958-959)."""
+    if FUSED_BLOCKS and x.is_cuda:
+        from . import ops_dense
+        if ops_dense.fused_supported(x, blocks):
+            act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+            IMPL["vit_block_rows"] = "hip"
+            return ops_dense.run_blocks(list(blocks), x, final_norm, act)
+    IMPL["vit_block_rows"] = "aten"
+    x = blocks(x)
+    return layer_norm(x, final_norm.weight, final_norm.bias, final_norm.eps)
 
 
 def layer_norm(x, weight, bias, eps):

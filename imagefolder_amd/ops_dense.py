@@ -1,0 +1,261 @@
+"""Autograd Functions over the fused row kernels of csrc/xq_dense.hip + the fused ViT block runner.
+
+The reference runs each timm block (dino_enc/vision_transformer.py:295-339) as ~25 ATen ops on an fp32 residual
+stream (that is what bf16 autocast does to `x + drop_path(ls(attn(norm(x))))`).  Here a block is 8 autograd nodes:
+
+    a  = LN1(x)                                   (produced by the previous ResLN)
+    qkv = a @ Wqkv^T + b        -> attention -> o -> p = o @ Wproj^T + b          (library GEMMs / SDPA)
+    x, a2 = ResLN(x, p, ls1.gamma, droppath mask, norm2)                           (xq_res_ln_forward)
+    h  = a2 @ W1^T + b1 ;  hg = GELU(h)                                             (xq_gelu_forward)
+    f  = hg @ W2^T + b2
+    x, a' = ResLN(x, f, ls2.gamma, droppath mask, next block's norm1 | final norm)
+
+with the bias gradients of proj / fc2 / fc1 coming out of the fused backward kernels (column partial sums) and the
+GEMMs reading a bf16 shadow of the fp32 master weights (written by the optimizer kernel) instead of re-casting them.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib
+from ._lib import XqError, check, ptr
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _act_flag(dtype):
+    if dtype == torch.bfloat16:
+        return 1
+    if dtype == torch.float32:
+        return 0
+    raise XqError(f"activation dtype {dtype} not supported (bf16 / fp32)")
+
+
+def _partials(rows, width, quantities, device):
+    nb = _lib.lib().xq_row_partials_blocks(rows)
+    return torch.empty(nb * quantities * width, dtype=torch.float32, device=device)
+
+
+SUPPORTED_D = (64, 128, 256, 384, 512, 768, 1024)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """a = LayerNorm(x) (fp32 statistics, output in `out_dtype`): the y-less form of xq_res_ln_forward."""
+
+    @staticmethod
+    def forward(ctx, x, lnw, lnb, eps, out_dtype):
+        B, N, D = x.shape
+        x32 = x.detach().float().contiguous()
+        a = torch.empty(B, N, D, dtype=out_dtype, device=x.device)
+        mean = torch.empty(B * N, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        w, b = lnw.detach().float().contiguous(), lnb.detach().float().contiguous()
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().xq_res_ln_forward(ptr(x32), None, None, None, B * N, D, N, ptr(w), ptr(b), ctypes.c_float(eps),
+                                              _act_flag(out_dtype), None, ptr(a), ptr(mean), ptr(rstd), _stream(x))
+        check(rc, "xq_res_ln_forward")
+        ctx.save_for_backward(x32, mean, rstd, w)
+        ctx.in_dtype = x.dtype
+        return a
+
+    @staticmethod
+    def backward(ctx, g_a):
+        x32, mean, rstd, w = ctx.saved_tensors
+        B, N, D = x32.shape
+        g_a = g_a.contiguous()
+        g_x = torch.empty_like(x32)
+        g_w = torch.empty(D, dtype=torch.float32, device=x32.device)
+        g_b = torch.empty_like(g_w)
+        part = _partials(B * N, D, 4, x32.device)
+        with torch.cuda.device(x32.device):
+            rc = _lib.lib().xq_res_ln_backward(ptr(g_a), None, ptr(x32), ptr(mean), ptr(rstd), ptr(w), None, None, None, B * N, D, N,
+                                               _act_flag(g_a.dtype), ptr(g_x), None, ptr(g_w), ptr(g_b), None, None, 0, ptr(part),
+                                               _stream(x32))
+        check(rc, "xq_res_ln_backward")
+        return g_x.to(ctx.in_dtype), g_w, g_b, None, None
+
+
+class ResLNFn(torch.autograd.Function):
+    """x_new = x + mask * (gamma * y);  a = LayerNorm(x_new).  `ybias` (the bias of the Linear that produced y) is an
+    input only so that its gradient (column sums of g_y) can be returned from the fused backward."""
+
+    @staticmethod
+    def forward(ctx, x, y, gamma, mask, lnw, lnb, eps, ybias):
+        B, N, D = x.shape
+        x32 = x.detach().float().contiguous()
+        yc = y.detach().contiguous()
+        dev = x.device
+        x_new = torch.empty(B, N, D, dtype=torch.float32, device=dev)
+        a = torch.empty(B, N, D, dtype=yc.dtype, device=dev)
+        mean = torch.empty(B * N, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        w, b = lnw.detach().float().contiguous(), lnb.detach().float().contiguous()
+        g = None if gamma is None else gamma.detach().float().contiguous()
+        m = None if mask is None else mask.detach().float().reshape(-1).contiguous()
+        with torch.cuda.device(dev):
+            rc = _lib.lib().xq_res_ln_forward(ptr(x32), ptr(yc), ptr(g), ptr(m), B * N, D, N, ptr(w), ptr(b), ctypes.c_float(eps),
+                                              _act_flag(yc.dtype), ptr(x_new), ptr(a), ptr(mean), ptr(rstd), _stream(x))
+        check(rc, "xq_res_ln_forward")
+        ctx.save_for_backward(x_new, mean, rstd, w, yc, g, m)
+        ctx.has = (gamma is not None, mask is not None, ybias is not None)
+        ctx.in_dtype = x.dtype
+        return x_new, a
+
+    @staticmethod
+    def backward(ctx, g_xnew, g_a):
+        x_new, mean, rstd, w, yc, g, m = ctx.saved_tensors
+        has_gamma, has_mask, has_ybias = ctx.has
+        B, N, D = x_new.shape
+        dev = x_new.device
+        g_a = None if g_a is None else g_a.contiguous()
+        g_xn = None if g_xnew is None else g_xnew.float().contiguous()
+        g_x = torch.empty_like(x_new)
+        g_y = torch.empty_like(yc)
+        g_w = torch.empty(D, dtype=torch.float32, device=dev)
+        g_b = torch.empty_like(g_w)
+        g_g = torch.empty_like(g_w) if has_gamma else None
+        g_yb = torch.empty_like(g_w) if has_ybias else None
+        part = _partials(B * N, D, 4, dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().xq_res_ln_backward(ptr(g_a), ptr(g_xn), ptr(x_new), ptr(mean), ptr(rstd), ptr(w), ptr(yc),
+                                               ptr(g) if has_gamma else None, ptr(m) if has_mask else None, B * N, D, N,
+                                               _act_flag(yc.dtype), ptr(g_x), ptr(g_y), ptr(g_w), ptr(g_b), ptr(g_g), ptr(g_yb), 0,
+                                               ptr(part), _stream(x_new))
+        check(rc, "xq_res_ln_backward")
+        return g_x.to(ctx.in_dtype), g_y, g_g, None, g_w, g_b, None, g_yb
+
+
+class GeluFn(torch.autograd.Function):
+    """hg = GELU(h) (exact erf form, nn.GELU()); `bias` = fc1.bias, present only to receive its gradient."""
+
+    @staticmethod
+    def forward(ctx, h, bias):
+        hc = h.detach().contiguous()
+        out = torch.empty_like(hc)
+        with torch.cuda.device(h.device):
+            rc = _lib.lib().xq_gelu_forward(ptr(hc), hc.numel(), _act_flag(hc.dtype), ptr(out), _stream(h))
+        check(rc, "xq_gelu_forward")
+        ctx.save_for_backward(hc)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (hc,) = ctx.saved_tensors
+        H = hc.shape[-1]
+        rows = hc.numel() // H
+        g = g.contiguous()
+        g_h = torch.empty_like(hc)
+        g_b = torch.empty(H, dtype=torch.float32, device=hc.device) if ctx.has_bias else None
+        nb = _lib.lib().xq_row_partials_blocks(rows * 4)
+        part = torch.empty(nb * H, dtype=torch.float32, device=hc.device) if ctx.has_bias else None
+        with torch.cuda.device(hc.device):
+            rc = _lib.lib().xq_gelu_backward(ptr(g), ptr(hc), rows, H, _act_flag(hc.dtype), ptr(g_h), ptr(g_b), 0, ptr(part),
+                                             _stream(hc))
+        check(rc, "xq_gelu_backward")
+        return g_h, g_b
+
+
+def _w16(weight):
+    """bf16 copy of a weight: the optimizer-maintained shadow for trainable params (train.FlatArena), a cached cast
+    for frozen ones (semantic teacher), an on-the-fly cast otherwise."""
+    w16 = getattr(weight, "_xq_w16", None)
+    if w16 is not None:
+        return w16
+    if not weight.requires_grad:
+        cache = getattr(weight, "_xq_w16_frozen", None)
+        if cache is None or cache[0] != weight._version or cache[1].device != weight.device:
+            cache = (weight._version, weight.detach().to(torch.bfloat16))
+            weight._xq_w16_frozen = cache
+        return cache[1]
+    return weight.detach().to(torch.bfloat16)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x @ W^T + b as library GEMMs (hipBLASLt through torch.addmm / mm): plain GEMMs are library calls by design.
+    bf16 activations read the bf16 weight shadow; weight gradients are produced in fp32 straight from the GEMM.
+    bias_grad_external: the bias gradient is delivered by the fused kernel that consumes/produces g_y."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, bias_grad_external):
+        shp = x.shape
+        x2 = x.detach().reshape(-1, shp[-1])
+        if x2.dtype == torch.bfloat16:
+            W = _w16(weight)
+            b = None if bias is None else bias.detach().to(torch.bfloat16)
+        else:
+            W = weight.detach()
+            b = None if bias is None else bias.detach()
+        y = torch.addmm(b, x2, W.t()) if b is not None else torch.mm(x2, W.t())
+        ctx.save_for_backward(x2, W)
+        ctx.meta = (shp, weight.dtype, bias is not None and not bias_grad_external, bias is not None)
+        return y.view(*shp[:-1], W.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, W = ctx.saved_tensors
+        shp, wdtype, want_bias, has_bias = ctx.meta
+        g2 = g.reshape(-1, g.shape[-1])
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        g_x = torch.mm(g2, W).view(shp)
+        if g2.dtype == torch.bfloat16:
+            try:
+                g_w = torch.mm(g2.t(), x2, out_dtype=torch.float32)  # fp32 straight out of the GEMM
+            except TypeError:
+                g_w = torch.mm(g2.t(), x2).to(wdtype)
+        else:
+            g_w = torch.mm(g2.t(), x2)
+        g_b = None
+        if want_bias:
+            H = g2.shape[1]
+            g_b = torch.empty(H, dtype=torch.float32, device=g2.device)
+            nb = _lib.lib().xq_row_partials_blocks(g2.shape[0] * 4)
+            part = torch.empty(nb * H, dtype=torch.float32, device=g2.device)
+            with torch.cuda.device(g2.device):
+                rc = _lib.lib().xq_colsum(ptr(g2), g2.shape[0], H, _act_flag(g2.dtype), ptr(g_b), 0, ptr(part), _stream(g2))
+            check(rc, "xq_colsum")
+        return g_x, g_w, g_b, None
+
+
+def attention_qkvpacked(qkv, num_heads):
+    """(B, N, 3*C) -> (B, N, C): library SDPA (flash kernels) on strided q/k/v views of the packed projection."""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    q, k, v = qkv.view(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+    x = F.scaled_dot_product_attention(q, k, v)
+    return x.transpose(1, 2).reshape(B, N, C)
+
+
+def fused_supported(x, blocks):
+    D = x.shape[-1]
+    return x.is_cuda and D in SUPPORTED_D and len(blocks) > 0
+
+
+def run_blocks(blocks, x, final_norm, act_dtype):
+    """x: (B, N, D) tokens entering block 0 -> final_norm(blocks(x)) in act_dtype, via the fused kernels.
+    The DropPath masks are drawn in the reference's order (drop_path1 then drop_path2 of each block)."""
+    from .dino_enc.vision_transformer import DropPath, LayerScale
+    x = x.contiguous()
+    b0 = blocks[0]
+    a = LayerNormFn.apply(x, b0.norm1.weight, b0.norm1.bias, b0.norm1.eps, act_dtype)
+    n = len(blocks)
+    for i, blk in enumerate(blocks):
+        at = blk.attn
+        qkv = LinearFn.apply(a, at.qkv.weight, at.qkv.bias, False)
+        o = attention_qkvpacked(qkv, at.num_heads)
+        p = LinearFn.apply(o, at.proj.weight, at.proj.bias, True)
+        g1 = blk.ls1.gamma if isinstance(blk.ls1, LayerScale) else None
+        m1 = blk.drop_path1.keep_mask(p) if isinstance(blk.drop_path1, DropPath) else None
+        x, a = ResLNFn.apply(x, p, g1, m1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, at.proj.bias)
+        h = LinearFn.apply(a, blk.mlp.fc1.weight, blk.mlp.fc1.bias, True)
+        hg = GeluFn.apply(h, blk.mlp.fc1.bias)
+        f = LinearFn.apply(hg, blk.mlp.fc2.weight, blk.mlp.fc2.bias, True)
+        g2 = blk.ls2.gamma if isinstance(blk.ls2, LayerScale) else None
+        m2 = blk.drop_path2.keep_mask(f) if isinstance(blk.drop_path2, DropPath) else None
+        nxt = blocks[i + 1].norm1 if i + 1 < n else final_norm
+        x, a = ResLNFn.apply(x, f, g2, m2, nxt.weight, nxt.bias, nxt.eps, blk.mlp.fc2.bias)
+    return a

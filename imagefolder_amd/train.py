@@ -52,6 +52,8 @@ class FlatArena:
         self.m = torch.zeros(n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(n, dtype=torch.float32, device=dev)
         self.ema = torch.zeros(n, dtype=torch.float32, device=dev) if with_ema else None
+        # bf16 shadow of the masters, refreshed by the optimizer kernel; the dense ops read it through p._xq_w16
+        self.p16 = torch.zeros(n, dtype=torch.bfloat16, device=dev) if dev.type == "cuda" else None
         with torch.no_grad():
             for p, o in zip(self.params, self.offsets):
                 self.p[o:o + p.numel()].copy_(p.data.reshape(-1))
@@ -59,6 +61,10 @@ class FlatArena:
                 p.grad = self.g[o:o + p.numel()].view(p.shape)
             if with_ema:
                 self.ema.copy_(self.p)  # ema = deepcopy(model) (xqgan_train.py:316)
+            if self.p16 is not None:
+                self.p16.copy_(self.p)
+                for p, o in zip(self.params, self.offsets):
+                    p._xq_w16 = self.p16[o:o + p.numel()].view(p.shape)
         self.step_count = 0
 
     def rebind_grads(self):
@@ -126,7 +132,7 @@ class TokenizerTrainStep:
         a.step_count += 1
         if a.p.is_cuda:
             with torch.cuda.device(a.p.device):
-                rc = _lib.lib().xq_adamw_ema_step(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), a.numel,
+                rc = _lib.lib().xq_adamw_ema_step(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
                                                   ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
                                                   ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
                                                   ctypes.c_float(self.weight_decay), a.step_count,

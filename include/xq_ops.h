@@ -145,11 +145,45 @@ int xq_msvq_backward(const float *f, int B, int C, int H, int W, int V, const in
  * One pass over n parameters: AdamW (torch.optim.AdamW single-tensor semantics, amsgrad=False, maximize=False) on
  * p with gradient g*grad_scale (grad_scale = 1/world_size folds DDP's mean), first/second moments m/v, bias
  * correction for the 1-based `step`; then ema = ema*ema_decay + p*(1-ema_decay) (ema nullable); g is zeroed when
- * zero_grad != 0.  All arenas: device fp32, 16-byte aligned, n elements.
+ * zero_grad != 0; p_bf16 (nullable, bf16 [n]) receives a bf16 shadow copy of the updated p (read by the GEMMs
+ * instead of re-casting the fp32 masters every step).  All arenas: device, 16-byte aligned, n elements.
  */
-int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, int64_t n, float lr, float beta1, float beta2,
-                      float eps, float weight_decay, int64_t step, float ema_decay, float grad_scale, int zero_grad,
-                      xq_stream_t stream);
+int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr, float beta1,
+                      float beta2, float eps, float weight_decay, int64_t step, float ema_decay, float grad_scale,
+                      int zero_grad, xq_stream_t stream);
+
+/* ---- fused row kernels of the ViT blocks (dino_enc/vision_transformer.py:280-339; timm Mlp) ------------------------
+ * Activations are [rows][D] row-major; act_bf16 selects their dtype (1 = bf16, 0 = fp32); the residual stream,
+ * LayerNorm statistics and all parameter tensors are fp32 (what bf16 autocast does upstream). */
+
+/* number of per-block partial rows the backward kernels write (size the `partials` workspace with it) */
+int xq_row_partials_blocks(int64_t rows);
+
+/* x_new = x + mask[row / rows_per_sample] * (gamma * y)   (LayerScale :291, DropPath, residual :337-338; y/gamma/mask
+ * nullable); a = LayerNorm(x_new; lnw, lnb, eps) (:310,323; final norm :959).  x_new (nullable when y is null),
+ * mean/rstd [rows] fp32 are saved for the backward.  D in {64,128,256,384,512,768,1024}. */
+int xq_res_ln_forward(const float *x, const void *y, const float *gamma, const float *mask, int64_t rows, int D,
+                      int rows_per_sample, const float *lnw, const float *lnb, float eps, int act_bf16, float *x_new,
+                      void *a, float *mean, float *rstd, xq_stream_t stream);
+
+/* transpose of the above.  g_a: grad of a (nullable); g_xnew: grad arriving on the residual stream (nullable).
+ * Outputs: g_x [rows][D] fp32 (grad of x), g_y (dtype of y; required when y is given), and the parameter grads
+ * g_lnw, g_lnb, g_gamma, g_ybias (= column sums of g_y: the bias grad of the Linear that produced y), each [D]
+ * fp32, nullable, overwritten or accumulated.  partials: workspace of xq_row_partials_blocks(rows)*4*D floats. */
+int xq_res_ln_backward(const void *g_a, const float *g_xnew, const float *x_new, const float *mean, const float *rstd,
+                       const float *lnw, const void *y, const float *gamma, const float *mask, int64_t rows, int D,
+                       int rows_per_sample, int act_bf16, float *g_x, void *g_y, float *g_lnw, float *g_lnb,
+                       float *g_gamma, float *g_ybias, int accumulate, float *partials, xq_stream_t stream);
+
+/* exact (erf) GELU, nn.GELU() of timm's Mlp; n elements (multiple of the 16-byte vector) */
+int xq_gelu_forward(const void *h, int64_t n, int act_bf16, void *out, xq_stream_t stream);
+/* g_h = g_out * gelu'(h); g_bias (nullable) [H] = column sums of g_h (the fc1 bias gradient);
+ * partials: xq_row_partials_blocks(rows*4)*H floats */
+int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, int H, int act_bf16, void *g_h, float *g_bias,
+                     int accumulate, float *partials, xq_stream_t stream);
+/* out[H] (+)= column sums of g [rows][H] (bias gradient of a Linear); partials as above */
+int xq_colsum(const void *g, int64_t rows, int H, int act_bf16, float *out, int accumulate, float *partials,
+              xq_stream_t stream);
 
 /* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
  *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the

@@ -1,0 +1,147 @@
+"""GPU numerics of the fused ViT row kernels vs the plain PyTorch fp32 reference of the same op (ATen), and of the
+fused block runner vs the per-op path (fp32: tight; bf16: vs the autocast ATen path)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_res_ln(x, y, gamma, mask, w, b, eps):
+    yy = y.float()
+    if gamma is not None:
+        yy = yy * gamma
+    if mask is not None:
+        yy = yy * mask.view(-1, 1, 1)
+    xn = x + yy
+    return xn, F.layer_norm(xn, (x.shape[-1],), w, b, eps)
+
+
+@pytest.mark.parametrize("D", [64, 128, 384, 768, 1024])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_res_ln_forward_backward(D, dt):
+    from imagefolder_amd.ops_dense import ResLNFn, LayerNormFn
+    torch.manual_seed(D)
+    B, N = 3, 37
+    dev = "cuda"
+    x = torch.randn(B, N, D, device=dev, requires_grad=True)
+    y = torch.randn(B, N, D, device=dev).to(dt).requires_grad_(True)
+    gamma = (torch.rand(D, device=dev) + 0.5).requires_grad_(True)
+    mask = torch.tensor([1.0 / 0.9, 0.0, 1.0 / 0.9], device=dev)
+    w = (torch.rand(D, device=dev) + 0.5).requires_grad_(True)
+    b = torch.randn(D, device=dev).requires_grad_(True)
+    yb = torch.zeros(D, device=dev, requires_grad=True)
+    xn, a = ResLNFn.apply(x, y, gamma, mask, w, b, 1e-6, yb)
+    gx, ga = torch.randn_like(xn), torch.randn_like(a)
+    torch.autograd.backward([xn, a], [gx, ga])
+    got = [t.grad.clone() for t in (x, y, gamma, w, b, yb)]
+    for t in (x, y, gamma, w, b):
+        t.grad = None
+    rxn, ra = _ref_res_ln(x, y, gamma, mask, w, b, 1e-6)
+    torch.autograd.backward([rxn, ra], [gx, ga.float()])
+    tol = 2e-5 if dt == torch.float32 else 2e-2
+    assert (xn - rxn).abs().max() <= 1e-5
+    assert (a.float() - ra).abs().max() <= tol
+    ref = [x.grad, y.grad, gamma.grad, w.grad, b.grad]
+    for g_, r_, nm in zip(got[:5], ref, ["x", "y", "gamma", "lnw", "lnb"]):
+        scale = r_.float().abs().max().item() + 1e-6
+        assert (g_.float() - r_.float()).abs().max().item() <= tol * scale * 4, nm
+    # bias-gradient by-product = column sums of g_y
+    assert (got[5] - got[1].float().sum((0, 1))).abs().max() <= 1e-2 * (got[5].abs().max() + 1)
+    # y-less form
+    x2 = torch.randn(B, N, D, device=dev, requires_grad=True)
+    a2 = LayerNormFn.apply(x2, w, b, 1e-6, dt)
+    r2 = F.layer_norm(x2, (D,), w, b, 1e-6)
+    assert (a2.float() - r2).abs().max() <= tol
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gelu_and_linear_functions(dt):
+    from imagefolder_amd.ops_dense import GeluFn, LinearFn
+    torch.manual_seed(1)
+    dev = "cuda"
+    h = (torch.randn(5, 33, 3072, device=dev) * 2).to(dt).requires_grad_(True)
+    bias = torch.zeros(3072, device=dev, requires_grad=True)
+    out = GeluFn.apply(h, bias)
+    g = torch.randn_like(out)
+    out.backward(g)
+    href = h.detach().float().requires_grad_(True)
+    oref = F.gelu(href)
+    oref.backward(g.float())
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert (out.float() - oref).abs().max() <= tol
+    assert (h.grad.float() - href.grad).abs().max() <= tol * 4
+    assert (bias.grad - h.grad.float().sum((0, 1))).abs().max() <= 1e-2 * (bias.grad.abs().max() + 1)
+    # Linear
+    x = torch.randn(4, 9, 64, device=dev).to(dt).requires_grad_(True)
+    W = torch.randn(96, 64, device=dev, requires_grad=True)
+    bb = torch.randn(96, device=dev, requires_grad=True)
+    y = LinearFn.apply(x, W, bb, False)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x.detach().float().requires_grad_(True)
+    Wr = W.detach().clone().requires_grad_(True)
+    br = bb.detach().clone().requires_grad_(True)
+    yr = F.linear(xr, Wr, br)
+    yr.backward(gy.float())
+    tl = 1e-4 if dt == torch.float32 else 5e-2
+    assert (y.float() - yr).abs().max() <= tl * yr.abs().max()
+    assert (x.grad.float() - xr.grad).abs().max() <= tl * xr.grad.abs().max()
+    assert (W.grad - Wr.grad).abs().max() <= tl * Wr.grad.abs().max()
+    assert (bb.grad - br.grad).abs().max() <= tl * br.grad.abs().max()
+
+
+def _tiny_vit(depth=3, D=64, heads=4, dp=0.0):
+    from imagefolder_amd.dino_enc.vision_transformer import VisionTransformer
+    torch.manual_seed(0)
+    m = VisionTransformer(img_size=16, patch_size=4, embed_dim=D, depth=depth, num_heads=heads, init_values=0.3,
+                          drop_path_rate=dp)
+    return m.cuda()
+
+
+def test_fused_block_runner_matches_per_op_path_fp32():
+    from imagefolder_amd import nn_ops
+    m = _tiny_vit()
+    x = torch.randn(5, 3, 16, 16, device="cuda")
+    outs, grads = [], []
+    for fused in (True, False):
+        nn_ops.FUSED_BLOCKS = fused
+        m.zero_grad()
+        o = m.forward_features(x)
+        o.square().mean().backward()
+        outs.append(o.detach().clone())
+        grads.append({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None})
+    nn_ops.FUSED_BLOCKS = True
+    assert (outs[0] - outs[1]).abs().max() <= 2e-5
+    assert grads[0].keys() == grads[1].keys()
+    for n in grads[0]:
+        s = grads[1][n].abs().max().item() + 1e-8
+        assert (grads[0][n] - grads[1][n]).abs().max().item() <= 2e-4 * s + 1e-7, n
+
+
+def test_fused_block_runner_bf16_autocast_close_to_aten_autocast():
+    from imagefolder_amd import nn_ops
+    m = _tiny_vit(depth=2)
+    x = torch.randn(4, 3, 16, 16, device="cuda")
+    res = []
+    for fused in (True, False):
+        nn_ops.FUSED_BLOCKS = fused
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            o = m.forward_features(x)
+        res.append(o.float())
+    nn_ops.FUSED_BLOCKS = True
+    assert (res[0] - res[1]).abs().max() <= 0.06 * res[1].abs().max()
+
+
+def test_droppath_masks_follow_reference_order_and_scale():
+    from imagefolder_amd import nn_ops
+    m = _tiny_vit(depth=2, dp=0.5).train()
+    x = torch.randn(6, 3, 16, 16, device="cuda")
+    outs = []
+    for fused in (True, False):
+        nn_ops.FUSED_BLOCKS = fused
+        torch.manual_seed(7); torch.cuda.manual_seed(7)
+        outs.append(m.forward_features(x).detach())
+    nn_ops.FUSED_BLOCKS = True
+    assert (outs[0] - outs[1]).abs().max() <= 2e-5
