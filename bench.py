@@ -10,10 +10,10 @@ checkpoints offline), codebook V=8192, C=32, product_quant=1, 256 latent tokens,
 bf16 autocast with fp32 master weights.
 A "step" = one tokenizer train step of xqgan_train.py:439-478 on one resident batch: encoder -> quant_conv ->
 VectorQuantizer (+ latent-perturbation call) -> post_quant_conv -> decoder -> semantic contrastive branch ->
-generator loss -> backward -> gradient all-reduce (RCCL, N > 1) -> fused AdamW + EMA.  What is NOT in the timed
-region yet is listed in config["not_in_timed_region"] (VQLoss's LPIPS / DinoDisc terms and the discriminator step:
-SURVEY.md §8f "next" #1).  config["op_impl"] says, per dense op, whether a hand-written HIP kernel or a
-PyTorch-ROCm library op ran.
+VQLoss generator loss (rec + LPIPS-VGG16 + DinoDisc GAN with DiffAug, adaptive weight; random-init VGG16/DINO trunks:
+no checkpoints offline) -> backward -> gradient all-reduce (RCCL, N > 1), overlapped with the discriminator step
+(VQLoss(optimizer_idx=1) + backward + AdamW on the heads) -> fused AdamW + EMA.  config["op_impl"] says, per dense op,
+whether a hand-written HIP kernel or a PyTorch-ROCm library op ran; config["loss"] says which loss was timed.
 
 roofline: the dominant HAND-WRITTEN kernel of the step, assign_kernel (fused normalise + distance + argmin on fp32
 MFMA): algorithmic flops per launch = 2*N*V*C, timed live with HIP events on its launch stream
@@ -45,6 +45,9 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (images)")
     p.add_argument("--workload", default="train_step", choices=["train_step", "quantizer"])
+    p.add_argument("--loss", default="full", choices=["full", "recon"],
+                   help="full = VQLoss (rec + LPIPS + DinoDisc GAN, adaptive weight, LeCAM) + discriminator step; "
+                        "recon = rec + codebook + semantic only")
     p.add_argument("--no-cpu-baseline", action="store_true")
     return p.parse_args()
 
@@ -74,7 +77,8 @@ def cpu_baseline(B_sample=16, iters=3):
 
 def build_train_step(args, dev, world):
     from imagefolder_amd.xqgan_model import VQ_models
-    from imagefolder_amd.train import TokenizerTrainStep
+    from imagefolder_amd.train import TokenizerTrainStep, DiscriminatorStep
+    from imagefolder_amd.vq_loss import VQLoss
     torch.manual_seed(0)  # identical weights on every rank (what DDP's construction-time broadcast guarantees)
     model = VQ_models["VQ-16"](codebook_size=CFG["V"], codebook_embed_dim=CFG["C"], v_patch_nums=[16], enc_type="dinov2",
                                dec_type="dinov2", semantic_guide="dinov2", detail_guide="none", num_latent_tokens=CFG["L"],
@@ -82,15 +86,30 @@ def build_train_step(args, dev, world):
                                decoder_model="vit_base_patch14_dinov2.lvd142m", abs_pos_embed=True, product_quant=1,
                                share_quant_resi=4, codebook_drop=0.0, half_sem=False, start_drop=3, sem_loss_weight=0.1,
                                guide_type_1="class").to(dev).train()
+    gbs = args.batch * world
+    lr, disc_lr = 3e-5 * gbs / 128, 1e-4 * gbs / 128  # yaml lr 3e-5, default disc_lr 1e-4, both x global_batch/128 (:338-339)
+    if args.loss == "full":
+        # VQLoss exactly as xqgan_train.py:320-335 builds it from VQ-8192.yaml + argparse defaults
+        vq_loss = VQLoss(disc_start=0, disc_weight=0.5, disc_type="dinodisc", disc_loss="hinge", gen_adv_loss="hinge",
+                         image_size=256, perceptual_weight=1.0, reconstruction_weight=1.0, reconstruction_loss="l2",
+                         codebook_weight=1.0, lecam_loss_weight=0.001, disc_adaptive_weight=True, norm_type="bn",
+                         aug_prob=1.0).to(dev).train()
+        disc = DiscriminatorStep(vq_loss, lr=disc_lr, betas=(0.9, 0.95), weight_decay=0.0005, amp_dtype=torch.bfloat16)
+        state = {"step": 0}
 
-    def gen_loss(out, imgs):
-        recons, (vq, commit, entropy, usages), sem, detail, dep = out
-        rec = torch.nn.functional.mse_loss(imgs, recons.float())  # VQLoss rec term (vq_loss.py:166), weight 1.0
-        return rec + vq + commit + entropy + (sem if sem is not None else 0.0)
-
-    # xqgan_train.py defaults: lr 1e-4 * global_batch/128 (yaml lr 3e-5), betas (0.9, 0.95), wd 0 (yaml), ema on
-    ts = TokenizerTrainStep(model, gen_loss, lr=3e-5 * args.batch * world / 128, betas=(0.9, 0.95), weight_decay=0.0,
-                            ema_decay=0.9999, use_ema=True, amp_dtype=torch.bfloat16)
+        def gen_loss(out, imgs):
+            recons, codebook_loss, sem, detail, dep = out
+            state["step"] += 1
+            return vq_loss(codebook_loss, sem, detail, dep, imgs, recons, optimizer_idx=0, global_step=state["step"],
+                           last_layer=model.decoder.last_layer, fade_blur_schedule=0)
+        disc_fn = disc
+    else:
+        def gen_loss(out, imgs):
+            recons, (vq, commit, entropy, usages), sem, detail, dep = out
+            return torch.nn.functional.mse_loss(imgs, recons.float()) + vq + commit + entropy + (sem if sem is not None else 0.0)
+        disc_fn = None
+    ts = TokenizerTrainStep(model, gen_loss, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999, use_ema=True,
+                            amp_dtype=torch.bfloat16, disc_step_fn=disc_fn)
     return model, ts
 
 
@@ -174,15 +193,18 @@ def main():
             "dtype": "bf16" if full else "f32", "data": "synthetic",
             "config": {
                 "workload": (f"{CFG['name']}.yaml: VQ-16 tokenizer, DINOv2 ViT-B encoder+decoder (random init), V={CFG['V']}, "
-                             f"C={CFG['C']}, 256 latent tokens, frozen ViT-B semantic teacher; B={B}/GPU x 256x256; fwd + bwd + "
-                             f"grad all-reduce + fused AdamW/EMA; bf16 autocast, fp32 master weights; inputs resident in HBM")
+                             f"C={CFG['C']}, 256 latent tokens, frozen ViT-B semantic teacher; B={B}/GPU x 256x256; generator fwd + "
+                             f"VQLoss + bwd + grad all-reduce + discriminator step + fused AdamW/EMA; bf16 autocast, fp32 master "
+                             f"weights; inputs resident in HBM")
                 if full else f"{CFG['name']}.yaml geometry: VectorQuantizer fwd+bwd only, B={B}/GPU (N={N} tokens)",
                 "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                 "trainable_params": n_params,
                 "op_impl": dict(nn_ops.IMPL, quantizer="hip", latent_perturbation="hip", adamw_ema="hip",
                                 grad_allreduce="rccl"),
-                "not_in_timed_region": ("VQLoss perceptual (LPIPS-VGG16) and adversarial (DinoDisc + DiffAug + LeCAM) terms and "
-                                        "the discriminator step (SURVEY §8f next #1)") if full else "everything but the quantizer",
+                "loss": args.loss,
+                "not_in_timed_region": ((None if args.loss == "full" else
+                                         "VQLoss perceptual (LPIPS-VGG16) and adversarial (DinoDisc) terms + discriminator step")
+                                        if full else "everything but the quantizer"),
             },
             "roofline": {"bound": "mfma", "kernel": "assign_kernel<C=32,L2_NORMED> (v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",

@@ -104,6 +104,52 @@ class GradAllReducer:
         self._works = []
 
 
+class ArenaOptimizer:
+    """AdamW (+ optional EMA) over a FlatArena with an optional data-parallel gradient all-reduce: the reference's
+    (optimizer, ema, DDP reducer) trio for one parameter set."""
+
+    def __init__(self, params, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2, eps=1e-8, ema_decay=0.9999, use_ema=True,
+                 group=None, chunk_bytes: int = 256 << 20):
+        self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
+        self.ema_decay = ema_decay
+        self.arena = FlatArena(params, with_ema=use_ema)
+        self.reducer = GradAllReducer(self.arena.g, group=group, chunk_bytes=chunk_bytes)
+        self.world = self.reducer.world
+
+    def zero_grad(self):
+        self.arena.g.zero_()
+
+    def step(self):
+        a = self.arena
+        a.step_count += 1
+        if a.p.is_cuda:
+            with torch.cuda.device(a.p.device):
+                rc = _lib.lib().xq_adamw_ema_step(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
+                                                  ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
+                                                  ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
+                                                  ctypes.c_float(self.weight_decay), a.step_count,
+                                                  ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1,
+                                                  ctypes.c_void_p(torch.cuda.current_stream(a.p.device).cuda_stream))
+            check(rc, "xq_adamw_ema_step")
+        else:
+            self._step_host()
+
+    @torch.no_grad()
+    def _step_host(self):
+        """CPU twin of xq_adamw_ema_step (used by the gloo multi-process tests; same formulas, tensor ops)."""
+        a, (b1, b2) = self.arena, self.betas
+        g = a.g * (1.0 / self.world)
+        a.p.mul_(1 - self.lr * self.weight_decay)
+        a.m.lerp_(g, 1 - b1)
+        a.v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        bc1, bc2 = 1 - b1 ** a.step_count, 1 - b2 ** a.step_count
+        denom = (a.v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
+        a.p.addcdiv_(a.m, denom, value=-self.lr / bc1)
+        if a.ema is not None:
+            a.ema.mul_(self.ema_decay).add_(a.p, alpha=1 - self.ema_decay)
+        a.g.zero_()
+
+
 class TokenizerTrainStep:
     """One object = the reference's (vq_model, optimizer, ema, vq_loss, optimizer_disc) bundle for one rank.
 
@@ -118,44 +164,13 @@ class TokenizerTrainStep:
         self.model = model
         self.gen_loss_fn = gen_loss_fn
         self.disc_step_fn = disc_step_fn
-        self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
-        self.ema_decay = ema_decay
         self.amp_dtype = amp_dtype
-        self.arena = FlatArena(model.parameters(), with_ema=use_ema)
-        self.reducer = GradAllReducer(self.arena.g, group=group, chunk_bytes=chunk_bytes)
-        self.world = self.reducer.world
+        self.opt = ArenaOptimizer(model.parameters(), lr=lr, betas=betas, weight_decay=weight_decay, eps=eps,
+                                  ema_decay=ema_decay, use_ema=use_ema, group=group, chunk_bytes=chunk_bytes)
+        self.arena = self.opt.arena
+        self.reducer = self.opt.reducer
+        self.world = self.opt.world
         self.device = self.arena.p.device
-
-    # -- optimizer ----------------------------------------------------------------------------------------------
-    def _optimizer_step(self):
-        a = self.arena
-        a.step_count += 1
-        if a.p.is_cuda:
-            with torch.cuda.device(a.p.device):
-                rc = _lib.lib().xq_adamw_ema_step(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
-                                                  ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
-                                                  ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
-                                                  ctypes.c_float(self.weight_decay), a.step_count,
-                                                  ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1,
-                                                  ctypes.c_void_p(torch.cuda.current_stream(a.p.device).cuda_stream))
-            check(rc, "xq_adamw_ema_step")
-        else:
-            self._optimizer_step_host()
-
-    @torch.no_grad()
-    def _optimizer_step_host(self):
-        """CPU twin of xq_adamw_ema_step (used by the gloo multi-process tests; same formulas, tensor ops)."""
-        a, (b1, b2) = self.arena, self.betas
-        g = a.g * (1.0 / self.world)
-        a.p.mul_(1 - self.lr * self.weight_decay)
-        a.m.lerp_(g, 1 - b1)
-        a.v.mul_(b2).addcmul_(g, g, value=1 - b2)
-        bc1, bc2 = 1 - b1 ** a.step_count, 1 - b2 ** a.step_count
-        denom = (a.v.sqrt() / (bc2 ** 0.5)).add_(self.eps)
-        a.p.addcdiv_(a.m, denom, value=-self.lr / bc1)
-        if a.ema is not None:
-            a.ema.mul_(self.ema_decay).add_(a.p, alpha=1 - self.ema_decay)
-        a.g.zero_()
 
     # -- one train step -----------------------------------------------------------------------------------------
     def step(self, imgs, epoch=0, alpha=0.0, beta=0.0, delta=100):
@@ -169,5 +184,32 @@ class TokenizerTrainStep:
         if self.disc_step_fn is not None:
             self.disc_step_fn(imgs, out[0].detach())   # ... the discriminator step (needs only recons.detach())
         self.reducer.wait()
-        self._optimizer_step()                     # AdamW + EMA + zero_grad + 1/world in one pass
+        self.opt.step()                            # AdamW + EMA + zero_grad + 1/world in one pass
         return loss_gen.detach()
+
+
+class DiscriminatorStep:
+    """The reference's discriminator half-step (xqgan_train.py:464-475): zero_grad, VQLoss(optimizer_idx=1) under
+    autocast, backward, AdamW on vq_loss.discriminator.parameters() — with the head gradients all-reduced once per
+    step (DDP reduces them a second, wasted, time during the generator backward: SURVEY §2.3 C2)."""
+
+    def __init__(self, vq_loss, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2, amp_dtype=torch.bfloat16, group=None):
+        self.vq_loss = vq_loss
+        self.amp_dtype = amp_dtype
+        self.opt = ArenaOptimizer(vq_loss.discriminator.parameters(), lr=lr, betas=betas, weight_decay=weight_decay,
+                                  use_ema=False, group=group)
+        self.global_step = 0
+        self.fade_blur_schedule = 0
+
+    def __call__(self, imgs, recons_detached):
+        self.opt.arena.rebind_grads()
+        self.opt.zero_grad()  # drops what the generator backward left on the heads (upstream: optimizer_disc.zero_grad())
+        with torch.autocast(device_type=imgs.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
+            loss_disc = self.vq_loss(None, None, None, None, imgs, recons_detached, optimizer_idx=1,
+                                     global_step=self.global_step + 1, fade_blur_schedule=self.fade_blur_schedule)
+        loss_disc.backward()
+        self.opt.reducer.start()
+        self.opt.reducer.wait()
+        self.opt.step()
+        self.global_step += 1
+        return loss_disc.detach()

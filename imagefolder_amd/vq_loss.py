@@ -1,0 +1,389 @@
+"""Generator / discriminator losses of the tokenizer train step — host mirror in plain tensor ops.
+
+SURVEY.md §8f lists `VQLoss` internals as "next" after the quantizer/encoder/decoder path: they "stay PyTorch"
+(library ops on the GPU), but the train step is not a train step without them, so the module is mirrored here with
+the reference's structure and state-dict names:
+    VQLoss        tokenizer/tokenizer_image/vq_loss.py:80-261 (disc_type='dinodisc' only — what every yaml selects)
+    LPIPS         tokenizer/tokenizer_image/lpips.py:53-163   (VGG16 trunk restated: torchvision is absent offline)
+    DinoDisc      tokenizer/tokenizer_image/discriminator_dino.py:26-363 (frozen DINO ViT-S/16 + 5 spectral-norm heads)
+    DiffAug       tokenizer/tokenizer_image/diffaug.py:22-118
+No network / checkpoints in this build: the VGG16 and DINO trunks are random-init unless a state_dict is loaded
+(names match torchvision's `features.N` slices / the DINO checkpoint).  wandb logging is not mirrored.
+"""
+import math
+import random
+from typing import List
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.utils.spectral_norm import SpectralNorm
+
+
+# ---- scalar loss helpers (vq_loss.py:17-78) -------------------------------------------------------------------
+def hinge_d_loss(logits_real, logits_fake):
+    return 0.5 * (torch.mean(F.relu(1. - logits_real)) + torch.mean(F.relu(1. + logits_fake)))
+
+
+def hinge_gen_loss(logit_fake):
+    return -torch.mean(logit_fake)
+
+
+def adopt_weight(weight, global_step, threshold=0, value=0.):
+    return value if global_step < threshold else weight
+
+
+class LeCAM_EMA(object):
+    def __init__(self, init=0., decay=0.999):
+        self.logits_real_ema = init
+        self.logits_fake_ema = init
+        self.decay = decay
+
+    def update(self, logits_real, logits_fake):
+        # upstream syncs twice per step here (.item()); one transfer for both means
+        means = torch.stack([logits_real.detach().mean(), logits_fake.detach().mean()]).tolist()
+        self.logits_real_ema = self.logits_real_ema * self.decay + means[0] * (1 - self.decay)
+        self.logits_fake_ema = self.logits_fake_ema * self.decay + means[1] * (1 - self.decay)
+
+
+def lecam_reg(real_pred, fake_pred, lecam_ema):
+    return torch.mean(F.relu(real_pred - lecam_ema.logits_fake_ema).pow(2)) + \
+        torch.mean(F.relu(lecam_ema.logits_real_ema - fake_pred).pow(2))
+
+
+# ---- LPIPS (lpips.py) -------------------------------------------------------------------------------------------
+_VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]  # features[0:30]
+
+
+class _VGG16Slices(nn.Module):
+    """torchvision vgg16().features[0:30] cut into the five LPIPS slices (lpips.py:118-155): outputs after
+    relu1_2, relu2_2, relu3_3, relu4_3, relu5_3.  Module indices equal torchvision's so `slice{k}.{idx}` keys match."""
+
+    def __init__(self):
+        super().__init__()
+        layers, cin = [], 3
+        for v in _VGG16_CFG:
+            if v == 'M':
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                layers += [nn.Conv2d(cin, v, kernel_size=3, padding=1), nn.ReLU(inplace=True)]
+                cin = v
+        cuts = [(0, 4), (4, 9), (9, 16), (16, 23), (23, 30)]
+        for si, (a, b) in enumerate(cuts):
+            seq = nn.Sequential()
+            for i in range(a, b):
+                seq.add_module(str(i), layers[i])
+            setattr(self, f"slice{si + 1}", seq)
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        outs = []
+        for si in range(1, 6):
+            x = getattr(self, f"slice{si}")(x)
+            outs.append(x)
+        return outs
+
+
+class _NetLin(nn.Module):
+    def __init__(self, chn_in, use_dropout=True):
+        super().__init__()
+        layers = [nn.Dropout()] if use_dropout else []
+        layers += [nn.Conv2d(chn_in, 1, 1, stride=1, padding=0, bias=False)]
+        self.model = nn.Sequential(*layers)
+
+
+class LPIPS(nn.Module):
+    def __init__(self, use_dropout=True):
+        super().__init__()
+        self.register_buffer('shift', torch.Tensor([-.030, -.088, -.188])[None, :, None, None])
+        self.register_buffer('scale', torch.Tensor([.458, .448, .450])[None, :, None, None])
+        self.chns = [64, 128, 256, 512, 512]
+        self.net = _VGG16Slices()
+        for k, c in enumerate(self.chns):
+            setattr(self, f"lin{k}", _NetLin(c, use_dropout=use_dropout))
+        for p in self.parameters():
+            p.requires_grad = False
+
+    @staticmethod
+    def _unit(x, eps=1e-10):
+        return x / (torch.sqrt(torch.sum(x ** 2, dim=1, keepdim=True)) + eps)
+
+    def forward(self, input, target):
+        f0 = self.net((input - self.shift) / self.scale)
+        f1 = self.net((target - self.shift) / self.scale)
+        val = 0
+        for k in range(len(self.chns)):
+            d = (self._unit(f0[k]) - self._unit(f1[k])) ** 2
+            val = val + getattr(self, f"lin{k}").model(d).mean([2, 3], keepdim=True)
+        return val
+
+
+# ---- DiffAug (diffaug.py:22-118) ----------------------------------------------------------------------------------
+class DiffAug(object):
+    def __init__(self, prob=1.0, cutout=0.2):
+        self.grids = {}
+        self.prob = abs(prob)
+        self.using_cutout = prob > 0
+        self.cutout = cutout
+        self.last_blur_radius = -1
+        self.kh = self.kw = None
+
+    def _grids(self, B, x, y, dev):
+        key = (B, x, y, str(dev))
+        if key not in self.grids:
+            self.grids[key] = torch.meshgrid(torch.arange(B, device=dev), torch.arange(x, device=dev),
+                                             torch.arange(y, device=dev), indexing='ij')
+        return self.grids[key]
+
+    def aug(self, BCHW, warmup_blur_schedule: float = 0):
+        if BCHW.dtype != torch.float32:
+            BCHW = BCHW.float()
+        if warmup_blur_schedule > 0:  # gaussian blur warm-up (:43-62)
+            C = BCHW.shape[1]
+            sigma = (BCHW.shape[-2] * 0.5) ** 0.5 * warmup_blur_schedule
+            r = math.floor(sigma * 3)
+            if r >= 1:
+                if self.last_blur_radius != r:
+                    self.last_blur_radius = r
+                    g = torch.arange(-r, r + 1, dtype=torch.float32, device=BCHW.device).mul_(1 / sigma).square_().neg_().exp2_()
+                    g.div_(g.sum())
+                    self.kh = g.view(1, 1, 2 * r + 1, 1).repeat(C, 1, 1, 1).contiguous()
+                    self.kw = g.view(1, 1, 1, 2 * r + 1).repeat(C, 1, 1, 1).contiguous()
+                BCHW = F.pad(BCHW, [r, r, r, r], mode='reflect')
+                BCHW = F.conv2d(BCHW, self.kh, groups=C)
+                BCHW = F.conv2d(BCHW, self.kw, groups=C)
+        if self.prob < 1e-6:
+            return BCHW
+        trans, color, cut = (torch.rand(3) <= self.prob).tolist()  # host RNG like upstream (:66-67)
+        B, dev = BCHW.shape[0], BCHW.device
+        rand01 = torch.rand(7, B, 1, 1, device=dev) if (trans or color or cut) else None
+        H, W = BCHW.shape[-2:]
+        if trans:
+            dh, dw = round(H * 0.125), round(W * 0.125)
+            th = rand01[0].mul(2 * dh + 1).floor().long() - dh
+            tw = rand01[1].mul(2 * dw + 1).floor().long() - dw
+            gb, gh, gw = self._grids(B, H, W, dev)
+            gh = (gh + th).add(1).clamp(0, H + 1)
+            gw = (gw + tw).add(1).clamp(0, W + 1)
+            pad = F.pad(BCHW, [1, 1, 1, 1, 0, 0, 0, 0])
+            BCHW = pad.permute(0, 2, 3, 1).contiguous()[gb, gh, gw].permute(0, 3, 1, 2).contiguous()
+        if color:
+            BCHW = BCHW.add(rand01[2].unsqueeze(-1).sub(0.5))
+            m = BCHW.mean(dim=1, keepdim=True)
+            BCHW = BCHW.sub(m).mul(rand01[3].unsqueeze(-1).mul(2)).add_(m)
+            m = BCHW.mean(dim=(1, 2, 3), keepdim=True)
+            BCHW = BCHW.sub(m).mul(rand01[4].unsqueeze(-1).add(0.5)).add_(m)
+        if self.using_cutout and cut:
+            ch, cw = round(H * self.cutout), round(W * self.cutout)
+            oh = rand01[5].mul(H + (1 - ch % 2)).floor().long()
+            ow = rand01[6].mul(W + (1 - cw % 2)).floor().long()
+            gb, gh, gw = self._grids(B, ch, cw, dev)
+            gh = (gh + oh).sub(ch // 2).clamp(min=0, max=H - 1)
+            gw = (gw + ow).sub(cw // 2).clamp(min=0, max=W - 1)
+            mask = torch.ones(B, H, W, dtype=BCHW.dtype, device=dev)
+            mask[gb, gh, gw] = 0
+            BCHW = BCHW.mul(mask.unsqueeze(1))
+        return BCHW
+
+
+# ---- DinoDisc (discriminator_dino.py) -----------------------------------------------------------------------------
+class _SABlock(nn.Module):
+    """frozen DINO ViT-S block: pre-LN, no LayerScale, tanh-GELU MLP (discriminator_dino.py:37-112)"""
+
+    def __init__(self, dim, heads, mlp_ratio, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = nn.Module()
+        self.attn.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.attn.proj = nn.Linear(dim, dim, bias=True)
+        self.heads = heads
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = nn.Module()
+        self.mlp.fc1 = nn.Linear(dim, round(dim * mlp_ratio))
+        self.mlp.fc2 = nn.Linear(round(dim * mlp_ratio), dim)
+
+    def forward(self, x):
+        B, L, C = x.shape
+        qkv = self.attn.qkv(self.norm1(x)).view(B, L, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
+        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, L, C)
+        x = x + self.attn.proj(o)
+        return x + self.mlp.fc2(F.gelu(self.mlp.fc1(self.norm2(x)), approximate='tanh'))
+
+
+class FrozenDINOSmallNoDrop(nn.Module):
+    def __init__(self, depth=12, key_depths=(2, 5, 8, 11), norm_eps=1e-6, patch_size=16, in_chans=3, embed_dim=384,
+                 num_heads=6, mlp_ratio=4.):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.img_size = 224
+        self.patch_embed = nn.Module()
+        self.patch_embed.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
+        self.patch_size = patch_size
+        self.patch_nums = self.img_size // patch_size
+        m, s = torch.tensor((0.485, 0.456, 0.406)), torch.tensor((0.229, 0.224, 0.225))
+        self.register_buffer('x_scale', (0.5 / s).reshape(1, 3, 1, 1))
+        self.register_buffer('x_shift', ((0.5 - m) / s).reshape(1, 3, 1, 1))
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.patch_nums * self.patch_nums + 1, embed_dim))
+        self.key_depths = set(d for d in key_depths if d < depth)
+        self.blocks = nn.Sequential(*[_SABlock(embed_dim, num_heads, mlp_ratio, norm_eps)
+                                      for _ in range(max(depth, 1 + max(self.key_depths)))])
+        self.norm = nn.LayerNorm(embed_dim, eps=norm_eps)
+        nn.init.trunc_normal_(self.pos_embed, std=.02)  # offline stand-in for the DINO checkpoint
+        self.eval()
+        [p.requires_grad_(False) for p in self.parameters()]
+
+    def forward(self, x, grad_ckpt=False) -> List[torch.Tensor]:
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x = (self.x_scale * x.float()).add_(self.x_shift)
+            H, W = x.shape[-2], x.shape[-1]
+            if H > self.img_size and W > self.img_size and random.random() <= 0.5:  # random 224-crop (:332-333)
+                i = int(torch.randint(0, H - self.img_size + 1, (1,)).item())
+                j = int(torch.randint(0, W - self.img_size + 1, (1,)).item())
+                x = x[..., i:i + self.img_size, j:j + self.img_size]
+            else:
+                x = F.interpolate(x, size=(self.img_size, self.img_size), mode='area' if H > self.img_size else 'bicubic')
+        x = self.patch_embed.proj(x).flatten(2).transpose(1, 2)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x.float()), dim=1) + self.pos_embed
+            acts = [(x[:, 1:] + x[:, :1]).transpose(1, 2)]
+        for i, b in enumerate(self.blocks):
+            x = b(x)
+            if i in self.key_depths:
+                acts.append((x[:, 1:].float() + x[:, :1].float()).transpose(1, 2))
+        return acts
+
+
+class _SpectralConv1d(nn.Conv1d):
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        SpectralNorm.apply(self, name='weight', n_power_iterations=1, dim=0, eps=1e-12)
+
+
+class BatchNormLocal(nn.Module):
+    """batch statistics over virtual batches of 8 samples, no communication (discriminator_dino.py:127-154)"""
+
+    def __init__(self, num_features, affine=True, virtual_bs=8, eps=1e-6):
+        super().__init__()
+        self.virtual_bs, self.eps, self.affine = virtual_bs, eps, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+
+    def forward(self, x):
+        shape = x.size()
+        x = x.float()
+        G = int(np.ceil(x.size(0) / self.virtual_bs))
+        x = x.view(G, -1, x.size(-2), x.size(-1))
+        mean = x.mean([1, 3], keepdim=True)
+        var = x.var([1, 3], keepdim=True, unbiased=False)
+        x = (x - mean) / torch.sqrt(var + self.eps)
+        if self.affine:
+            x = x * self.weight[None, :, None] + self.bias[None, :, None]
+        return x.view(shape)
+
+
+class _Residual(nn.Module):
+    def __init__(self, fn):
+        super().__init__()
+        self.fn = fn
+        self.ratio = 1 / np.sqrt(2)
+
+    def forward(self, x):
+        return (self.fn(x).add(x)).mul_(self.ratio)
+
+
+def _make_block(ch, ks, eps):
+    return nn.Sequential(_SpectralConv1d(ch, ch, kernel_size=ks, padding=ks // 2, padding_mode='circular'),
+                         BatchNormLocal(ch, eps=eps), nn.LeakyReLU(negative_slope=0.2, inplace=True))
+
+
+class DinoDisc(nn.Module):
+    def __init__(self, ks=9, depth=12, key_depths=(2, 5, 8, 11), norm_type='bn', using_spec_norm=True, norm_eps=1e-6):
+        super().__init__()
+        assert norm_type == 'bn' and using_spec_norm, "only the configuration used by VQLoss is mirrored"
+        key_depths = tuple(d for d in key_depths if d < depth)
+        d = FrozenDINOSmallNoDrop(depth=depth, key_depths=key_depths, norm_eps=norm_eps)
+        # kept outside the module tree like upstream (a tuple, :202): invisible to parameters()/state_dict()/optimizer
+        self.dino_proxy = (d,)
+        C = d.embed_dim
+        self.heads = nn.ModuleList([
+            nn.Sequential(_make_block(C, 1, norm_eps), _Residual(_make_block(C, ks, norm_eps)),
+                          _SpectralConv1d(C, 1, kernel_size=1, padding=0))
+            for _ in range(len(key_depths) + 1)])
+
+    def _apply(self, fn, *a, **k):  # the proxy must follow .to()/.cuda() even though it is not a submodule
+        self.dino_proxy = (self.dino_proxy[0]._apply(fn),)
+        return super()._apply(fn, *a, **k)
+
+    def forward(self, x_in_pm1, grad_ckpt=False):
+        acts = self.dino_proxy[0](x_in_pm1.float())
+        B = x_in_pm1.shape[0]
+        return torch.cat([h(a).view(B, -1) for h, a in zip(self.heads, acts)], dim=1)
+
+
+# ---- VQLoss (vq_loss.py:80-261) -------------------------------------------------------------------------------------
+class VQLoss(nn.Module):
+    def __init__(self, disc_start, disc_loss="hinge", disc_dim=64, disc_type='dinodisc', image_size=256, disc_num_layers=3,
+                 disc_in_channels=3, disc_weight=1.0, disc_adaptive_weight=False, gen_adv_loss='hinge',
+                 reconstruction_loss='l2', reconstruction_weight=1.0, codebook_weight=1.0, perceptual_weight=1.0,
+                 lecam_loss_weight=None, norm_type='bn', aug_prob=1):
+        super().__init__()
+        if disc_type != 'dinodisc' or disc_loss != 'hinge' or gen_adv_loss != 'hinge':
+            raise NotImplementedError("only disc_type='dinodisc' with hinge losses (all reference yamls) is mirrored")
+        self.disc_type = disc_type
+        self.discriminator = DinoDisc(norm_type=norm_type)
+        self.daug = DiffAug(prob=aug_prob, cutout=0.2)
+        self.disc_loss = hinge_d_loss
+        self.gen_adv_loss = hinge_gen_loss
+        self.discriminator_iter_start = disc_start
+        self.disc_weight = disc_weight
+        self.disc_adaptive_weight = disc_adaptive_weight
+        self.perceptual_loss = LPIPS().eval()
+        self.perceptual_weight = perceptual_weight
+        self.rec_loss = F.l1_loss if reconstruction_loss == "l1" else F.mse_loss
+        self.rec_weight = reconstruction_weight
+        self.codebook_weight = codebook_weight
+        self.lecam_loss_weight = lecam_loss_weight
+        if lecam_loss_weight is not None:
+            self.lecam_ema = LeCAM_EMA()
+
+    def calculate_adaptive_weight(self, nll_loss, g_loss, last_layer):
+        nll_grads = torch.autograd.grad(nll_loss, last_layer, retain_graph=True)[0]
+        g_grads = torch.autograd.grad(g_loss, last_layer, retain_graph=True)[0]
+        d_weight = torch.norm(nll_grads) / (torch.norm(g_grads) + 1e-4)
+        return torch.clamp(d_weight, 0.0, 1e4).detach()
+
+    def forward(self, codebook_loss, sem_loss, detail_loss, dependency_loss, inputs, reconstructions, optimizer_idx,
+                global_step, last_layer=None, logger=None, log_every=100, fade_blur_schedule=0):
+        if fade_blur_schedule < 1e-6:
+            fade_blur_schedule = 0
+        if optimizer_idx == 0:  # generator update (:163-223)
+            rec_loss = self.rec_loss(inputs.contiguous(), reconstructions.contiguous())
+            p_loss = torch.mean(self.perceptual_loss(inputs.contiguous(), reconstructions.contiguous()))
+            logits_fake = self.discriminator(self.daug.aug(reconstructions.contiguous(), fade_blur_schedule))
+            generator_adv_loss = self.gen_adv_loss(logits_fake)
+            if self.disc_adaptive_weight:
+                null_loss = self.rec_weight * rec_loss + self.perceptual_weight * p_loss
+                disc_adaptive_weight = self.calculate_adaptive_weight(null_loss, generator_adv_loss, last_layer=last_layer)
+            else:
+                disc_adaptive_weight = 1
+            disc_weight = adopt_weight(self.disc_weight, global_step, threshold=self.discriminator_iter_start)
+            sem_loss = 0 if sem_loss is None else sem_loss
+            detail_loss = 0 if detail_loss is None else detail_loss
+            dependency_loss = 0 if dependency_loss is None else dependency_loss
+            return self.rec_weight * rec_loss + self.perceptual_weight * p_loss + \
+                disc_adaptive_weight * disc_weight * generator_adv_loss + \
+                codebook_loss[0] + codebook_loss[1] + codebook_loss[2] + sem_loss + detail_loss + dependency_loss
+        if optimizer_idx == 1:  # discriminator update (:226-261)
+            logits_fake = self.discriminator(self.daug.aug(reconstructions.contiguous().detach(), fade_blur_schedule))
+            logits_real = self.discriminator(self.daug.aug(inputs.contiguous().detach(), fade_blur_schedule))
+            disc_weight = adopt_weight(self.disc_weight, global_step, threshold=self.discriminator_iter_start)
+            if self.lecam_loss_weight is not None:
+                self.lecam_ema.update(logits_real, logits_fake)
+                lecam_loss = lecam_reg(logits_real, logits_fake, self.lecam_ema)
+                return disc_weight * (lecam_loss * self.lecam_loss_weight + self.disc_loss(logits_real, logits_fake))
+            return disc_weight * self.disc_loss(logits_real, logits_fake)
+        raise ValueError(optimizer_idx)
