@@ -79,11 +79,22 @@ class _VGG16Slices(nn.Module):
             p.requires_grad = False
 
     def forward(self, x):
+        # channels-last activations: MIOpen's bf16 implicit-GEMM solvers are NHWC (igemm_*_nhwc_bf16); with NCHW bf16
+        # it falls back to naive_conv_* kernels on gfx950 (profiles/r01_full_step_naive_conv_stats.txt: 0.75 s/step)
+        if x.is_cuda:
+            x = x.contiguous(memory_format=torch.channels_last)
         outs = []
         for si in range(1, 6):
             x = getattr(self, f"slice{si}")(x)
             outs.append(x)
         return outs
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d) and m.weight.is_cuda:
+                m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+        return self
 
 
 class _NetLin(nn.Module):
@@ -245,7 +256,8 @@ class FrozenDINOSmallNoDrop(nn.Module):
                 x = x[..., i:i + self.img_size, j:j + self.img_size]
             else:
                 x = F.interpolate(x, size=(self.img_size, self.img_size), mode='area' if H > self.img_size else 'bicubic')
-        x = self.patch_embed.proj(x).flatten(2).transpose(1, 2)
+        from . import nn_ops
+        x = nn_ops.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.patch_size)  # conv as GEMM
         with torch.autocast(device_type=x.device.type, enabled=False):
             x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x.float()), dim=1) + self.pos_embed
             acts = [(x[:, 1:] + x[:, :1]).transpose(1, 2)]
@@ -257,9 +269,46 @@ class FrozenDINOSmallNoDrop(nn.Module):
 
 
 class _SpectralConv1d(nn.Conv1d):
+    """Conv1d with spectral normalisation, state-dict compatible with torch's SpectralNorm (weight_orig, weight_u,
+    weight_v; discriminator_dino.py:121-124).  Two deliberate differences in *how* it is evaluated:
+      * the power iteration runs in fp32 outside autocast — under bf16 autocast torch.mv becomes a bf16 gemv that costs
+        ~5 ms per call on this stack (15 convs x 2 gemv = 170 ms per discriminator forward, measured);
+      * the convolution is a GEMM (kernel 1: channel matmul; kernel k, circular padding: k shifted copies gathered into
+        (B*L, C_in*k) x W^T)."""
+
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         SpectralNorm.apply(self, name='weight', n_power_iterations=1, dim=0, eps=1e-12)
+        for k, hook in list(self._forward_pre_hooks.items()):  # keep the parametrisation, drop the autocast-ed hook
+            if isinstance(hook, SpectralNorm):
+                del self._forward_pre_hooks[k]
+
+    def _normalised_weight(self):
+        with torch.autocast(device_type=self.weight_orig.device.type, enabled=False):
+            W = self.weight_orig
+            Wm = W.reshape(W.shape[0], -1)
+            u, v = self.weight_u, self.weight_v
+            if self.training:  # one power iteration per training forward, like SpectralNorm.compute_weight
+                with torch.no_grad():
+                    v = F.normalize(torch.mv(Wm.t(), u), dim=0, eps=1e-12, out=v)
+                    u = F.normalize(torch.mv(Wm, v), dim=0, eps=1e-12, out=u)
+                u, v = u.clone(), v.clone()
+            sigma = torch.dot(u, torch.mv(Wm, v))
+            return W / sigma
+
+    def forward(self, x):
+        W, k = self._normalised_weight(), self.kernel_size[0]
+        if k == 1:
+            y = torch.matmul(W[:, :, 0].to(x.dtype), x)
+        else:
+            pad = k // 2
+            xp = F.pad(x, (pad, pad), mode='circular') if self.padding_mode == 'circular' else F.pad(x, (pad, pad))
+            B, C, L = x.shape
+            cols = xp.unfold(2, k, 1).permute(0, 2, 1, 3).reshape(B * L, C * k)   # (B*L, C_in*k), (c, tap) order
+            y = torch.mm(cols, W.reshape(W.shape[0], -1).t().to(cols.dtype)).view(B, L, -1).permute(0, 2, 1)
+        if self.bias is not None:
+            y = y + self.bias.to(y.dtype)[None, :, None]
+        return y
 
 
 class BatchNormLocal(nn.Module):

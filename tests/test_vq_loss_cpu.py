@@ -61,7 +61,7 @@ def test_frozen_dino_trunk_and_heads_match_reference_classes():
     hb.load_state_dict(hb_ref.state_dict())
     t = torch.randn(16, 64, 50)
     hb_ref.train(); hb.train()
-    assert (hb_ref(t.clone()) - hb(t.clone())).abs().max() <= 1e-6
+    assert (hb_ref(t.clone()) - hb(t.clone())).abs().max() <= 1e-5
 
 
 @needs_ref
