@@ -35,7 +35,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
-CFG = dict(name="VQ-8192", B=128, C=32, V=8192, L=256, beta=0.25)
+# BASELINE.json configs; "VQ-8192" (configs[1]) is the one the metric is quoted on and the default.
+CONFIGS = {
+    "VQ-8192": dict(name="VQ-8192", B=128, C=32, V=8192, L=256, P=1, pns=[16], enc="dinov2", drop=0.0, half_sem=False, alpha=0.0, beta_lp=0.0, delta=100),
+    "VQ-4096-cnn": dict(name="VQ-4096 (CNN enc/dec, the CPU-runnable case)", B=4, C=64, V=4096, L=256, P=1, pns=[16], enc="cnn", drop=0.0, half_sem=False, alpha=0.0, beta_lp=0.0, delta=100),
+    "VQ-4096": dict(name="VQ-4096", B=128, C=64, V=4096, L=256, P=1, pns=[16], enc="dinov2", drop=0.0, half_sem=False, alpha=0.0, beta_lp=0.0, delta=100),
+    "VP2-16384": dict(name="VP2-16384", B=128, C=32, V=16384, L=256, P=2, pns=[16], enc="dinov2", drop=0.1, half_sem=True, alpha=0.0, beta_lp=0.0, delta=100),
+    "MSVR10P2-4096": dict(name="MSVR10P2-4096", B=128, C=32, V=4096, L=121, P=2, pns=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11], enc="dinov2", drop=0.1, half_sem=True, alpha=0.0, beta_lp=0.0, delta=100),
+    "RobustTok": dict(name="RobustTok", B=128, C=64, V=4096, L=256, P=1, pns=[16], enc="dinov2", drop=0.0, half_sem=False, alpha=1.0, beta_lp=0.1, delta=100),
+}
+CFG = dict(CONFIGS["VQ-8192"], beta=0.25)
 
 
 def parse():
@@ -45,6 +54,7 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (images)")
     p.add_argument("--workload", default="train_step", choices=["train_step", "quantizer"])
+    p.add_argument("--config", default="VQ-8192", choices=sorted(CONFIGS), help="BASELINE.json config (default: the metric's)")
     p.add_argument("--loss", default="full", choices=["full", "recon"],
                    help="full = VQLoss (rec + LPIPS + DinoDisc GAN, adaptive weight, LeCAM) + discriminator step; "
                         "recon = rec + codebook + semantic only")
@@ -80,12 +90,12 @@ def build_train_step(args, dev, world):
     from imagefolder_amd.train import TokenizerTrainStep, DiscriminatorStep
     from imagefolder_amd.vq_loss import VQLoss
     torch.manual_seed(0)  # identical weights on every rank (what DDP's construction-time broadcast guarantees)
-    model = VQ_models["VQ-16"](codebook_size=CFG["V"], codebook_embed_dim=CFG["C"], v_patch_nums=[16], enc_type="dinov2",
-                               dec_type="dinov2", semantic_guide="dinov2", detail_guide="none", num_latent_tokens=CFG["L"],
-                               encoder_model="vit_base_patch14_dinov2.lvd142m",
-                               decoder_model="vit_base_patch14_dinov2.lvd142m", abs_pos_embed=True, product_quant=1,
-                               share_quant_resi=4, codebook_drop=0.0, half_sem=False, start_drop=3, sem_loss_weight=0.1,
-                               guide_type_1="class").to(dev).train()
+    model = VQ_models["VQ-16"](codebook_size=CFG["V"], codebook_embed_dim=CFG["C"], v_patch_nums=list(CFG["pns"]),
+                               enc_type=CFG["enc"], dec_type=CFG["enc"], semantic_guide="dinov2", detail_guide="none",
+                               num_latent_tokens=CFG["L"], encoder_model="vit_base_patch14_dinov2.lvd142m",
+                               decoder_model="vit_base_patch14_dinov2.lvd142m", abs_pos_embed=True, product_quant=CFG["P"],
+                               share_quant_resi=4, codebook_drop=CFG["drop"], half_sem=CFG["half_sem"], start_drop=3,
+                               sem_loss_weight=0.1, guide_type_1="class").to(dev).train()
     gbs = args.batch * world
     lr, disc_lr = 3e-5 * gbs / 128, 1e-4 * gbs / 128  # yaml lr 3e-5, default disc_lr 1e-4, both x global_batch/128 (:338-339)
     if args.loss == "full":
@@ -115,6 +125,9 @@ def build_train_step(args, dev, world):
 
 def main():
     args = parse()
+    CFG.update(CONFIGS[args.config])
+    if args.batch == CONFIGS["VQ-8192"]["B"] and args.config != "VQ-8192":
+        args.batch = CFG["B"]
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -137,7 +150,7 @@ def main():
         imgs = torch.rand(B, 3, 256, 256, device=dev, generator=g) * 2 - 1
 
         def step():
-            ts.step(imgs, epoch=0, alpha=0.0, beta=0.0, delta=100)
+            ts.step(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"])
         n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     else:
         from imagefolder_amd.xqgan_model import VectorQuantizer
@@ -178,8 +191,13 @@ def main():
     dt = tmax.item()
 
     if rank == 0:
-        N = B * CFG["L"]
-        flops = 2.0 * N * CFG["V"] * CFG["C"]
+        # algorithmic flops of the assign kernel: 2*N*V*C per launch; a step launches it once per
+        # product branch (single scale) or once per branch and scale (ladder, N_s = B*pn^2)
+        tokens_per_branch = B * (sum(p * p for p in CFG["pns"]) if len(CFG["pns"]) > 1 else CFG["L"])
+        flops_step = 2.0 * tokens_per_branch * CFG["V"] * CFG["C"] * CFG["P"]
+        launches_step = max(1, n_launch.value // max(1, args.steps))
+        flops = flops_step / launches_step  # average per launch
+        N = tokens_per_branch
         k_ms = ms_tot.value / max(1, n_launch.value)
         achieved = flops / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
         full = args.workload == "train_step"
@@ -192,8 +210,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if full else "f32", "data": "synthetic",
             "config": {
-                "workload": (f"{CFG['name']}.yaml: VQ-16 tokenizer, DINOv2 ViT-B encoder+decoder (random init), V={CFG['V']}, "
-                             f"C={CFG['C']}, 256 latent tokens, frozen ViT-B semantic teacher; B={B}/GPU x 256x256; generator fwd + "
+                "workload": (f"{CFG['name']}.yaml: VQ-16 tokenizer, {'DINOv2 ViT-B' if CFG['enc'] == 'dinov2' else 'CNN'} encoder+decoder "
+                             f"(random init), V={CFG['V']}, C={CFG['C']}, P={CFG['P']}, scales={CFG['pns']}, {CFG['L']} latent tokens/branch, "
+                             f"frozen ViT-B semantic teacher; B={B}/GPU x 256x256; generator fwd + "
                              f"VQLoss + bwd + grad all-reduce + discriminator step + fused AdamW/EMA; bf16 autocast, fp32 master "
                              f"weights; inputs resident in HBM")
                 if full else f"{CFG['name']}.yaml geometry: VectorQuantizer fwd+bwd only, B={B}/GPU (N={N} tokens)",
@@ -206,7 +225,7 @@ def main():
                                          "VQLoss perceptual (LPIPS-VGG16) and adversarial (DinoDisc) terms + discriminator step")
                                         if full else "everything but the quantizer"),
             },
-            "roofline": {"bound": "mfma", "kernel": "assign_kernel<C=32,L2_NORMED> (v_mfma_f32_32x32x2_f32)",
+            "roofline": {"bound": "mfma", "kernel": f"assign_kernel<C={CFG['C']}> (v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                          "flops_per_launch": flops, "avg_launch_ms": k_ms, "launches": n_launch.value,

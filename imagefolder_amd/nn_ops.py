@@ -123,5 +123,12 @@ def group_norm_silu(x, groups, weight, bias, eps, silu=True):
     return y * torch.sigmoid(y) if silu else y
 
 
+# CNN encoder/decoder activations are kept channels-last on the GPU: MIOpen's bf16 solvers for gfx950 are NHWC
+# implicit-GEMM kernels; with NCHW bf16 it falls back to naive_conv_* (profiles/r01_full_step_naive_conv_stats.txt)
+CHANNELS_LAST = True
+
+
 def conv2d(x, weight, bias, stride=1, padding=0):
+    if CHANNELS_LAST and x.is_cuda and x.dim() == 4 and weight.shape[-1] > 1:
+        x = x.contiguous(memory_format=torch.channels_last)
     return F.conv2d(x, weight, bias, stride=stride, padding=padding)

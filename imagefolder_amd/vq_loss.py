@@ -405,11 +405,53 @@ class VQLoss(nn.Module):
         d_weight = torch.norm(nll_grads) / (torch.norm(g_grads) + 1e-4)
         return torch.clamp(d_weight, 0.0, 1e4).detach()
 
+    def _generator_loss_single_backward(self, codebook_loss, sem_loss, detail_loss, dependency_loss, inputs, reconstructions,
+                                        global_step, last_layer, fade_blur_schedule):
+        """Same loss value and the same gradients as the upstream generator branch (:163-196), but LPIPS/VGG and the
+        discriminator are back-propagated ONCE.  Upstream runs their backward three times per step: twice inside
+        calculate_adaptive_weight (two autograd.grad(..., last_layer) calls, :153-159) and again in loss.backward().
+        Here d(nll)/d(recons) and d(adv)/d(recons) are computed once on a detached copy of the reconstruction, the
+        last-layer gradient norms come from pushing those two cotangents through the decoder tail only, and the total
+        cotangent re-enters the graph through a linear surrogate term whose VALUE equals the upstream loss."""
+        rec_leaf = reconstructions.detach().requires_grad_(True)
+        with torch.enable_grad():
+            rec_loss = self.rec_loss(inputs.contiguous(), rec_leaf.contiguous())
+            p_loss = torch.mean(self.perceptual_loss(inputs.contiguous(), rec_leaf.contiguous()))
+            null_loss = self.rec_weight * rec_loss + self.perceptual_weight * p_loss
+            logits_fake = self.discriminator(self.daug.aug(rec_leaf.contiguous(), fade_blur_schedule))
+            generator_adv_loss = self.gen_adv_loss(logits_fake)
+        disc_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+        g_nll = torch.autograd.grad(null_loss, rec_leaf)[0]
+        adv_grads = torch.autograd.grad(generator_adv_loss, [rec_leaf] + disc_params, allow_unused=True)
+        g_adv = adv_grads[0]
+        # gradient norms w.r.t. the decoder's last layer: only the graph between last_layer and recons is traversed
+        nll_ll, adv_ll = (torch.autograd.grad(reconstructions, last_layer, grad_outputs=g.to(reconstructions.dtype),
+                                              retain_graph=True)[0] for g in (g_nll, g_adv))
+        d_weight = torch.clamp(torch.norm(nll_ll) / (torch.norm(adv_ll) + 1e-4), 0.0, 1e4).detach()
+        disc_weight = adopt_weight(self.disc_weight, global_step, threshold=self.discriminator_iter_start)
+        # upstream's generator backward also deposits d(adv)/d(head params) on the discriminator (discarded by
+        # optimizer_disc.zero_grad(), :465); keep that observable behaviour
+        for p, gp in zip(disc_params, adv_grads[1:]):
+            if gp is not None:
+                gp = gp * (d_weight * disc_weight)
+                p.grad = gp if p.grad is None else p.grad.add_(gp)
+        cot = (g_nll + (d_weight * disc_weight) * g_adv).detach()
+        value = (null_loss + d_weight * disc_weight * generator_adv_loss).detach()
+        surrogate = (reconstructions.float() * cot).sum()
+        surrogate = surrogate + (value - surrogate.detach())  # value of the upstream loss, gradient = cot
+        sem_loss = 0 if sem_loss is None else sem_loss
+        detail_loss = 0 if detail_loss is None else detail_loss
+        dependency_loss = 0 if dependency_loss is None else dependency_loss
+        return surrogate + codebook_loss[0] + codebook_loss[1] + codebook_loss[2] + sem_loss + detail_loss + dependency_loss
+
     def forward(self, codebook_loss, sem_loss, detail_loss, dependency_loss, inputs, reconstructions, optimizer_idx,
                 global_step, last_layer=None, logger=None, log_every=100, fade_blur_schedule=0):
         if fade_blur_schedule < 1e-6:
             fade_blur_schedule = 0
         if optimizer_idx == 0:  # generator update (:163-223)
+            if self.disc_adaptive_weight and reconstructions.requires_grad and last_layer is not None:
+                return self._generator_loss_single_backward(codebook_loss, sem_loss, detail_loss, dependency_loss, inputs,
+                                                            reconstructions, global_step, last_layer, fade_blur_schedule)
             rec_loss = self.rec_loss(inputs.contiguous(), reconstructions.contiguous())
             p_loss = torch.mean(self.perceptual_loss(inputs.contiguous(), reconstructions.contiguous()))
             logits_fake = self.discriminator(self.daug.aug(reconstructions.contiguous(), fade_blur_schedule))

@@ -120,9 +120,44 @@ def gen_msvq(name, V, C, B, pns, seed, codebook_drop=0.1, start_drop=3, using_zn
     print("wrote", name, "vq", vq.item(), "commit", float(commit), "usages", [round(u, 2) for u in usages][:4])
 
 
+def gen_model(name, kw, seed):
+    """VQModel.img_to_reconstructed_img + code indices (xqgan_model.py:367-403) with deterministic weights
+    (oracle/det_init.py); eval mode (no DropPath), fp32 CPU = the reference CPU path of BASELINE config 1/2."""
+    from oracle.det_init import det_state_dict
+    R = load_reference()
+    torch.manual_seed(seed)
+    m = R["VQ_models"]["VQ-16"](**kw).eval()
+    m.load_state_dict(det_state_dict(m.state_dict(), seed))
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(1234 + seed)) * 2 - 1
+    with torch.no_grad():
+        rec = m.img_to_reconstructed_img(x)
+        h = m.encoder(x)
+        if kw["enc_type"] == "dinov2":
+            b, l, c = h.shape
+            h = h.view(b, int(l ** 0.5), int(l ** 0.5), c).permute(0, 3, 1, 2)
+        f = m.quant_conv(h)
+        idx = m.quantize.f_to_idxBl_or_fhat(f, to_fhat=False, v_patch_nums=None)[0]
+    np.savez(os.path.join(OUT, name + ".npz"), x=x.numpy(), rec=rec.numpy(), idx=idx.numpy(), f=f.numpy(), seed=np.int32(seed),
+             meta=np.array(str(meta())))
+    print("wrote", name, "rec range", float(rec.min()), float(rec.max()), "distinct codes", len(set(idx.tolist())))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
+    if only in ("model", ""):
+        # BASELINE config 1 (the reference's own CPU-runnable case): VQ-4096, CNN encoder/decoder, 72 M parameters
+        gen_model("model_cfg1_cnn_vq4096", dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], enc_type="cnn",
+                                                dec_type="cnn", semantic_guide="none", detail_guide="none",
+                                                num_latent_tokens=256, product_quant=1), seed=31)
+        # BASELINE config 2 geometry: VQ-8192, DINOv2 ViT-B encoder/decoder (vendored reference ViT over the timm shim)
+        gen_model("model_cfg2_vitb_vq8192", dict(codebook_size=8192, codebook_embed_dim=32, v_patch_nums=[16], enc_type="dinov2",
+                                                 dec_type="dinov2", semantic_guide="none", detail_guide="none",
+                                                 num_latent_tokens=256, product_quant=1, abs_pos_embed=True,
+                                                 encoder_model="vit_base_patch14_dinov2.lvd142m",
+                                                 decoder_model="vit_base_patch14_dinov2.lvd142m"), seed=32)
+        if only:
+            return
     if only in ("msvq", ""):
         # BASELINE config 4 ladder (MSVR10P2: 1x1 -> 11x11, C=32, codebook_drop 0.1, start_drop 3); V reduced to keep the
         # fixture small (V=4096 full-size runs are oracle-vs-HIP tests)

@@ -103,3 +103,41 @@ def test_vqloss_generator_and_discriminator_paths_run_and_differentiate():
     # frozen trunks stay out of parameters()/state_dict(), like upstream's tuple-held proxy
     assert not any("dino_proxy" in k for k in L.state_dict())
     assert all(not p.requires_grad for p in L.perceptual_loss.parameters())
+
+
+def test_single_backward_generator_loss_equals_upstream_formulation():
+    """value and every gradient of the restructured generator loss == the literal upstream branch (3 backward passes)"""
+    from imagefolder_amd.vq_loss import VQLoss
+    torch.manual_seed(0)
+    L = VQLoss(disc_start=0, disc_type='dinodisc', disc_weight=0.5, disc_adaptive_weight=True, lecam_loss_weight=0.001,
+               norm_type='bn', aug_prob=0.0).eval()  # aug off + eval: both evaluations see the same network/randomness
+    last = torch.nn.Parameter(torch.randn(3, 3, 1, 1) * 0.2)
+    pre = torch.nn.Parameter(torch.rand(4, 3, 64, 64) * 2 - 1)
+    imgs = torch.rand(4, 3, 64, 64) * 2 - 1
+    cb = (torch.tensor(0.1), torch.tensor(0.02), 0.0, [1.0])
+    res = []
+    for single in (True, False):
+        for p in (last, pre):
+            p.grad = None
+        for p in L.discriminator.parameters():
+            p.grad = None
+        rec = torch.nn.functional.conv2d(pre, last)
+        if single:
+            loss = L(cb, None, None, 0.0, imgs, rec, optimizer_idx=0, global_step=5, last_layer=last)
+        else:
+            L.disc_adaptive_weight = False  # take the literal branch, computing the adaptive weight by hand
+            rec_loss = L.rec_loss(imgs, rec)
+            p_loss = torch.mean(L.perceptual_loss(imgs, rec))
+            adv = L.gen_adv_loss(L.discriminator(L.daug.aug(rec, 0)))
+            w = L.calculate_adaptive_weight(rec_loss + p_loss, adv, last_layer=last)
+            loss = rec_loss + p_loss + w * 0.5 * adv + cb[0] + cb[1] + cb[2]
+            L.disc_adaptive_weight = True
+        loss.backward()
+        res.append((loss.item(), last.grad.clone(), pre.grad.clone(),
+                    [p.grad.clone() for p in L.discriminator.parameters() if p.requires_grad]))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0])
+    for a, b in ((res[0][1], res[1][1]), (res[0][2], res[1][2])):
+        assert (a - b).abs().max() <= 1e-5 * b.abs().max() + 1e-9
+    scale = max(b.abs().max().item() for b in res[1][3])  # conv biases in front of a BatchNorm have an exactly-zero gradient:
+    for a, b in zip(res[0][3], res[1][3]):                  # compare against the global head-gradient scale, not per tensor
+        assert (a - b).abs().max().item() <= 1e-4 * scale
