@@ -51,6 +51,8 @@ SIGNATURES = {
     "xq_gelu_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp]),
     "xq_gelu_backward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]),
     "xq_colsum": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
+    "xq_lpips_level_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_lpips_level_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
 }

@@ -385,3 +385,125 @@ extern "C" int xq_colsum(const void *g, int64_t rows, int H, int act_bf16, float
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + 63) / 64), dim3(256), 0, s, partials, blocks, 1, H, out, nullptr, nullptr, nullptr, accumulate);
     return xq_check_launch(fn);
 }
+
+// ================================================================================================
+// LPIPS feature comparison (reference lpips.py:85-96,159-164), one fused pass per VGG level:
+//   val[b] = (1/HW) sum_{h,w} sum_c w_c * ( f0/(|f0|+eps) - f1/(|f1|+eps) )^2 ,  |f| = sqrt(sum_c f^2), eps = 1e-10
+// f0, f1: channels-last activations, i.e. [B][HW][C] contiguous (T = bf16 under autocast, fp32 otherwise); w: [C] fp32.
+// The reference runs ~10 elementwise/reduction kernels over fp32 copies of both feature maps per level (1 G elements
+// per image set at B = 128); here each level reads f0 and f1 once (forward) and once more + writes d f1 (backward).
+// A pixel is handled by C/8 consecutive lanes (8 channels = one 16-byte load per lane for bf16).
+// ================================================================================================
+template <typename T, int C>
+__global__ __launch_bounds__(256) void lpips_level_fwd_kernel(const T *__restrict__ f0, const T *__restrict__ f1,
+                                                              const float *__restrict__ w, int HW, float *__restrict__ val) {
+    constexpr int LPP = C / 8;  // lanes per pixel (8, 16, 32, 64)
+    constexpr int PPW = 64 / LPP;  // pixels per wave
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPP, pix_in_wave = lane / LPP;
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = w[sub * 8 + j];
+    float acc = 0.0f;
+    const size_t base = (size_t)b * HW * C;
+    for (int p = (blockIdx.x * 4 + wave) * PPW + pix_in_wave; p < HW; p += gridDim.x * 4 * PPW) {
+        float a[8], c[8];
+        load_vec<T, 8>(f0 + base + (size_t)p * C + sub * 8, a);
+        load_vec<T, 8>(f1 + base + (size_t)p * C + sub * 8, c);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0 = __builtin_fmaf(a[j], a[j], s0); s1 = __builtin_fmaf(c[j], c[j], s1); }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+        const float i0 = 1.0f / (__builtin_sqrtf(s0) + 1e-10f), i1 = 1.0f / (__builtin_sqrtf(s1) + 1e-10f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = a[j] * i0 - c[j] * i1; acc = __builtin_fmaf(wv[j] * d, d, acc); }
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if (lane == 0) red[wave] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(val + b, ((red[0] + red[1]) + (red[2] + red[3])) / (float)HW);
+}
+
+// g1 = d val[b]/d f1 * gout[b]:  g_u = -2 w (u0 - u1) * gout/HW ;  g_f = g_u/n - f * (g_u . f) / (n^2 r),  n = r + eps
+template <typename T, int C>
+__global__ __launch_bounds__(256) void lpips_level_bwd_kernel(const T *__restrict__ f0, const T *__restrict__ f1,
+                                                              const float *__restrict__ w, const float *__restrict__ gout,
+                                                              int HW, T *__restrict__ g1) {
+    constexpr int LPP = C / 8;
+    constexpr int PPW = 64 / LPP;
+    const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane % LPP, pix_in_wave = lane / LPP;
+    float wv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[j] = w[sub * 8 + j];
+    const float gs = gout[b] / (float)HW;
+    const size_t base = (size_t)b * HW * C;
+    for (int p = (blockIdx.x * 4 + wave) * PPW + pix_in_wave; p < HW; p += gridDim.x * 4 * PPW) {
+        float a[8], c[8];
+        load_vec<T, 8>(f0 + base + (size_t)p * C + sub * 8, a);
+        load_vec<T, 8>(f1 + base + (size_t)p * C + sub * 8, c);
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { s0 = __builtin_fmaf(a[j], a[j], s0); s1 = __builtin_fmaf(c[j], c[j], s1); }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+        const float r1 = __builtin_sqrtf(s1);
+        const float i0 = 1.0f / (__builtin_sqrtf(s0) + 1e-10f), n1 = r1 + 1e-10f, i1 = 1.0f / n1;
+        float gu[8], dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gu[j] = -2.0f * wv[j] * (a[j] * i0 - c[j] * i1) * gs;
+            dot = __builtin_fmaf(gu[j], c[j], dot);
+        }
+#pragma unroll
+        for (int o = LPP / 2; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        const float k = r1 > 0.0f ? dot * i1 * i1 / r1 : 0.0f;
+        float out[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = gu[j] * i1 - c[j] * k;
+        store_vec<T, 8>(g1 + base + (size_t)p * C + sub * 8, out);
+    }
+}
+
+template <typename T>
+static int lpips_dispatch(bool bwd, const T *f0, const T *f1, const float *w, const float *gout, int B, int HW, int C, float *val,
+                          T *g1, hipStream_t s) {
+    int bx = (HW + 31) / 32;
+    const int cap = (num_cus() * 8 + B - 1) / B;
+    if (bx > cap) bx = cap < 1 ? 1 : cap;
+    dim3 grid(bx, B), block(256);
+#define LP_CASE(CC)                                                                                                      \
+    case CC:                                                                                                             \
+        if (bwd) hipLaunchKernelGGL((lpips_level_bwd_kernel<T, CC>), grid, block, 0, s, f0, f1, w, gout, HW, g1);        \
+        else hipLaunchKernelGGL((lpips_level_fwd_kernel<T, CC>), grid, block, 0, s, f0, f1, w, HW, val);                 \
+        break;
+    switch (C) {
+        LP_CASE(64) LP_CASE(128) LP_CASE(256) LP_CASE(512)
+        default: return xq_set_error(XQ_EINVAL, "%s: unsupported channel count C=%ld (64,128,256,512)", "xq_lpips_level", C);
+    }
+#undef LP_CASE
+    return xq_check_launch("lpips_level kernel");
+}
+
+extern "C" int xq_lpips_level_forward(const void *f0, const void *f1, const float *w, int B, int HW, int C, int act_bf16, float *val,
+                                      xq_stream_t stream) {
+    if (B == 0) return XQ_OK;
+    if (!f0 || !f1 || !w || !val) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_lpips_level_forward");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(val, 0, (size_t)B * 4, s) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipMemsetAsync failed");
+    if (act_bf16) return lpips_dispatch<bf16>(false, (const bf16 *)f0, (const bf16 *)f1, w, nullptr, B, HW, C, val, nullptr, s);
+    return lpips_dispatch<float>(false, (const float *)f0, (const float *)f1, w, nullptr, B, HW, C, val, nullptr, s);
+}
+
+extern "C" int xq_lpips_level_backward(const void *f0, const void *f1, const float *w, const float *gout, int B, int HW, int C,
+                                       int act_bf16, void *g1, xq_stream_t stream) {
+    if (B == 0) return XQ_OK;
+    if (!f0 || !f1 || !w || !gout || !g1) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_lpips_level_backward");
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) return lpips_dispatch<bf16>(true, (const bf16 *)f0, (const bf16 *)f1, w, gout, B, HW, C, nullptr, (bf16 *)g1, s);
+    return lpips_dispatch<float>(true, (const float *)f0, (const float *)f1, w, gout, B, HW, C, nullptr, (float *)g1, s);
+}

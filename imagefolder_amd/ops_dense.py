@@ -274,3 +274,35 @@ def run_blocks(blocks, x, final_norm, act_dtype):
         nxt = blocks[i + 1].norm1 if i + 1 < n else final_norm
         x, a = ResLNFn.apply(x, f, g2, m2, nxt.weight, nxt.bias, nxt.eps, blk.mlp.fc2.bias)
     return a
+
+
+class LpipsLevelFn(torch.autograd.Function):
+    """val[b] = mean_hw sum_c w_c (unit(f0) - unit(f1))^2 for one VGG level (lpips.py:85-96) — one fused kernel each way.
+    f0 (no grad), f1: (B, C, H, W) tensors in channels_last memory format; w: (C,) fp32."""
+
+    @staticmethod
+    def forward(ctx, f0, f1, w):
+        B, C, H, W = f1.shape
+        f0c = f0.detach().contiguous(memory_format=torch.channels_last)
+        f1c = f1.detach().contiguous(memory_format=torch.channels_last)
+        if f0c.dtype != f1c.dtype:
+            f0c = f0c.to(f1c.dtype)
+        wc = w.detach().float().reshape(-1).contiguous()
+        val = torch.empty(B, dtype=torch.float32, device=f1.device)
+        with torch.cuda.device(f1.device):
+            rc = _lib.lib().xq_lpips_level_forward(ptr(f0c), ptr(f1c), ptr(wc), B, H * W, C, _act_flag(f1c.dtype), ptr(val), _stream(f1))
+        check(rc, "xq_lpips_level_forward")
+        ctx.save_for_backward(f0c, f1c, wc)
+        return val
+
+    @staticmethod
+    def backward(ctx, g):
+        f0c, f1c, wc = ctx.saved_tensors
+        B, C, H, W = f1c.shape
+        g1 = torch.empty_like(f1c, memory_format=torch.channels_last)
+        gg = g.float().contiguous()
+        with torch.cuda.device(f1c.device):
+            rc = _lib.lib().xq_lpips_level_backward(ptr(f0c), ptr(f1c), ptr(wc), ptr(gg), B, H * W, C, _act_flag(f1c.dtype), ptr(g1),
+                                                    _stream(f1c))
+        check(rc, "xq_lpips_level_backward")
+        return None, g1, None

@@ -122,6 +122,17 @@ class LPIPS(nn.Module):
         return x / (torch.sqrt(torch.sum(x ** 2, dim=1, keepdim=True)) + eps)
 
     def forward(self, input, target):
+        """`input` is the data (no gradient), `target` the reconstruction — the order VQLoss calls it in (vq_loss.py:169)."""
+        if target.is_cuda and not input.requires_grad:
+            from .ops_dense import LpipsLevelFn
+            with torch.no_grad():
+                f0 = self.net((input - self.shift) / self.scale)
+            f1 = self.net((target - self.shift) / self.scale)
+            val = 0
+            for k in range(len(self.chns)):
+                wk = getattr(self, f"lin{k}").model[-1].weight
+                val = val + LpipsLevelFn.apply(f0[k], f1[k], wk)
+            return val.view(-1, 1, 1, 1)
         f0 = self.net((input - self.shift) / self.scale)
         f1 = self.net((target - self.shift) / self.scale)
         val = 0

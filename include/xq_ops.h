@@ -185,6 +185,15 @@ int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, int H, int 
 int xq_colsum(const void *g, int64_t rows, int H, int act_bf16, float *out, int accumulate, float *partials,
               xq_stream_t stream);
 
+/* ---- LPIPS feature comparison (lpips.py:85-96,159-164), one fused pass per VGG level -------------------------------
+ * val[b] = mean_{h,w} sum_c w_c (f0/(|f0|+1e-10) - f1/(|f1|+1e-10))^2 with f0, f1 channels-last activations
+ * ([B][HW][C] contiguous; act_bf16 selects bf16 / fp32), w [C] fp32, val [B] fp32.  C in {64,128,256,512}. */
+int xq_lpips_level_forward(const void *f0, const void *f1, const float *w, int B, int HW, int C, int act_bf16, float *val,
+                           xq_stream_t stream);
+/* g1 [B][HW][C] (dtype of f1) = gout[b] * d val[b] / d f1 */
+int xq_lpips_level_backward(const void *f0, const void *f1, const float *w, const float *gout, int B, int HW, int C,
+                            int act_bf16, void *g1, xq_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
  *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the
  *      recorded events and returns the summed duration and launch count since arming. ------------------ */

@@ -145,3 +145,30 @@ def test_droppath_masks_follow_reference_order_and_scale():
         outs.append(m.forward_features(x).detach())
     nn_ops.FUSED_BLOCKS = True
     assert (outs[0] - outs[1]).abs().max() <= 2e-5
+
+
+@pytest.mark.parametrize("C,HW", [(64, 24), (128, 12), (256, 8), (512, 5)])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_lpips_level_kernel_vs_reference_expression(C, HW, dt):
+    from imagefolder_amd.ops_dense import LpipsLevelFn
+    torch.manual_seed(C)
+    B = 3
+    f0 = torch.relu(torch.randn(B, C, HW, HW, device="cuda")).to(dt).contiguous(memory_format=torch.channels_last)
+    f1 = torch.relu(torch.randn(B, C, HW, HW, device="cuda")).to(dt).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    f1.data[0, :, 0, 0] = 0  # an all-zero pixel (|f| = 0) must not produce NaN
+    w = torch.rand(1, C, 1, 1, device="cuda")
+    val = LpipsLevelFn.apply(f0, f1, w)
+    gout = torch.rand(B, device="cuda")
+    (val * gout).sum().backward()
+
+    def unit(x, eps=1e-10):  # lpips.py:159-161
+        return x / (torch.sqrt(torch.sum(x ** 2, dim=1, keepdim=True)) + eps)
+    r1 = f1.detach().float().requires_grad_(True)
+    ref = (w * (unit(f0.float()) - unit(r1)) ** 2).sum(1, keepdim=True).mean([2, 3]).view(-1)
+    (ref * gout).sum().backward()
+    tol = 1e-5 if dt == torch.float32 else 2e-2
+    assert (val - ref).abs().max() <= tol * ref.abs().max()
+    assert torch.isfinite(f1.grad).all()  # the all-zero pixel gets gradient 0 (ATen's sqrt backward yields 0/0 = NaN there)
+    ok = torch.isfinite(r1.grad)
+    assert (~ok).sum() <= C and ok.float().mean() > 0.95
+    assert (f1.grad.float() - r1.grad)[ok].abs().max() <= tol * r1.grad[ok].abs().max() * 2
