@@ -1,0 +1,188 @@
+// xq_conv.hip — 3x3 convolution (stride 1, pad 1) as an implicit GEMM on bf16 MFMA, NHWC activations (gfx950).
+//
+// Replaces the cuDNN/MIOpen conv3x3 calls of the reference's CNN encoder/decoder (tokenizer/tokenizer_image/
+// xqgan_model.py:454-622: conv_in/ResnetBlock.conv1/conv2/Upsample.conv/conv_out — 99 % of its 391 GFLOP/img) and of the
+// LPIPS VGG16 trunk (lpips.py:118-155).  On gfx950 MIOpen serves these shapes with igemm_*_nhwc_bf16 kernels at
+// ~110 TFLOP/s (profiles/r01_train_step_full_kernel_stats.txt).
+//
+//   Y[b,y,x,n] = act( bias[n] + sum_{ky,kx,c} X[b, y+ky-1, x+kx-1, c] * W[n][c][ky][kx] )
+// GEMM view: M = B*H*W output pixels, N = Cout, K = 9*Cin with k = (ky*3+kx)*Cin + c (channel fastest: every K-slice of
+// 32 is a contiguous 64-byte run of one input pixel -> 16-byte coalesced gathers straight from NHWC, no im2col buffer).
+// Weights are pre-packed once per update to Wp[n][k] (bf16), the same K order.
+// The data gradient is the same kernel run on dY with Wp'[c][(2-ky)*3+(2-kx)][n] (rotated taps, swapped channels).
+//
+// Tile: 128 pixels x BN channels x 32 K per step, 256 threads = 2x2 waves, each wave 64 x BN/2 through
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate); A/B tiles staged global -> VGPR -> LDS (row pitch 80 B: conflict-free
+// ds_read_b128 fragments), double-buffered, one barrier per K step.  Epilogue: + bias, optional ReLU, bf16 NHWC store.
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "../../include/xq_ops.h"
+
+#include <hip/hip_bf16.h>
+
+using namespace xq;
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+
+static constexpr int CV_BM = 128, CV_BK = 32, CV_PITCH = 40;  // LDS row pitch in bf16 elements (80 bytes)
+
+
+template <int BN, bool RELU>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__restrict__ X, const __hip_bfloat16 *__restrict__ Wp,
+                                                      const float *__restrict__ bias, long M, int H, int Wd, int Cin, int Cout,
+                                                      __hip_bfloat16 *__restrict__ Y) {
+    constexpr int WN = BN / 2;          // channels per wave
+    constexpr int NT = WN / 32;         // 32-wide N tiles per wave (2 for BN=128, 1 for BN=64)
+    constexpr int B_CHUNKS = BN * 4 / 256;  // 16-byte chunks of the B tile per thread (2 or 1)
+    __shared__ __attribute__((aligned(16))) short lds[2][(CV_BM + BN) * CV_PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.x * CV_BM;
+    const int n0 = blockIdx.y * BN;
+    const int K = 9 * Cin;
+    const int ksteps = K / CV_BK;
+
+    // ---- A gather bookkeeping: this thread fetches rows ra0 = tid/4 and ra0+64, 16-byte part tid%4 ----
+    const int part = tid & 3;
+    const long HWd = (long)H * Wd;
+    const long ma = m0 + (tid >> 2), mb = ma + 64;
+    const bool ok0 = ma < M, ok1 = mb < M;
+    const long mma = ok0 ? ma : 0, mmb = ok1 ? mb : 0;
+    const long ba = mma / HWd, bb = mmb / HWd;
+    const int rema = (int)(mma - ba * HWd), remb = (int)(mmb - bb * HWd);
+    const int ay0 = rema / Wd, ax0 = rema - ay0 * Wd, ay1 = remb / Wd, ax1 = remb - ay1 * Wd;
+    const long ab0 = ba * HWd, ab1 = bb * HWd;  // pixel index of (b, 0, 0)
+
+    // staged registers (kept as named scalars: arrays captured by lambdas end up in scratch with hipcc)
+    uint4 ra0, ra1, rb0, rb1;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+#define CV_LOAD_TILES(KS)                                                                                              \
+    {                                                                                                                  \
+        const int k0_ = (KS) * CV_BK;                                                                                  \
+        const int tap_ = k0_ / Cin, c0_ = k0_ - tap_ * Cin;                                                            \
+        const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                                                 \
+        {                                                                                                              \
+            const int yy = ay0 + dy_, xx = ax0 + dx_;                                                              \
+            const bool ok = ok0 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                     \
+            ra0 = ok ? *reinterpret_cast<const uint4 *>(X + ((ab0 + (long)yy * Wd + xx) * Cin + c0_ + part * 8)) : zero4; \
+        }                                                                                                              \
+        {                                                                                                              \
+            const int yy = ay1 + dy_, xx = ax1 + dx_;                                                              \
+            const bool ok = ok1 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                     \
+            ra1 = ok ? *reinterpret_cast<const uint4 *>(X + ((ab1 + (long)yy * Wd + xx) * Cin + c0_ + part * 8)) : zero4; \
+        }                                                                                                              \
+        rb0 = *reinterpret_cast<const uint4 *>(Wp + ((long)(n0 + (tid >> 2)) * K + k0_ + (tid & 3) * 8));              \
+        if (B_CHUNKS > 1) rb1 = *reinterpret_cast<const uint4 *>(Wp + ((long)(n0 + ((tid + 256) >> 2)) * K + k0_ + (tid & 3) * 8)); \
+    }
+#define CV_STORE_TILES(BUF)                                                                                            \
+    {                                                                                                                  \
+        short *A_ = lds[BUF], *B_ = lds[BUF] + CV_BM * CV_PITCH;                                                       \
+        *reinterpret_cast<uint4 *>(A_ + (tid >> 2) * CV_PITCH + part * 8) = ra0;                                       \
+        *reinterpret_cast<uint4 *>(A_ + ((tid >> 2) + 64) * CV_PITCH + part * 8) = ra1;                                \
+        *reinterpret_cast<uint4 *>(B_ + (tid >> 2) * CV_PITCH + (tid & 3) * 8) = rb0;                                  \
+        if (B_CHUNKS > 1) *reinterpret_cast<uint4 *>(B_ + ((tid + 256) >> 2) * CV_PITCH + (tid & 3) * 8) = rb1;        \
+    }
+    rb1 = zero4;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    CV_LOAD_TILES(0)
+    CV_STORE_TILES(0)
+    __syncthreads();
+
+    const int frow = lane & 31, fk = (lane >> 5) * 8;  // fragment: row/col = lane%32, k offset = 8*(lane/32)
+    for (int ks = 0; ks < ksteps; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < ksteps) CV_LOAD_TILES(ks + 1)  // global -> VGPR, lands under the MFMAs below
+        const short *A = lds[cur] + (wm * 64) * CV_PITCH;
+        const short *Bs = lds[cur] + CV_BM * CV_PITCH + (wn * WN) * CV_PITCH;
+#pragma unroll
+        for (int kk = 0; kk < CV_BK; kk += 16) {
+            bf16x8 af[2], bfr[NT];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(A + (i * 32 + frow) * CV_PITCH + kk + fk);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + frow) * CV_PITCH + kk + fk);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+        if (ks + 1 < ksteps) CV_STORE_TILES(cur ^ 1)
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int n = n0 + wn * WN + j * 32 + (lane & 31);
+        const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                float v = acc[i][j][r] + bv;
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                if (m < M) Y[m * Cout + n] = __float2bfloat16(v);
+            }
+        }
+    }
+}
+
+#undef CV_LOAD_TILES
+#undef CV_STORE_TILES
+
+// W[n][c][ky][kx] (fp32 or bf16 source, given as fp32 here) -> Wp[n][(ky*3+kx)*Cin + c] bf16          (forward)
+//                                                           -> Wp'[c][((2-ky)*3+(2-kx))*Cout + n]     (data gradient)
+__global__ __launch_bounds__(256) void pack_conv3x3_weights_kernel(const float *__restrict__ W, int Cout, int Cin, int transpose_flip,
+                                                                   __hip_bfloat16 *__restrict__ Wp) {
+    const long total = (long)Cout * Cin * 9;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int kx = (int)(i % 3), ky = (int)((i / 3) % 3);
+    const int c = (int)((i / 9) % Cin), n = (int)(i / (9L * Cin));
+    const float v = W[i];
+    long o;
+    if (!transpose_flip) o = (long)n * 9 * Cin + (ky * 3 + kx) * Cin + c;
+    else o = (long)c * 9 * Cout + ((2 - ky) * 3 + (2 - kx)) * Cout + n;
+    Wp[o] = __float2bfloat16(v);
+}
+
+extern "C" int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad, void *Wp, xq_stream_t stream) {
+    if (!W || !Wp || Cout < 1 || Cin < 1) return xq_set_error(XQ_EINVAL, "%s: bad arguments", "xq_conv3x3_pack_weights");
+    const long total = (long)Cout * Cin * 9;
+    hipLaunchKernelGGL(pack_conv3x3_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, W, Cout, Cin,
+                       for_data_grad, (__hip_bfloat16 *)Wp);
+    return xq_check_launch("pack_conv3x3_weights_kernel");
+}
+
+extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
+                                    void *Y, xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_nhwc_bf16";
+    if (B == 0) return XQ_OK;
+    if (!X || !Wp || !Y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (Cin % 32 != 0 || Cout % 64 != 0)
+        return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %ld, %ld)", fn, Cin, Cout);
+    const long M = (long)B * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned gx = (unsigned)((M + CV_BM - 1) / CV_BM);
+    const __hip_bfloat16 *x = (const __hip_bfloat16 *)X, *w = (const __hip_bfloat16 *)Wp;
+    __hip_bfloat16 *y = (__hip_bfloat16 *)Y;
+    if (Cout % 128 == 0) {
+        if (relu) hipLaunchKernelGGL((conv3x3_kernel<128, true>), dim3(gx, Cout / 128), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+        else hipLaunchKernelGGL((conv3x3_kernel<128, false>), dim3(gx, Cout / 128), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+    } else {
+        if (relu) hipLaunchKernelGGL((conv3x3_kernel<64, true>), dim3(gx, Cout / 64), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+        else hipLaunchKernelGGL((conv3x3_kernel<64, false>), dim3(gx, Cout / 64), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+    }
+    return xq_check_launch(fn);
+}

@@ -49,7 +49,7 @@ __device__ __forceinline__ void store_vec(T *p, const float (&in)[VEC]) {
 }
 
 static constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows in flight per block
-static constexpr int MAX_ROW_BLOCKS = 1024;  // also the number of partial rows the finalize kernel reduces
+static constexpr int MAX_ROW_BLOCKS = 512;   // also the number of partial rows the finalize kernel reduces
 
 // element index of (chunk k, lane l, j): k*64*VEC + l*VEC + j  -> each wave instruction reads 64*VEC contiguous elements
 template <typename T, int NV, int VEC>

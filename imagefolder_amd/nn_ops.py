@@ -128,7 +128,19 @@ def group_norm_silu(x, groups, weight, bias, eps, silu=True):
 CHANNELS_LAST = True
 
 
-def conv2d(x, weight, bias, stride=1, padding=0):
+def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
+    """conv2d [+ ReLU].  3x3 / stride 1 / pad 1 convs with 64-multiple channel counts run on the hand-written
+    implicit-GEMM kernel (csrc/xq_conv.hip) when activations are bf16 (autocast); everything else is the library conv."""
+    if x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled("cuda")):
+        from . import ops_dense
+        if ops_dense.conv3x3_supported(x, weight, stride, padding):
+            IMPL["conv2d"] = "hip(3x3 s1 p1, C%64==0) + aten(rest)"
+            return ops_dense.Conv3x3Fn.apply(x, weight, bias, relu)
+    y = _conv2d_library(x, weight, bias, stride, padding)
+    return torch.relu(y) if relu else y
+
+
+def _conv2d_library(x, weight, bias, stride=1, padding=0):
     if CHANNELS_LAST and x.is_cuda and x.dim() == 4 and weight.shape[-1] > 1:
         x = x.contiguous(memory_format=torch.channels_last)
     return F.conv2d(x, weight, bias, stride=stride, padding=padding)

@@ -306,3 +306,67 @@ class LpipsLevelFn(torch.autograd.Function):
                                                     _stream(f1c))
         check(rc, "xq_lpips_level_backward")
         return None, g1, None
+
+
+def _packed_conv_weight(weight, for_data_grad: bool):
+    """bf16 K-major pack of a conv3x3 weight, cached on the parameter and refreshed when it changes."""
+    key = "_xq_pack_dgrad" if for_data_grad else "_xq_pack_fwd"
+    cache = getattr(weight, key, None)
+    if cache is not None and cache[0] == weight._version and cache[1].device == weight.device:
+        return cache[1]
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    w32 = weight.detach().float().contiguous()
+    wp = torch.empty((Cin, 9 * Cout) if for_data_grad else (Cout, 9 * Cin), dtype=torch.bfloat16, device=weight.device)
+    with torch.cuda.device(weight.device):
+        rc = _lib.lib().xq_conv3x3_pack_weights(ptr(w32), Cout, Cin, int(for_data_grad), ptr(wp), _stream(weight))
+    check(rc, "xq_conv3x3_pack_weights")
+    setattr(weight, key, (weight._version, wp))
+    return wp
+
+
+def conv3x3_supported(x, weight, stride, padding):
+    return (x.is_cuda and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and padding == 1
+            and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0)  # the data gradient swaps the two
+
+
+def _conv3x3_call(x_cl, wp, bias, Cout, relu):
+    B, Cin, H, W = x_cl.shape
+    y = torch.empty((B, Cout, H, W), dtype=torch.bfloat16, device=x_cl.device, memory_format=torch.channels_last)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    with torch.cuda.device(x_cl.device):
+        rc = _lib.lib().xq_conv3x3_nhwc_bf16(ptr(x_cl), ptr(wp), ptr(b32), B, H, W, Cin, Cout, int(relu), ptr(y), _stream(x_cl))
+    check(rc, "xq_conv3x3_nhwc_bf16")
+    return y
+
+
+class Conv3x3Fn(torch.autograd.Function):
+    """y = [relu](conv3x3(x, W) + b), stride 1, pad 1, bf16 NHWC, hand-written implicit-GEMM kernel both ways for the
+    activations; the weight gradient (only needed for the trainable CNN encoder/decoder) uses the library wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x_cl = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        y = _conv3x3_call(x_cl, _packed_conv_weight(weight, False), bias, weight.shape[0], relu)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x_cl, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x_cl, weight, y = ctx.saved_tensors
+        g = g.to(torch.bfloat16)
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)  # one pass: g * (y > 0)
+        g = g.contiguous(memory_format=torch.channels_last)
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = _conv3x3_call(g, _packed_conv_weight(weight, True), None, weight.shape[1], False).to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            _, g_w, _ = torch.ops.aten.convolution_backward(g, x_cl, weight.detach().to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
+                                                            False, [0, 0], 1, [False, True, False])
+            g_w = g_w.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_b = g.float().sum((0, 2, 3))
+        return g_x, g_w, g_b, None

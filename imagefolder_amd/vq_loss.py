@@ -83,9 +83,19 @@ class _VGG16Slices(nn.Module):
         # it falls back to naive_conv_* kernels on gfx950 (profiles/r01_full_step_naive_conv_stats.txt: 0.75 s/step)
         if x.is_cuda:
             x = x.contiguous(memory_format=torch.channels_last)
+        from . import nn_ops
         outs = []
         for si in range(1, 6):
-            x = getattr(self, f"slice{si}")(x)
+            mods = list(getattr(self, f"slice{si}"))
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, nn.Conv2d):  # conv + the ReLU that always follows it, as one op (fused epilogue on the HIP path)
+                    x = nn_ops.conv2d(x, m.weight, m.bias, stride=1, padding=1, relu=True)
+                    i += 2
+                else:
+                    x = m(x)
+                    i += 1
             outs.append(x)
         return outs
 
@@ -285,7 +295,7 @@ class _SpectralConv1d(nn.Conv1d):
       * the power iteration runs in fp32 outside autocast — under bf16 autocast torch.mv becomes a bf16 gemv that costs
         ~5 ms per call on this stack (15 convs x 2 gemv = 170 ms per discriminator forward, measured);
       * the convolution is a GEMM (kernel 1: channel matmul; kernel k, circular padding: k shifted copies gathered into
-        (B*L, C_in*k) x W^T)."""
+        (B*L, C_in*k) x W^T; k rolled matmuls were measured slower in the backward)."""
 
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)

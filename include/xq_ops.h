@@ -194,6 +194,18 @@ int xq_lpips_level_forward(const void *f0, const void *f1, const float *w, int B
 int xq_lpips_level_backward(const void *f0, const void *f1, const float *w, const float *gout, int B, int HW, int C,
                             int act_bf16, void *g1, xq_stream_t stream);
 
+/* ---- 3x3 convolution, stride 1, pad 1, NHWC bf16, implicit GEMM on MFMA (xqgan_model.py:454-622 conv3x3 layers;
+ *      lpips.py:118-155 VGG16 trunk) ------------------------------------------------------------------------------------ */
+
+/* W [Cout][Cin][3][3] fp32 (device) -> Wp bf16 [Cout][9*Cin] with k = (ky*3+kx)*Cin + c (for_data_grad = 0), or the
+ * rotated/transposed pack [Cin][9*Cout] that turns the same kernel into the data-gradient conv (for_data_grad = 1). */
+int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad, void *Wp, xq_stream_t stream);
+
+/* Y[b,y,x,n] = act(bias[n] + sum_{ky,kx,c} X[b,y+ky-1,x+kx-1,c] * W[n][c][ky][kx]); X [B][H][W][Cin], Y [B][H][W][Cout]
+ * bf16 NHWC (= torch channels_last); bias fp32 [Cout] nullable; relu != 0 fuses ReLU.  Cin % 32 == 0, Cout % 64 == 0. */
+int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
+                         void *Y, xq_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
  *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the
  *      recorded events and returns the summed duration and launch count since arming. ------------------ */

@@ -172,3 +172,30 @@ def test_lpips_level_kernel_vs_reference_expression(C, HW, dt):
     ok = torch.isfinite(r1.grad)
     assert (~ok).sum() <= C and ok.float().mean() > 0.95
     assert (f1.grad.float() - r1.grad)[ok].abs().max() <= tol * r1.grad[ok].abs().max() * 2
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 16), (3, 64, 128, 9, 11), (1, 128, 256, 32, 32), (2, 512, 512, 5, 7), (1, 64, 192, 8, 8)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_conv3x3_implicit_gemm_vs_aten_fp32(shape, relu):
+    """hand-written NHWC bf16 conv3x3 (fwd + data gradient) vs F.conv2d in fp32 on the same bf16-rounded operands"""
+    from imagefolder_amd.ops_dense import Conv3x3Fn
+    B, Cin, Cout, H, W = shape
+    torch.manual_seed(Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") / (3 * Cin ** 0.5)).requires_grad_(True)
+    b = torch.randn(Cout, device="cuda").requires_grad_(True)
+    y = Conv3x3Fn.apply(x, w, b, relu)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, padding=1)
+    if relu:
+        yr = torch.relu(yr)
+    yr.backward(g.float())
+    assert y.shape == yr.shape
+    assert (y.float() - yr).abs().max() <= 2e-2 * yr.abs().max()
+    assert (x.grad.float() - xr.grad).abs().max() <= 3e-2 * xr.grad.abs().max()
+    assert (w.grad - wr.grad).abs().max() <= 3e-2 * wr.grad.abs().max()
+    assert (b.grad - br.grad).abs().max() <= 3e-2 * br.grad.abs().max()
