@@ -1,0 +1,539 @@
+// xq_attn.hip — multi-head self-attention (head_dim 64, no mask, no dropout) on the packed qkv projection, forward and
+// backward, bf16 MFMA with fp32 softmax statistics (gfx950).
+//
+// Replaces F.scaled_dot_product_attention in the reference's ViT blocks (tokenizer/tokenizer_image/dino_enc/
+// vision_transformer.py:175-195: qkv.reshape(B,N,3,H,hd).permute(2,0,3,1,4) -> SDPA -> transpose(1,2).reshape(B,N,C)) and in
+// the frozen DINO-S trunk of the discriminator (discriminator_dino.py:28).  The kernels read q/k/v straight out of the
+// packed (B, N, 3, H, 64) projection and write (B, N, H*64) / the packed gradient, so the permute copies and the
+// gradient concat of the library path do not exist.
+//
+// Layouts (v_mfma_f32_32x32x16_bf16: A[i][k] lane = i, 8 consecutive k per lane half; B[k][j] lane = j; D[i][j] col = lane&31,
+// row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
+//  * forward / dQ kernels keep one query per lane: S^T = K Q^T (A = K rows from LDS, B = Q in registers), so softmax row
+//    statistics are per-lane scalars (+ one cross-half shuffle), P stays in registers and is directly the B operand of
+//    O^T = V^T P^T (resp. dQ^T = K^T dS^T); the register order of P defines the key order of the contraction, the A operand
+//    (V^T / K^T) is read in the same order out of the row-major LDS tile with the gfx950 transpose read ds_read_b64_tr_b16.
+//  * the dK/dV kernel keeps one key per lane: S = Q K^T (A = Q rows from LDS, B = K in registers), P / dS are the B operands
+//    of dV^T = dO^T P and dK^T = Q^T dS (A = dO^T / Q^T through transpose reads); lse and delta come per register from LDS.
+// ds_read_b64_tr_b16 (probed in tools/ubench/ds_read_tr.hip): in each group of 16 lanes, lane i receives element (i & 3) of
+// the 8-byte chunks addressed by lanes 4j + (i >> 2), j = 0..3 -> with lane x pointing at row (x >> 2), columns 4*(x & 3)..+3
+// of a row-major tile, lane i gets column i of rows 0..3: four consecutive contraction indices at a fixed output row.
+// S and dP are recomputed in both backward kernels (7 tile products in total, no atomics, no N x N buffer).
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "../../include/xq_ops.h"
+
+using namespace xq;
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+typedef float fv2 __attribute__((ext_vector_type(2)));
+
+static constexpr int AT_RP = 72;   // row-major tile pitch in bf16 (144 B: conflict-free ds_read_b128 fragments)
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    fv2 v = {a, b};
+    bfv2 r = __builtin_convertvector(v, bfv2);   // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, float a4, float a5, float a6, float a7) {
+    uint4 u = make_uint4(pack_bf16(a0, a1), pack_bf16(a2, a3), pack_bf16(a4, a5), pack_bf16(a6, a7));
+    return __builtin_bit_cast(bf16x8, u);
+}
+
+__device__ __forceinline__ bf16x8 cat4(bf16x4 lo, bf16x4 hi) {
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// blocks that share one (batch, head) land on the same XCD (round-robin dispatch: XCD = block id mod 8), so its K/V (or
+// Q/dO) rows are fetched into one L2 only
+__device__ __forceinline__ bool map_block(int L, int nper, int G, int &g, int &i) {
+    const int xcd = L & 7, slot = L >> 3;
+    const int gl = slot / nper;
+    i = slot - gl * nper;
+    g = gl * 8 + xcd;
+    return g < G;
+}
+
+typedef short s4lds __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x4 lds_tr4(const short *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s4lds __attribute__((address_space(3))) *)p);
+}
+// A-operand fragment of T^T for a row-major tile T (pitch AT_RP): rows (contraction index) ROW0 + {4hh..4hh+3, 8+4hh..},
+// output rows = columns COL0 + (lane & 31).  trp = T + (4*hh + ((lane&15)>>2))*AT_RP + 16*((lane>>4)&1) + 4*(lane&3).
+#define AT_TFRAG(TRP, ROW0, COL0) cat4(lds_tr4((TRP) + (ROW0) * AT_RP + (COL0)), lds_tr4((TRP) + ((ROW0) + 8) * AT_RP + (COL0)))
+
+// row index clamped by the caller: the load is unconditional and the value is zeroed afterwards (a "cond ? *p : zero" select
+// makes hipcc pick between a global and a private pointer and issue flat loads through scratch)
+__device__ __forceinline__ uint4 load16_or_zero(const short *p, bool ok) {
+    uint4 v = *reinterpret_cast<const uint4 *>(p);
+    if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+    return v;
+}
+
+#define AT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: out[b, n, h, :] = softmax(q k^T * scale) v ; lse[b, h, n] = log sum exp (natural log, scaled scores)
+// block = 128 queries of one (b, h) (4 waves x 32), loop over 64-key tiles: K row-major + V transposed in LDS, 2 buffers.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const short *__restrict__ qkv, int B, int N, int H, float c, short *__restrict__ out,
+                                                       float *__restrict__ lse, int nqb) {
+    __shared__ __attribute__((aligned(16))) short Ks[2][64 * AT_RP];
+    __shared__ __attribute__((aligned(16))) short Vs[2][64 * AT_RP];
+    int g, qb;
+    if (!map_block(blockIdx.x, nqb, B * H, g, qb)) return;
+    const int b = g / H, h = g - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hh = lane >> 5;
+    const int troff = (4 * hh + ((lane & 15) >> 2)) * AT_RP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const long RS = 3L * H * 64;
+    const short *base = qkv + (long)b * N * RS + h * 64;
+    const short *kbase = base + H * 64, *vbase = base + 2 * H * 64;
+
+    const int qn = qb * 128 + wave * 32 + li;
+    const int qc = qn < N ? qn : N - 1;
+    bf16x8 qf0, qf1, qf2, qf3;
+    {
+        const short *qp = base + (long)qc * RS + 8 * hh;
+        qf0 = *reinterpret_cast<const bf16x8 *>(qp);
+        qf1 = *reinterpret_cast<const bf16x8 *>(qp + 16);
+        qf2 = *reinterpret_cast<const bf16x8 *>(qp + 32);
+        qf3 = *reinterpret_cast<const bf16x8 *>(qp + 48);
+    }
+
+    // staging: 16-byte chunks of K and V, key = tid/8 [+32], part = tid%8, both row-major
+    const int kkey = tid >> 3, kpart = tid & 7;
+    uint4 rk0, rk1, rv0, rv1;
+#define FW_LOAD(KV0)                                                                                                   \
+    {                                                                                                                  \
+        const int k0_ = (KV0) + kkey, k1_ = k0_ + 32;                                                                  \
+        rk0 = load16_or_zero(kbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                              \
+        rk1 = load16_or_zero(kbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                              \
+        rv0 = load16_or_zero(vbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                              \
+        rv1 = load16_or_zero(vbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                              \
+    }
+#define FW_STORE(BUF)                                                                                                  \
+    {                                                                                                                  \
+        *reinterpret_cast<uint4 *>(Ks[BUF] + kkey * AT_RP + 8 * kpart) = rk0;                                          \
+        *reinterpret_cast<uint4 *>(Ks[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rk1;                                   \
+        *reinterpret_cast<uint4 *>(Vs[BUF] + kkey * AT_RP + 8 * kpart) = rv0;                                          \
+        *reinterpret_cast<uint4 *>(Vs[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rv1;                                   \
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; }
+    float m_run = -INFINITY, l_run = 0.0f;
+
+    const int ntiles = (N + 63) / 64;
+    FW_LOAD(0)
+    FW_STORE(0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1, kv0 = t * 64;
+        if (t + 1 < ntiles) FW_LOAD(kv0 + 64)
+        const short *K = Ks[cur], *V = Vs[cur] + troff;
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.0f; s1[r] = 0.0f; }
+        {
+            const short *ka = K + li * AT_RP + 8 * hh, *kb = ka + 32 * AT_RP;
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka), qf0, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb), qf0, s1);
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 16), qf1, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 16), qf1, s1);
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 32), qf2, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 32), qf2, s1);
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 48), qf3, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 48), qf3, s1);
+        }
+        if (kv0 + 64 > N) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (key >= N) s0[r] = -INFINITY;
+                if (key + 32 >= N) s1[r] = -INFINITY;
+            }
+        }
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m_run, mx * c);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - mn);
+        m_run = mn;
+        float rs = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mn));
+            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mn));
+            rs += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        const bf16x8 p00 = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+        const bf16x8 p01 = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        const bf16x8 p10 = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+        const bf16x8 p11 = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+        {
+            // A = V^T rows d (lane), key slots {4hh..4hh+3, 8+4hh..} of each 16-key step: the order P's registers hold
+            o0 = AT_MFMA(AT_TFRAG(V, 0, 0), p00, o0);
+            o1 = AT_MFMA(AT_TFRAG(V, 0, 32), p00, o1);
+            o0 = AT_MFMA(AT_TFRAG(V, 16, 0), p01, o0);
+            o1 = AT_MFMA(AT_TFRAG(V, 16, 32), p01, o1);
+            o0 = AT_MFMA(AT_TFRAG(V, 32, 0), p10, o0);
+            o1 = AT_MFMA(AT_TFRAG(V, 32, 32), p10, o1);
+            o0 = AT_MFMA(AT_TFRAG(V, 48, 0), p11, o0);
+            o1 = AT_MFMA(AT_TFRAG(V, 48, 32), p11, o1);
+        }
+        if (t + 1 < ntiles) FW_STORE(cur ^ 1)
+        __syncthreads();
+    }
+#undef FW_LOAD
+#undef FW_STORE
+
+    l_run += __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_run;
+    if (qn < N) {
+        short *op = out + ((long)b * N + qn) * (H * 64) + h * 64 + 4 * hh;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            uint2 w0 = make_uint2(pack_bf16(o0[4 * r4] * inv, o0[4 * r4 + 1] * inv), pack_bf16(o0[4 * r4 + 2] * inv, o0[4 * r4 + 3] * inv));
+            uint2 w1 = make_uint2(pack_bf16(o1[4 * r4] * inv, o1[4 * r4 + 1] * inv), pack_bf16(o1[4 * r4 + 2] * inv, o1[4 * r4 + 3] * inv));
+            *reinterpret_cast<uint2 *>(op + 8 * r4) = w0;
+            *reinterpret_cast<uint2 *>(op + 32 + 8 * r4) = w1;
+        }
+        if (hh == 0) lse[((long)b * H + h) * N + qn] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// delta[b, h, n] = sum_d dO[b, n, h, d] * O[b, n, h, d]   (8 lanes per row, 16 bytes each)
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_delta_kernel(const short *__restrict__ o, const short *__restrict__ dout, int B, int N, int H,
+                                                         float *__restrict__ delta) {
+    const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);   // row = (b*N + n)*H + h
+    const long rows = (long)B * N * H;
+    const int part = threadIdx.x & 7;
+    float acc = 0.0f;
+    if (row < rows) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(o + row * 64 + 8 * part);
+        const uint4 d = *reinterpret_cast<const uint4 *>(dout + row * 64 + 8 * part);
+        acc = bf_lo(a.x) * bf_lo(d.x) + bf_hi(a.x) * bf_hi(d.x) + bf_lo(a.y) * bf_lo(d.y) + bf_hi(a.y) * bf_hi(d.y) +
+              bf_lo(a.z) * bf_lo(d.z) + bf_hi(a.z) * bf_hi(d.z) + bf_lo(a.w) * bf_lo(d.w) + bf_hi(a.w) * bf_hi(d.w);
+    }
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    acc += __shfl_xor(acc, 4);
+    if (row < rows && part == 0) {
+        const long bn = row / H;
+        const int h = (int)(row - bn * H);
+        const long b = bn / N;
+        const int n = (int)(bn - b * N);
+        delta[(b * H + h) * N + n] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dQ: one query per lane (as the forward).  Per 64-key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP - delta) scale,
+// dQ^T += K^T dS^T.  LDS per buffer: K and V row-major (K^T fragments through transpose reads).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
+                                                          const float *__restrict__ lse, const float *__restrict__ delta, int B, int N, int H,
+                                                          float scale, short *__restrict__ dqkv, int nqb) {
+    __shared__ __attribute__((aligned(16))) short Ks[2][64 * AT_RP];
+    __shared__ __attribute__((aligned(16))) short Vs[2][64 * AT_RP];
+    int g, qb;
+    if (!map_block(blockIdx.x, nqb, B * H, g, qb)) return;
+    const int b = g / H, h = g - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hh = lane >> 5;
+    const int troff = (4 * hh + ((lane & 15) >> 2)) * AT_RP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const long RS = 3L * H * 64;
+    const short *base = qkv + (long)b * N * RS + h * 64;
+    const short *kbase = base + H * 64, *vbase = base + 2 * H * 64;
+    const float c = scale * 1.4426950408889634f;
+
+    const int qn = qb * 128 + wave * 32 + li;
+    const int qc = qn < N ? qn : N - 1;
+    bf16x8 qf0, qf1, qf2, qf3, df0, df1, df2, df3;
+    {
+        const short *qp = base + (long)qc * RS + 8 * hh;
+        qf0 = *reinterpret_cast<const bf16x8 *>(qp);
+        qf1 = *reinterpret_cast<const bf16x8 *>(qp + 16);
+        qf2 = *reinterpret_cast<const bf16x8 *>(qp + 32);
+        qf3 = *reinterpret_cast<const bf16x8 *>(qp + 48);
+        const short *dp = dout + ((long)b * N + qc) * (H * 64) + h * 64 + 8 * hh;
+        df0 = *reinterpret_cast<const bf16x8 *>(dp);
+        df1 = *reinterpret_cast<const bf16x8 *>(dp + 16);
+        df2 = *reinterpret_cast<const bf16x8 *>(dp + 32);
+        df3 = *reinterpret_cast<const bf16x8 *>(dp + 48);
+    }
+    const float lse2 = lse[((long)b * H + h) * N + qc] * 1.4426950408889634f;
+    const float dq_ = delta[((long)b * H + h) * N + qc];
+
+    const int kkey = tid >> 3, kpart = tid & 7;
+    uint4 rk0, rk1, rv0, rv1;
+#define DQ_LOAD(KV0)                                                                                                   \
+    {                                                                                                                  \
+        const int k0_ = (KV0) + kkey, k1_ = k0_ + 32;                                                                  \
+        rk0 = load16_or_zero(kbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                   \
+        rk1 = load16_or_zero(kbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                   \
+        rv0 = load16_or_zero(vbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                   \
+        rv1 = load16_or_zero(vbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                   \
+    }
+#define DQ_STORE(BUF)                                                                                                  \
+    {                                                                                                                  \
+        *reinterpret_cast<uint4 *>(Ks[BUF] + kkey * AT_RP + 8 * kpart) = rk0;                                          \
+        *reinterpret_cast<uint4 *>(Ks[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rk1;                                   \
+        *reinterpret_cast<uint4 *>(Vs[BUF] + kkey * AT_RP + 8 * kpart) = rv0;                                          \
+        *reinterpret_cast<uint4 *>(Vs[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rv1;                                   \
+    }
+
+    f32x16 a0, a1;   // dQ^T, d rows 0..31 / 32..63
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
+
+    const int ntiles = (N + 63) / 64;
+    DQ_LOAD(0)
+    DQ_STORE(0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1, kv0 = t * 64;
+        if (t + 1 < ntiles) DQ_LOAD(kv0 + 64)
+        const short *K = Ks[cur], *V = Vs[cur], *T = Ks[cur] + troff;
+        f32x16 s0, s1, p0, p1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.0f; s1[r] = 0.0f; p0[r] = 0.0f; p1[r] = 0.0f; }
+        {
+            const short *ka = K + li * AT_RP + 8 * hh, *kb = ka + 32 * AT_RP;
+            const short *va = V + li * AT_RP + 8 * hh, *vb = va + 32 * AT_RP;
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka), qf0, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb), qf0, s1);
+            p0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(va), df0, p0);
+            p1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(vb), df0, p1);
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 16), qf1, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 16), qf1, s1);
+            p0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(va + 16), df1, p0);
+            p1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(vb + 16), df1, p1);
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 32), qf2, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 32), qf2, s1);
+            p0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(va + 32), df2, p0);
+            p1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(vb + 32), df2, p1);
+            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 48), qf3, s0);
+            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 48), qf3, s1);
+            p0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(va + 48), df3, p0);
+            p1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(vb + 48), df3, p1);
+        }
+        // keys beyond N were staged as zeros: their dS is finite and multiplies K^T = 0
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -lse2)) * (p0[r] - dq_) * scale;
+            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -lse2)) * (p1[r] - dq_) * scale;
+        }
+        const bf16x8 d00 = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+        const bf16x8 d01 = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
+        const bf16x8 d10 = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+        const bf16x8 d11 = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+        {
+            a0 = AT_MFMA(AT_TFRAG(T, 0, 0), d00, a0);
+            a1 = AT_MFMA(AT_TFRAG(T, 0, 32), d00, a1);
+            a0 = AT_MFMA(AT_TFRAG(T, 16, 0), d01, a0);
+            a1 = AT_MFMA(AT_TFRAG(T, 16, 32), d01, a1);
+            a0 = AT_MFMA(AT_TFRAG(T, 32, 0), d10, a0);
+            a1 = AT_MFMA(AT_TFRAG(T, 32, 32), d10, a1);
+            a0 = AT_MFMA(AT_TFRAG(T, 48, 0), d11, a0);
+            a1 = AT_MFMA(AT_TFRAG(T, 48, 32), d11, a1);
+        }
+        if (t + 1 < ntiles) DQ_STORE(cur ^ 1)
+        __syncthreads();
+    }
+#undef DQ_LOAD
+#undef DQ_STORE
+
+    if (qn < N) {
+        short *op = dqkv + ((long)b * N + qn) * RS + h * 64 + 4 * hh;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            uint2 w0 = make_uint2(pack_bf16(a0[4 * r4], a0[4 * r4 + 1]), pack_bf16(a0[4 * r4 + 2], a0[4 * r4 + 3]));
+            uint2 w1 = make_uint2(pack_bf16(a1[4 * r4], a1[4 * r4 + 1]), pack_bf16(a1[4 * r4 + 2], a1[4 * r4 + 3]));
+            *reinterpret_cast<uint2 *>(op + 8 * r4) = w0;
+            *reinterpret_cast<uint2 *>(op + 32 + 8 * r4) = w1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dK, dV: one key per lane (block = 128 keys of one (b, h), 4 waves x 32).  Per 32-query tile: S = Q K^T, dP = dO V^T,
+// P = exp2(S c - lse2), dS = P (dP - delta) scale, dV^T += dO^T P, dK^T += Q^T dS.
+// LDS per buffer: Q, dO row-major [32][72]; Q, dO transposed [64][36]; lse2, delta [32].
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
+                                                            const float *__restrict__ lse, const float *__restrict__ delta, int B, int N, int H,
+                                                            float scale, short *__restrict__ dqkv, int nkb) {
+    __shared__ __attribute__((aligned(16))) short Qs[2][32 * AT_RP];
+    __shared__ __attribute__((aligned(16))) short Os[2][32 * AT_RP];
+    __shared__ __attribute__((aligned(16))) float Ls[2][32];
+    __shared__ __attribute__((aligned(16))) float Ds[2][32];
+    int g, kb;
+    if (!map_block(blockIdx.x, nkb, B * H, g, kb)) return;
+    const int b = g / H, h = g - b * H;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, hh = lane >> 5;
+    const int troff = (4 * hh + ((lane & 15) >> 2)) * AT_RP + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    const long RS = 3L * H * 64;
+    const int OSr = H * 64;
+    const short *base = qkv + (long)b * N * RS + h * 64;
+    const short *dob = dout + (long)b * N * OSr + h * 64;
+    const float *lseb = lse + ((long)b * H + h) * N, *delb = delta + ((long)b * H + h) * N;
+    const float c = scale * 1.4426950408889634f;
+
+    const int kn = kb * 128 + wave * 32 + li;
+    const bool wave_live = kb * 128 + wave * 32 < N;   // waves whose 32 keys are all padding only help with staging
+    bf16x8 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
+    {
+        const bool ok = kn < N;
+        const short *kp = base + (long)(ok ? kn : 0) * RS + H * 64 + 8 * hh;
+        const short *vp = kp + H * 64;
+        kf0 = __builtin_bit_cast(bf16x8, load16_or_zero(kp, ok));
+        kf1 = __builtin_bit_cast(bf16x8, load16_or_zero(kp + 16, ok));
+        kf2 = __builtin_bit_cast(bf16x8, load16_or_zero(kp + 32, ok));
+        kf3 = __builtin_bit_cast(bf16x8, load16_or_zero(kp + 48, ok));
+        vf0 = __builtin_bit_cast(bf16x8, load16_or_zero(vp, ok));
+        vf1 = __builtin_bit_cast(bf16x8, load16_or_zero(vp + 16, ok));
+        vf2 = __builtin_bit_cast(bf16x8, load16_or_zero(vp + 32, ok));
+        vf3 = __builtin_bit_cast(bf16x8, load16_or_zero(vp + 48, ok));
+    }
+
+    // staging: one 16-byte chunk of Q and of dO per thread (query = tid/8, part = tid%8); threads 0..31 fetch lse, 32..63 delta
+    const int sq = tid >> 3, sp = tid & 7;
+    uint4 rq, ro;
+    float rl = 0.0f;
+#define KV_LOAD(Q0)                                                                                                    \
+    {                                                                                                                  \
+        const int q_ = (Q0) + sq;                                                                                      \
+        rq = load16_or_zero(base + (long)(q_ < N ? q_ : 0) * RS + 8 * sp, q_ < N);                          \
+        ro = load16_or_zero(dob + (long)(q_ < N ? q_ : 0) * OSr + 8 * sp, q_ < N);                          \
+        if (tid < 64) {                                                                                                \
+            const int ql_ = (Q0) + li;                                                                                 \
+            rl = ql_ < N ? (hh == 0 ? lseb[ql_] * 1.4426950408889634f : delb[ql_]) : 0.0f;                              \
+        }                                                                                                              \
+    }
+#define KV_STORE(BUF)                                                                                                  \
+    {                                                                                                                  \
+        *reinterpret_cast<uint4 *>(Qs[BUF] + sq * AT_RP + 8 * sp) = rq;                                                \
+        *reinterpret_cast<uint4 *>(Os[BUF] + sq * AT_RP + 8 * sp) = ro;                                                \
+        if (tid < 32) Ls[BUF][li] = rl;                                                                                \
+        else if (tid < 64) Ds[BUF][li] = rl;                                                                           \
+    }
+
+    f32x16 dk0, dk1, dv0, dv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dk0[r] = 0.0f; dk1[r] = 0.0f; dv0[r] = 0.0f; dv1[r] = 0.0f; }
+
+    const int ntiles = (N + 31) / 32;
+    KV_LOAD(0)
+    KV_STORE(0)
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < ntiles) KV_LOAD(t * 32 + 32)
+        if (wave_live) {
+            const short *qa = Qs[cur] + li * AT_RP + 8 * hh, *oa = Os[cur] + li * AT_RP + 8 * hh;
+            f32x16 s, p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.0f; p[r] = 0.0f; }
+            s = AT_MFMA(*reinterpret_cast<const bf16x8 *>(qa), kf0, s);
+            p = AT_MFMA(*reinterpret_cast<const bf16x8 *>(oa), vf0, p);
+            s = AT_MFMA(*reinterpret_cast<const bf16x8 *>(qa + 16), kf1, s);
+            p = AT_MFMA(*reinterpret_cast<const bf16x8 *>(oa + 16), vf1, p);
+            s = AT_MFMA(*reinterpret_cast<const bf16x8 *>(qa + 32), kf2, s);
+            p = AT_MFMA(*reinterpret_cast<const bf16x8 *>(oa + 32), vf2, p);
+            s = AT_MFMA(*reinterpret_cast<const bf16x8 *>(qa + 48), kf3, s);
+            p = AT_MFMA(*reinterpret_cast<const bf16x8 *>(oa + 48), vf3, p);
+            // register r <-> query (r&3) + 8*(r>>2) + 4*hh of the tile; padded queries have Q = dO = 0 and lse2 = delta = 0:
+            // their P is finite and multiplies dO^T = 0 / their dS multiplies Q^T = 0
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const float4 l4 = *reinterpret_cast<const float4 *>(&Ls[cur][8 * r4 + 4 * hh]);
+                const float4 d4 = *reinterpret_cast<const float4 *>(&Ds[cur][8 * r4 + 4 * hh]);
+                float e;
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 0], c, -l4.x)); s[4 * r4 + 0] = e; p[4 * r4 + 0] = e * (p[4 * r4 + 0] - d4.x) * scale;
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 1], c, -l4.y)); s[4 * r4 + 1] = e; p[4 * r4 + 1] = e * (p[4 * r4 + 1] - d4.y) * scale;
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 2], c, -l4.z)); s[4 * r4 + 2] = e; p[4 * r4 + 2] = e * (p[4 * r4 + 2] - d4.z) * scale;
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 3], c, -l4.w)); s[4 * r4 + 3] = e; p[4 * r4 + 3] = e * (p[4 * r4 + 3] - d4.w) * scale;
+            }
+            const bf16x8 pb0 = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
+            const bf16x8 pb1 = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
+            const bf16x8 db0 = pack8(p[0], p[1], p[2], p[3], p[4], p[5], p[6], p[7]);
+            const bf16x8 db1 = pack8(p[8], p[9], p[10], p[11], p[12], p[13], p[14], p[15]);
+            const short *ot = Os[cur] + troff, *qt = Qs[cur] + troff;
+            dv0 = AT_MFMA(AT_TFRAG(ot, 0, 0), pb0, dv0);
+            dv1 = AT_MFMA(AT_TFRAG(ot, 0, 32), pb0, dv1);
+            dk0 = AT_MFMA(AT_TFRAG(qt, 0, 0), db0, dk0);
+            dk1 = AT_MFMA(AT_TFRAG(qt, 0, 32), db0, dk1);
+            dv0 = AT_MFMA(AT_TFRAG(ot, 16, 0), pb1, dv0);
+            dv1 = AT_MFMA(AT_TFRAG(ot, 16, 32), pb1, dv1);
+            dk0 = AT_MFMA(AT_TFRAG(qt, 16, 0), db1, dk0);
+            dk1 = AT_MFMA(AT_TFRAG(qt, 16, 32), db1, dk1);
+        }
+        if (t + 1 < ntiles) KV_STORE(cur ^ 1)
+        __syncthreads();
+    }
+#undef KV_LOAD
+#undef KV_STORE
+
+    if (kn < N) {
+        short *kp = dqkv + ((long)b * N + kn) * RS + H * 64 + h * 64 + 4 * hh;
+        short *vp = kp + H * 64;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            *reinterpret_cast<uint2 *>(kp + 8 * r4) = make_uint2(pack_bf16(dk0[4 * r4], dk0[4 * r4 + 1]), pack_bf16(dk0[4 * r4 + 2], dk0[4 * r4 + 3]));
+            *reinterpret_cast<uint2 *>(kp + 32 + 8 * r4) = make_uint2(pack_bf16(dk1[4 * r4], dk1[4 * r4 + 1]), pack_bf16(dk1[4 * r4 + 2], dk1[4 * r4 + 3]));
+            *reinterpret_cast<uint2 *>(vp + 8 * r4) = make_uint2(pack_bf16(dv0[4 * r4], dv0[4 * r4 + 1]), pack_bf16(dv0[4 * r4 + 2], dv0[4 * r4 + 3]));
+            *reinterpret_cast<uint2 *>(vp + 32 + 8 * r4) = make_uint2(pack_bf16(dv1[4 * r4], dv1[4 * r4 + 1]), pack_bf16(dv1[4 * r4 + 2], dv1[4 * r4 + 3]));
+        }
+    }
+}
+
+static int attn_check(const char *fn, int B, int N, int H, int head_dim) {
+    if (B < 0 || N < 1 || H < 1) return xq_set_error(XQ_EINVAL, "%s: bad sizes (N=%ld, H=%ld)", fn, (long)N, (long)H);
+    if (head_dim != 64) return xq_set_error(XQ_EINVAL, "%s: head_dim must be 64 (got %ld)", fn, (long)head_dim);
+    return XQ_OK;
+}
+
+extern "C" int xq_attn_forward(const void *qkv, int B, int N, int H, int head_dim, float scale, void *out, float *lse, xq_stream_t stream) {
+    const char *fn = "xq_attn_forward";
+    if (int rc = attn_check(fn, B, N, H, head_dim)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!qkv || !out || !lse) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const int nqb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(G8 * nqb)), dim3(256), 0, (hipStream_t)stream, (const short *)qkv, B, N, H,
+                       scale * 1.4426950408889634f, (short *)out, lse, nqb);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_attn_backward(const void *qkv, const void *out, const void *dout, const float *lse, int B, int N, int H, int head_dim,
+                                float scale, void *dqkv, float *delta, xq_stream_t stream) {
+    const char *fn = "xq_attn_backward";
+    if (int rc = attn_check(fn, B, N, H, head_dim)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!qkv || !out || !dout || !lse || !dqkv || !delta) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = (hipStream_t)stream;
+    const long rows = (long)B * N * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const short *)out, (const short *)dout, B, N, H,
+                       delta);
+    const int nb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N,
+                       H, scale, (short *)dqkv, nb);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N, H,
+                       scale, (short *)dqkv, nb);
+    return xq_check_launch(fn);
+}

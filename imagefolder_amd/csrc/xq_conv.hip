@@ -65,12 +65,14 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__re
         {                                                                                                              \
             const int yy = ay0 + dy_, xx = ax0 + dx_;                                                              \
             const bool ok = ok0 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                     \
-            ra0 = ok ? *reinterpret_cast<const uint4 *>(X + ((ab0 + (long)yy * Wd + xx) * Cin + c0_ + part * 8)) : zero4; \
+            ra0 = *reinterpret_cast<const uint4 *>(X + ((ab0 + (ok ? (long)yy * Wd + xx : 0L)) * Cin + c0_ + part * 8)); \
+            if (!ok) ra0 = zero4;                                                                                     \
         }                                                                                                              \
         {                                                                                                              \
             const int yy = ay1 + dy_, xx = ax1 + dx_;                                                              \
             const bool ok = ok1 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                     \
-            ra1 = ok ? *reinterpret_cast<const uint4 *>(X + ((ab1 + (long)yy * Wd + xx) * Cin + c0_ + part * 8)) : zero4; \
+            ra1 = *reinterpret_cast<const uint4 *>(X + ((ab1 + (ok ? (long)yy * Wd + xx : 0L)) * Cin + c0_ + part * 8)); \
+            if (!ok) ra1 = zero4;                                                                                     \
         }                                                                                                              \
         rb0 = *reinterpret_cast<const uint4 *>(Wp + ((long)(n0 + (tid >> 2)) * K + k0_ + (tid & 3) * 8));              \
         if (B_CHUNKS > 1) rb1 = *reinterpret_cast<const uint4 *>(Wp + ((long)(n0 + ((tid + 256) >> 2)) * K + k0_ + (tid & 3) * 8)); \

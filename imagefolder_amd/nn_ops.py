@@ -79,9 +79,11 @@ def linear_gelu(x, weight, bias=None):
 
 def attention_qkvpacked(qkv, num_heads):
     """qkv: (B, N, 3*C) packed as [3][heads][head_dim] -> (B, N, C); softmax(q k^T / sqrt(d)) v, no mask, no dropout."""
-    f = _hip("attention")
-    if f is not None and qkv.is_cuda:
-        return f(qkv, num_heads)
+    if qkv.is_cuda:
+        from . import ops_dense
+        if ops_dense.attention_supported(qkv, num_heads):
+            IMPL["attention"] = "hip"
+            return ops_dense.AttentionFn.apply(qkv, num_heads)
     B, N, C3 = qkv.shape
     C = C3 // 3
     q, k, v = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)

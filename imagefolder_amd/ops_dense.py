@@ -236,8 +236,49 @@ class LinearFn(torch.autograd.Function):
         return g_x, g_w, g_b, None
 
 
+class AttentionFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v on the packed (B, N, 3*H*64) bf16 projection: xq_attn_forward / xq_attn_backward
+    (csrc/xq_attn.hip).  Mirrors dino_enc/vision_transformer.py:175-195 (fused_attn branch, attn_drop = 0)."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads):
+        B, N, C3 = qkv.shape
+        hd = C3 // (3 * num_heads)
+        q = qkv.detach().contiguous()
+        out = torch.empty(B, N, C3 // 3, dtype=q.dtype, device=q.device)
+        lse = torch.empty(B, num_heads, N, dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().xq_attn_forward(ptr(q), B, N, num_heads, hd, float(hd) ** -0.5, ptr(out), ptr(lse), _stream(q))
+        check(rc, "xq_attn_forward")
+        ctx.save_for_backward(q, out, lse)
+        ctx.num_heads = num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, out, lse = ctx.saved_tensors
+        B, N, C3 = q.shape
+        H = ctx.num_heads
+        hd = C3 // (3 * H)
+        g = g.detach().to(q.dtype).contiguous()
+        dqkv = torch.empty_like(q)
+        delta = torch.empty_like(lse)
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().xq_attn_backward(ptr(q), ptr(out), ptr(g), ptr(lse), B, N, H, hd, float(hd) ** -0.5, ptr(dqkv), ptr(delta),
+                                             _stream(q))
+        check(rc, "xq_attn_backward")
+        return dqkv, None
+
+
+def attention_supported(qkv, num_heads):
+    return qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.dim() == 3 and qkv.shape[-1] == 3 * num_heads * 64
+
+
 def attention_qkvpacked(qkv, num_heads):
-    """(B, N, 3*C) -> (B, N, C): library SDPA (flash kernels) on strided q/k/v views of the packed projection."""
+    """(B, N, 3*C) -> (B, N, C).  bf16 with head_dim 64: the hand-written kernels on the packed projection; anything else
+    (the fp32 parity path): library SDPA on strided q/k/v views."""
+    if attention_supported(qkv, num_heads):
+        return AttentionFn.apply(qkv, num_heads)
     B, N, C3 = qkv.shape
     C = C3 // 3
     q, k, v = qkv.view(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)

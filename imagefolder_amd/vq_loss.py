@@ -238,8 +238,8 @@ class _SABlock(nn.Module):
 
     def forward(self, x):
         B, L, C = x.shape
-        qkv = self.attn.qkv(self.norm1(x)).view(B, L, 3, self.heads, C // self.heads).permute(2, 0, 3, 1, 4)
-        o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2]).transpose(1, 2).reshape(B, L, C)
+        from . import nn_ops
+        o = nn_ops.attention_qkvpacked(self.attn.qkv(self.norm1(x)), self.heads)
         x = x + self.attn.proj(o)
         return x + self.mlp.fc2(F.gelu(self.mlp.fc1(self.norm2(x)), approximate='tanh'))
 

@@ -206,6 +206,18 @@ int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad
 int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
                          void *Y, xq_stream_t stream);
 
+/* ---- multi-head self-attention on the packed qkv projection (dino_enc/vision_transformer.py:175-195: qkv.reshape(B,N,3,H,hd)
+ *      .permute(2,0,3,1,4) -> F.scaled_dot_product_attention -> transpose(1,2).reshape(B,N,C); discriminator_dino.py:28).
+ *      bf16 MFMA, fp32 softmax statistics, head_dim 64 only, no mask, no dropout. ------------------------------------------ */
+
+/* qkv bf16 [B][N][3][H][64] (the output of the qkv Linear as is); out bf16 [B][N][H*64]; lse fp32 [B][H][N] = natural-log
+ * sum-exp of the scaled scores (kept for the backward). */
+int xq_attn_forward(const void *qkv, int B, int N, int H, int head_dim, float scale, void *out, float *lse, xq_stream_t stream);
+
+/* dout bf16 [B][N][H*64] -> dqkv bf16 [B][N][3][H][64] (every element written).  delta: fp32 [B][H][N] scratch. */
+int xq_attn_backward(const void *qkv, const void *out, const void *dout, const float *lse, int B, int N, int H, int head_dim,
+                     float scale, void *dqkv, float *delta, xq_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
  *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the
  *      recorded events and returns the summed duration and launch count since arming. ------------------ */
