@@ -138,6 +138,8 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
         if ops_dense.conv3x3_supported(x, weight, stride, padding):
             IMPL["conv2d"] = "hip(3x3 s1 p1, C%64==0) + aten(rest)"
             return ops_dense.Conv3x3Fn.apply(x, weight, bias, relu)
+        if ops_dense.conv3x3_small_cin_supported(x, weight, stride, padding):
+            return ops_dense.Conv3x3SmallCinFn.apply(x, weight, bias, relu)
     y = _conv2d_library(x, weight, bias, stride, padding)
     return torch.relu(y) if relu else y
 

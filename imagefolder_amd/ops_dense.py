@@ -357,7 +357,10 @@ def _packed_conv_weight(weight, for_data_grad: bool):
         return cache[1]
     Cout, Cin = weight.shape[0], weight.shape[1]
     w32 = weight.detach().float().contiguous()
-    wp = torch.empty((Cin, 9 * Cout) if for_data_grad else (Cout, 9 * Cin), dtype=torch.bfloat16, device=weight.device)
+    if for_data_grad:  # rows = input channels, padded with zero rows to the kernel's 64-channel output tile
+        wp = torch.zeros(((Cin + 63) // 64 * 64, 9 * Cout), dtype=torch.bfloat16, device=weight.device)
+    else:
+        wp = torch.empty((Cout, 9 * Cin), dtype=torch.bfloat16, device=weight.device)
     with torch.cuda.device(weight.device):
         rc = _lib.lib().xq_conv3x3_pack_weights(ptr(w32), Cout, Cin, int(for_data_grad), ptr(wp), _stream(weight))
     check(rc, "xq_conv3x3_pack_weights")
@@ -404,6 +407,48 @@ class Conv3x3Fn(torch.autograd.Function):
         g_x = g_w = g_b = None
         if ctx.needs_input_grad[0]:
             g_x = _conv3x3_call(g, _packed_conv_weight(weight, True), None, weight.shape[1], False).to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            _, g_w, _ = torch.ops.aten.convolution_backward(g, x_cl, weight.detach().to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
+                                                            False, [0, 0], 1, [False, True, False])
+            g_w = g_w.to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_b = g.float().sum((0, 2, 3))
+        return g_x, g_w, g_b, None
+
+
+def conv3x3_small_cin_supported(x, weight, stride, padding):
+    """first-layer convs (Cin = 3): forward on the library conv, data gradient on the hand-written kernel with the input
+    channels zero-padded to 64 (MIOpen's bwd-data solver for Cin = 3 takes 27 ms at 128 x 256 x 256: profiles/r01)."""
+    return (x.is_cuda and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and padding == 1
+            and weight.shape[1] < 64 and weight.shape[0] % 64 == 0 and x.requires_grad)
+
+
+class Conv3x3SmallCinFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        x_cl = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w16 = weight.detach().to(torch.bfloat16)
+        y = F.conv2d(x_cl, w16, None if bias is None else bias.detach().to(torch.bfloat16), stride=1, padding=1)
+        if relu:
+            y = torch.relu_(y)
+        ctx.relu = bool(relu)
+        ctx.save_for_backward(x_cl, weight, y if relu else None)
+        ctx.has_bias = bias is not None
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x_cl, weight, y = ctx.saved_tensors
+        g = g.to(torch.bfloat16)
+        if ctx.relu:
+            g = torch.ops.aten.threshold_backward(g, y, 0)
+        g = g.contiguous(memory_format=torch.channels_last)
+        g_x = g_w = g_b = None
+        Cin = weight.shape[1]
+        if ctx.needs_input_grad[0]:
+            wp = _packed_conv_weight(weight, True)
+            g_x = _conv3x3_call(g, wp, None, wp.shape[0], False)[:, :Cin].to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
             _, g_w, _ = torch.ops.aten.convolution_backward(g, x_cl, weight.detach().to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
                                                             False, [0, 0], 1, [False, True, False])

@@ -249,3 +249,27 @@ def test_attention_matches_library_sdpa_in_blocks():
     q, k, v = qkv.view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4).unbind(0)
     lib = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(B, N, H * 64).float()
     assert (mine - lib).abs().max().item() <= 2e-2
+
+
+@pytest.mark.gpu
+def test_conv3x3_small_cin_data_grad():
+    """first-layer conv (Cin = 3): data gradient through the zero-padded hand-written kernel vs fp32 autograd"""
+    from imagefolder_amd import nn_ops
+    torch.manual_seed(11)
+    dev = "cuda"
+    x = torch.randn(2, 3, 24, 20, device=dev, requires_grad=True)
+    w = (torch.randn(64, 3, 3, 3, device=dev) * 0.2).requires_grad_(True)
+    b = torch.randn(64, device=dev) * 0.1
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = nn_ops.conv2d(x, w, b, stride=1, padding=1, relu=True)
+    assert y.dtype == torch.bfloat16
+    g = torch.randn_like(y, dtype=torch.float32)
+    gx, gw = torch.autograd.grad(y.float(), (x, w), g)
+    xr = x.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b.to(torch.bfloat16).float(), padding=1)
+    # mask by the kernel's own ReLU decisions so that near-zero pre-activations do not flip gradients
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), g.to(torch.bfloat16).float() * (y.float() > 0))
+    assert (y.float() - torch.relu(yr)).abs().max().item() <= 3e-2
+    assert (gx - gxr).abs().max().item() <= 2e-2 * max(1.0, gxr.abs().max().item())
+    assert (gw - gwr).abs().max().item() <= 2e-2 * max(1.0, gwr.abs().max().item())
