@@ -48,8 +48,8 @@ SIGNATURES = {
                                          ctypes.c_int, vp, vp, vp, vp, vp]),
     "xq_res_ln_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, vp, vp, vp, vp, vp, vp, ctypes.c_int, vp, vp]),
-    "xq_gelu_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, vp, vp]),
-    "xq_gelu_backward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]),
+    "xq_gelu_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_gelu_backward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]),
     "xq_colsum": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "xq_lpips_level_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_lpips_level_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),

@@ -206,14 +206,43 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float *__res
     }
 }
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+// erf through Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, the size of erff's own fp32 rounding): one exp2 and one rcp,
+// no branches; the exponential e = exp(-x^2/2) is the same one the GELU derivative needs.  (libm erff costs ~40 VALU ops
+// and made the bf16 backward pass VALU-bound at 3.2 TB/s.)
+__device__ __forceinline__ void erf_cdf(float x, float &cdf, float &e) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    e = __builtin_amdgcn_exp2f(x * x * -0.72134752044448170368f);   // exp(-x^2/2)
+    float p = fmaf(t, 1.061405429f, -1.453152027f);
+    p = fmaf(t, p, 1.421413741f);
+    p = fmaf(t, p, -0.284496736f);
+    p = fmaf(t, p, 0.254829592f);
+    const float half_tail = 0.5f * t * p * e;                        // 0.5 * (1 - erf(|x|/sqrt2))
+    cdf = x >= 0.0f ? 1.0f - half_tail : half_tail;
+}
+template <bool TANH> __device__ __forceinline__ float gelu_val(float x) {
+    if (TANH) {   // F.gelu(approximate='tanh'): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u)
+        const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+        return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));
+    }
+    float cdf, e;
+    erf_cdf(x, cdf, e);
+    return x * cdf;
+}
+template <bool TANH> __device__ __forceinline__ float gelu_grad(float x) {
+    if (TANH) {
+        const float x2 = x * x;
+        const float u = 0.7978845608028654f * fmaf(0.044715f * x2, x, x);
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.8853900817779268f * u));   // 0.5 (1 + tanh u)
+        const float du = 0.7978845608028654f * fmaf(0.134145f, x2, 1.0f);
+        return fmaf(2.0f * x * sg * (1.0f - sg), du, sg);   // sg + x * (1 - tanh^2 u)/2 * du,  (1 - tanh^2)/2 = 2 sg (1 - sg)
+    }
+    float cdf, e;
+    erf_cdf(x, cdf, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
 }
 
-template <typename T>
+template <typename T, bool TANH>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ h, long n, T *__restrict__ out) {
     constexpr int VEC = 16 / sizeof(T);
     const long nv = n / VEC;
@@ -221,13 +250,13 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ h, 
         float v[VEC];
         load_vec<T, VEC>(h + i * VEC, v);
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) v[j] = gelu_exact(v[j]);
+        for (int j = 0; j < VEC; ++j) v[j] = gelu_val<TANH>(v[j]);
         store_vec<T, VEC>(out + i * VEC, v);
     }
 }
 
 // g_h = g_out * gelu'(h); column partial sums of g_h (fc1 bias gradient): partials[block][H]
-template <typename T>
+template <typename T, bool TANH>
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ h, long rows, int H,
                                                        T *__restrict__ g_h, float *__restrict__ partials) {
     constexpr int VEC = 16 / sizeof(T);
@@ -242,7 +271,7 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ g_o
             load_vec<T, VEC>(h + r * H + c0, x);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                o[j] = g[j] * gelu_grad(x[j]);
+                o[j] = g[j] * gelu_grad<TANH>(x[j]);
                 acc[j] += to_f<T>(from_f<T>(o[j]));
             }
             store_vec<T, VEC>(g_h + r * H + c0, o);
@@ -339,7 +368,7 @@ extern "C" int xq_res_ln_backward(const void *g_a, const float *g_xnew, const fl
     return xq_check_launch(fn);
 }
 
-extern "C" int xq_gelu_forward(const void *h, int64_t n, int act_bf16, void *out, xq_stream_t stream) {
+extern "C" int xq_gelu_forward(const void *h, int64_t n, int act_bf16, int approximate_tanh, void *out, xq_stream_t stream) {
     const char *fn = "xq_gelu_forward";
     if (n == 0) return XQ_OK;
     if (!h || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
@@ -349,13 +378,15 @@ extern "C" int xq_gelu_forward(const void *h, int64_t n, int act_bf16, void *out
     const long cap = (long)num_cus() * 16;
     if (blocks > cap) blocks = cap;
     hipStream_t s = (hipStream_t)stream;
-    if (act_bf16) hipLaunchKernelGGL((gelu_fwd_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16 *)h, (long)n, (bf16 *)out);
-    else hipLaunchKernelGGL((gelu_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)h, (long)n, (float *)out);
+#define GELU_FWD(T, TANH) hipLaunchKernelGGL((gelu_fwd_kernel<T, TANH>), dim3((unsigned)blocks), dim3(256), 0, s, (const T *)h, (long)n, (T *)out)
+    if (act_bf16) { if (approximate_tanh) GELU_FWD(bf16, true); else GELU_FWD(bf16, false); }
+    else { if (approximate_tanh) GELU_FWD(float, true); else GELU_FWD(float, false); }
+#undef GELU_FWD
     return xq_check_launch(fn);
 }
 
-extern "C" int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, int H, int act_bf16, void *g_h, float *g_bias,
-                                int accumulate, float *partials, xq_stream_t stream) {
+extern "C" int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, int H, int act_bf16, int approximate_tanh, void *g_h,
+                                float *g_bias, int accumulate, float *partials, xq_stream_t stream) {
     const char *fn = "xq_gelu_backward";
     if (rows == 0) return XQ_OK;
     if (!g_out || !h || !g_h) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
@@ -364,8 +395,11 @@ extern "C" int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, 
     if (g_bias && !partials) return xq_set_error(XQ_EINVAL, "%s: partials workspace required for the bias gradient", fn);
     const int blocks = row_blocks(rows * 4);
     hipStream_t s = (hipStream_t)stream;
-    if (act_bf16) hipLaunchKernelGGL((gelu_bwd_kernel<bf16>), dim3(blocks), dim3(256), 0, s, (const bf16 *)g_out, (const bf16 *)h, (long)rows, H, (bf16 *)g_h, g_bias ? partials : nullptr);
-    else hipLaunchKernelGGL((gelu_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)g_out, (const float *)h, (long)rows, H, (float *)g_h, g_bias ? partials : nullptr);
+#define GELU_BWD(T, TANH) hipLaunchKernelGGL((gelu_bwd_kernel<T, TANH>), dim3(blocks), dim3(256), 0, s, (const T *)g_out, (const T *)h, (long)rows, H, \
+                                             (T *)g_h, g_bias ? partials : nullptr)
+    if (act_bf16) { if (approximate_tanh) GELU_BWD(bf16, true); else GELU_BWD(bf16, false); }
+    else { if (approximate_tanh) GELU_BWD(float, true); else GELU_BWD(float, false); }
+#undef GELU_BWD
     if (g_bias)
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + 63) / 64), dim3(256), 0, s, partials, blocks, 1, H, g_bias, nullptr, nullptr, nullptr, accumulate);
     return xq_check_launch(fn);

@@ -129,17 +129,19 @@ class ResLNFn(torch.autograd.Function):
 
 
 class GeluFn(torch.autograd.Function):
-    """hg = GELU(h) (exact erf form, nn.GELU()); `bias` = fc1.bias, present only to receive its gradient."""
+    """hg = GELU(h): exact erf form (nn.GELU()) or the tanh approximation (F.gelu(approximate='tanh'));
+    `bias` = fc1.bias, present only to receive its gradient."""
 
     @staticmethod
-    def forward(ctx, h, bias):
+    def forward(ctx, h, bias, tanh=False):
         hc = h.detach().contiguous()
         out = torch.empty_like(hc)
         with torch.cuda.device(h.device):
-            rc = _lib.lib().xq_gelu_forward(ptr(hc), hc.numel(), _act_flag(hc.dtype), ptr(out), _stream(h))
+            rc = _lib.lib().xq_gelu_forward(ptr(hc), hc.numel(), _act_flag(hc.dtype), int(tanh), ptr(out), _stream(h))
         check(rc, "xq_gelu_forward")
         ctx.save_for_backward(hc)
-        ctx.has_bias = bias is not None
+        ctx.has_bias = bias is not None and bias.requires_grad
+        ctx.tanh = bool(tanh)
         return out
 
     @staticmethod
@@ -153,10 +155,10 @@ class GeluFn(torch.autograd.Function):
         nb = _lib.lib().xq_row_partials_blocks(rows * 4)
         part = torch.empty(nb * H, dtype=torch.float32, device=hc.device) if ctx.has_bias else None
         with torch.cuda.device(hc.device):
-            rc = _lib.lib().xq_gelu_backward(ptr(g), ptr(hc), rows, H, _act_flag(hc.dtype), ptr(g_h), ptr(g_b), 0, ptr(part),
-                                             _stream(hc))
+            rc = _lib.lib().xq_gelu_backward(ptr(g), ptr(hc), rows, H, _act_flag(hc.dtype), int(ctx.tanh), ptr(g_h), ptr(g_b), 0,
+                                             ptr(part), _stream(hc))
         check(rc, "xq_gelu_backward")
-        return g_h, g_b
+        return g_h, g_b, None
 
 
 def _w16(weight):
@@ -222,10 +224,10 @@ class LinearFn(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        g_x = torch.mm(g2, W).view(shp)
-        g_w = _weight_grad(g2, x2, wdtype)
+        g_x = torch.mm(g2, W).view(shp) if ctx.needs_input_grad[0] else None
+        g_w = _weight_grad(g2, x2, wdtype) if ctx.needs_input_grad[1] else None
         g_b = None
-        if want_bias:
+        if want_bias and ctx.needs_input_grad[2]:
             H = g2.shape[1]
             g_b = torch.empty(H, dtype=torch.float32, device=g2.device)
             nb = _lib.lib().xq_row_partials_blocks(g2.shape[0] * 4)
@@ -291,30 +293,38 @@ def fused_supported(x, blocks):
     return x.is_cuda and D in SUPPORTED_D and len(blocks) > 0
 
 
-def run_blocks(blocks, x, final_norm, act_dtype):
+def run_blocks(blocks, x, final_norm, act_dtype, taps=None):
     """x: (B, N, D) tokens entering block 0 -> final_norm(blocks(x)) in act_dtype, via the fused kernels.
-    The DropPath masks are drawn in the reference's order (drop_path1 then drop_path2 of each block)."""
+    The DropPath masks are drawn in the reference's order (drop_path1 then drop_path2 of each block).
+    Blocks are timm-style pre-LN blocks (norm1, attn.qkv/proj/num_heads, norm2, mlp.fc1/fc2) with optional ls1/ls2
+    (LayerScale), drop_path1/2 (DropPath) and `mlp.gelu_tanh` (tanh-approximate GELU).
+    taps: block indices whose output residual stream (fp32) is wanted -> returns (a, {index: x})."""
     from .dino_enc.vision_transformer import DropPath, LayerScale
     x = x.contiguous()
     b0 = blocks[0]
     a = LayerNormFn.apply(x, b0.norm1.weight, b0.norm1.bias, b0.norm1.eps, act_dtype)
     n = len(blocks)
+    tapped = {}
     for i, blk in enumerate(blocks):
         at = blk.attn
+        ls1, ls2 = getattr(blk, "ls1", None), getattr(blk, "ls2", None)
+        dp1, dp2 = getattr(blk, "drop_path1", None), getattr(blk, "drop_path2", None)
         qkv = LinearFn.apply(a, at.qkv.weight, at.qkv.bias, False)
         o = attention_qkvpacked(qkv, at.num_heads)
         p = LinearFn.apply(o, at.proj.weight, at.proj.bias, True)
-        g1 = blk.ls1.gamma if isinstance(blk.ls1, LayerScale) else None
-        m1 = blk.drop_path1.keep_mask(p) if isinstance(blk.drop_path1, DropPath) else None
+        g1 = ls1.gamma if isinstance(ls1, LayerScale) else None
+        m1 = dp1.keep_mask(p) if isinstance(dp1, DropPath) else None
         x, a = ResLNFn.apply(x, p, g1, m1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, at.proj.bias)
         h = LinearFn.apply(a, blk.mlp.fc1.weight, blk.mlp.fc1.bias, True)
-        hg = GeluFn.apply(h, blk.mlp.fc1.bias)
+        hg = GeluFn.apply(h, blk.mlp.fc1.bias, bool(getattr(blk.mlp, "gelu_tanh", False)))
         f = LinearFn.apply(hg, blk.mlp.fc2.weight, blk.mlp.fc2.bias, True)
-        g2 = blk.ls2.gamma if isinstance(blk.ls2, LayerScale) else None
-        m2 = blk.drop_path2.keep_mask(f) if isinstance(blk.drop_path2, DropPath) else None
+        g2 = ls2.gamma if isinstance(ls2, LayerScale) else None
+        m2 = dp2.keep_mask(f) if isinstance(dp2, DropPath) else None
         nxt = blocks[i + 1].norm1 if i + 1 < n else final_norm
         x, a = ResLNFn.apply(x, f, g2, m2, nxt.weight, nxt.bias, nxt.eps, blk.mlp.fc2.bias)
-    return a
+        if taps is not None and i in taps:
+            tapped[i] = x
+    return a if taps is None else (a, tapped)
 
 
 class LpipsLevelFn(torch.autograd.Function):

@@ -231,10 +231,12 @@ class _SABlock(nn.Module):
         self.attn.qkv = nn.Linear(dim, dim * 3, bias=True)
         self.attn.proj = nn.Linear(dim, dim, bias=True)
         self.heads = heads
+        self.attn.num_heads = heads     # attribute names of the fused block runner (ops_dense.run_blocks)
         self.norm2 = nn.LayerNorm(dim, eps=eps)
         self.mlp = nn.Module()
         self.mlp.fc1 = nn.Linear(dim, round(dim * mlp_ratio))
         self.mlp.fc2 = nn.Linear(round(dim * mlp_ratio), dim)
+        self.mlp.gelu_tanh = True
 
     def forward(self, x):
         B, L, C = x.shape
@@ -282,6 +284,16 @@ class FrozenDINOSmallNoDrop(nn.Module):
         with torch.autocast(device_type=x.device.type, enabled=False):
             x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x.float()), dim=1) + self.pos_embed
             acts = [(x[:, 1:] + x[:, :1]).transpose(1, 2)]
+        if x.is_cuda and nn_ops.FUSED_BLOCKS:
+            from . import ops_dense
+            blocks = list(self.blocks)
+            if ops_dense.fused_supported(x, blocks):  # fused row kernels + attention kernels, as the tokenizer's ViT blocks
+                act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+                _, tapped = ops_dense.run_blocks(blocks, x, self.norm, act, taps=self.key_depths)
+                for i in sorted(tapped):
+                    t = tapped[i]
+                    acts.append((t[:, 1:] + t[:, :1]).transpose(1, 2))
+                return acts
         for i, b in enumerate(self.blocks):
             x = b(x)
             if i in self.key_depths:

@@ -175,12 +175,14 @@ int xq_res_ln_backward(const void *g_a, const float *g_xnew, const float *x_new,
                        int rows_per_sample, int act_bf16, float *g_x, void *g_y, float *g_lnw, float *g_lnb,
                        float *g_gamma, float *g_ybias, int accumulate, float *partials, xq_stream_t stream);
 
-/* exact (erf) GELU, nn.GELU() of timm's Mlp; n elements (multiple of the 16-byte vector) */
-int xq_gelu_forward(const void *h, int64_t n, int act_bf16, void *out, xq_stream_t stream);
+/* GELU: approximate_tanh = 0: exact erf form, nn.GELU() of timm's Mlp (vision_transformer.py Mlp.act);
+ * approximate_tanh = 1: F.gelu(approximate='tanh') of the discriminator's frozen DINO blocks (discriminator_dino.py:37-112).
+ * n elements (multiple of the 16-byte vector) */
+int xq_gelu_forward(const void *h, int64_t n, int act_bf16, int approximate_tanh, void *out, xq_stream_t stream);
 /* g_h = g_out * gelu'(h); g_bias (nullable) [H] = column sums of g_h (the fc1 bias gradient);
  * partials: xq_row_partials_blocks(rows*4)*H floats */
-int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, int H, int act_bf16, void *g_h, float *g_bias,
-                     int accumulate, float *partials, xq_stream_t stream);
+int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, int H, int act_bf16, int approximate_tanh, void *g_h,
+                     float *g_bias, int accumulate, float *partials, xq_stream_t stream);
 /* out[H] (+)= column sums of g [rows][H] (bias gradient of a Linear); partials as above */
 int xq_colsum(const void *g, int64_t rows, int H, int act_bf16, float *out, int accumulate, float *partials,
               xq_stream_t stream);

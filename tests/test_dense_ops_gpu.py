@@ -273,3 +273,53 @@ def test_conv3x3_small_cin_data_grad():
     assert (y.float() - torch.relu(yr)).abs().max().item() <= 3e-2
     assert (gx - gxr).abs().max().item() <= 2e-2 * max(1.0, gxr.abs().max().item())
     assert (gw - gwr).abs().max().item() <= 2e-2 * max(1.0, gwr.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_gelu_tanh(dt):
+    from imagefolder_amd.ops_dense import GeluFn
+    torch.manual_seed(5)
+    h = (torch.randn(3, 17, 1536, device="cuda") * 2.5).to(dt).requires_grad_(True)
+    out = GeluFn.apply(h, None, True)
+    g = torch.randn_like(out)
+    out.backward(g)
+    href = h.detach().float().requires_grad_(True)
+    oref = F.gelu(href, approximate='tanh')
+    oref.backward(g.float())
+    tol = 2e-6 if dt == torch.float32 else 2e-2
+    assert (out.float() - oref).abs().max() <= tol * 4
+    assert (h.grad.float() - href.grad).abs().max() <= tol * 8
+
+
+@pytest.mark.gpu
+def test_frozen_dino_trunk_fused_matches_per_op():
+    """the discriminator's frozen ViT-S trunk on the fused block runner vs its per-op ATen form (bf16 autocast)"""
+    from imagefolder_amd import nn_ops
+    from imagefolder_amd.vq_loss import FrozenDINOSmallNoDrop
+    torch.manual_seed(9)
+    dev = "cuda"
+    net = FrozenDINOSmallNoDrop(depth=4, key_depths=(1, 3)).to(dev)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * 0.05)
+    x0 = torch.rand(3, 3, 224, 224, device=dev) * 2 - 1
+    outs = {}
+    for fused in (True, False):
+        nn_ops.FUSED_BLOCKS = fused
+        try:
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                acts = net(x)
+            loss = sum((a.float() ** 2).mean() for a in acts)
+            (gx,) = torch.autograd.grad(loss, x)
+            outs[fused] = ([a.float() for a in acts], gx)
+        finally:
+            nn_ops.FUSED_BLOCKS = True
+    assert len(outs[True][0]) == len(outs[False][0]) == 3
+    for a, r in zip(outs[True][0], outs[False][0]):
+        assert a.shape == r.shape
+        assert (a - r).abs().max().item() <= 3e-2 * max(1.0, r.abs().max().item())
+    ga, gr = outs[True][1], outs[False][1]
+    assert ((ga - gr).norm() / gr.norm()).item() <= 5e-2
