@@ -59,8 +59,15 @@ SIGNATURES = {
     "xq_attn_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
     "xq_attn_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         vp, vp, vp]),
+    "xq_bnlocal_lrelu_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]),
+    "xq_bnlocal_lrelu_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                 ctypes.c_float, ctypes.c_float, ctypes.c_int, vp, vp, vp, vp, vp]),
+    "xq_unfold1d_circular": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_fold1d_circular": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "xq_prof_marker": (ctypes.c_int, [ctypes.c_int, vp]),
 }
 
 _lib = None
@@ -101,3 +108,20 @@ def ptr(t):
 def current_stream_handle(device=None):
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+MARKERS = os.environ.get("XQ_MARKERS", "0") == "1"
+
+
+def marker(section_id: int):
+    """section boundary for kernel traces (no-op unless XQ_MARKERS=1)"""
+    if MARKERS:
+        import torch
+        if torch.cuda.is_available():
+            lib().xq_prof_marker(int(section_id), current_stream_handle())
+
+
+def marker_on_grad(t, section_id: int):
+    """emit the marker when the backward pass reaches tensor t"""
+    if MARKERS and t is not None and getattr(t, "requires_grad", False):
+        t.register_hook(lambda g: marker(section_id))

@@ -18,35 +18,9 @@
 #include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
 
-#include <hip/hip_bf16.h>
+#include "xq_vec.hpp"
 
 using namespace xq;
-
-typedef __hip_bfloat16 bf16;
-
-template <typename T> __device__ __forceinline__ float to_f(T v);
-template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
-template <> __device__ __forceinline__ float to_f<bf16>(bf16 v) { return __bfloat162float(v); }
-template <typename T> __device__ __forceinline__ T from_f(float v);
-template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
-template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return __float2bfloat16(v); }
-
-// vector of VEC elements of T, loaded/stored in one instruction
-template <typename T, int VEC> struct Pack { T v[VEC]; };
-
-template <typename T, int VEC>
-__device__ __forceinline__ void load_vec(const T *p, float (&out)[VEC]) {
-    const Pack<T, VEC> pk = *reinterpret_cast<const Pack<T, VEC> *>(p);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) out[j] = to_f<T>(pk.v[j]);
-}
-template <typename T, int VEC>
-__device__ __forceinline__ void store_vec(T *p, const float (&in)[VEC]) {
-    Pack<T, VEC> pk;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) pk.v[j] = from_f<T>(in[j]);
-    *reinterpret_cast<Pack<T, VEC> *>(p) = pk;
-}
 
 static constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows in flight per block
 static constexpr int MAX_ROW_BLOCKS = 512;   // also the number of partial rows the finalize kernel reduces

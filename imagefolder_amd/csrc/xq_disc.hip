@@ -1,0 +1,290 @@
+// xq_disc.hip — fused kernels of the DinoDisc discriminator heads (gfx950), token-major activations [B][L][C].
+//
+// Replaces, per head block of the reference (tokenizer/tokenizer_image/discriminator_dino.py:127-154 BatchNormLocal,
+// :157-166 make_block = SpectralConv1d -> BatchNormLocal -> LeakyReLU(0.2), :113-119 ResidualBlock), the ~12 unfused fp32
+// ATen passes per block forward (float(), mean, var, sub, add, sqrt, div, mul, add, leaky_relu, add, mul) and their ~30
+// autograd passes backward, plus F.pad(circular) + unfold / the generic unfold backward of the kernel-9 conv:
+//   bnlocal_lrelu_fwd : per virtual batch g (8 samples) and channel c: mean/var over the 8*L tokens (fp32, two-pass),
+//                       out = [ (lrelu((y - mean) * rstd * w + b) + skip) * ratio ]   (skip/ratio: the ResidualBlock)
+//   bnlocal_lrelu_bwd : the transpose: g_y, g_skip, per-group partial sums of g_w / g_b
+//   unfold1d_circular : cols[b, l, tap, :] = h[b, (l + tap - K/2) mod L, :]   (the im2col of the circular conv, so that the
+//                       conv itself is one library GEMM with the taps in the reduction)
+//   fold1d_circular   : dh[b, l, :] = sum_tap dcols[b, (l - tap + K/2) mod L, tap, :]
+// One block owns (group g) x (64 channels): its 8*L x 64 slab (200 KB bf16) stays in L2 across the passes.
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "../../include/xq_ops.h"
+
+#include "xq_vec.hpp"
+
+using namespace xq;
+
+static constexpr int BN_CH = 64;   // channels per block
+
+// column sums over the block's rows: thread (rt, ct) owns VEC columns, rows rt, rt+RPP, ...; reduce over rt through LDS
+template <int VEC, int TPR, int RPP>
+__device__ __forceinline__ void block_colsum(float (&acc)[VEC], float *lds /* [RPP][BN_CH] */, float *out /* [BN_CH] in LDS */) {
+    const int ct = threadIdx.x % TPR, rt = threadIdx.x / TPR;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) lds[rt * BN_CH + ct * VEC + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < BN_CH) {
+        float s = 0.0f;
+        for (int r = 0; r < RPP; ++r) s += lds[r * BN_CH + threadIdx.x];
+        out[threadIdx.x] = s;
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bnlocal_lrelu_fwd_kernel(const T *__restrict__ y, const float *__restrict__ w, const float *__restrict__ b,
+                                                                const T *__restrict__ skip, int R, int C, float eps, float slope, float ratio,
+                                                                T *__restrict__ out, float *__restrict__ mean_out, float *__restrict__ rstd_out) {
+    constexpr int VEC = 16 / sizeof(T), TPR = BN_CH / VEC, RPP = 256 / TPR;
+    __shared__ float red[RPP * BN_CH];
+    __shared__ float stat[2][BN_CH];
+    const int g = blockIdx.y, c0 = blockIdx.x * BN_CH;
+    const int ct = threadIdx.x % TPR, rt = threadIdx.x / TPR;
+    const T *yb = y + (long)g * R * C + c0 + ct * VEC;
+    float acc[VEC], v[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+    for (int r = rt; r < R; r += RPP) {
+        load_vec<T, VEC>(yb + (long)r * C, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+    }
+    block_colsum<VEC, TPR, RPP>(acc, red, stat[0]);
+    float mu[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { mu[j] = stat[0][ct * VEC + j] / (float)R; acc[j] = 0.0f; }
+    for (int r = rt; r < R; r += RPP) {
+        load_vec<T, VEC>(yb + (long)r * C, v);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { const float d = v[j] - mu[j]; acc[j] = fmaf(d, d, acc[j]); }
+    }
+    block_colsum<VEC, TPR, RPP>(acc, red, stat[1]);
+    float rs[VEC], ww[VEC], bb[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        rs[j] = 1.0f / sqrtf(stat[1][ct * VEC + j] / (float)R + eps);
+        ww[j] = w ? w[c0 + ct * VEC + j] : 1.0f;
+        bb[j] = b ? b[c0 + ct * VEC + j] : 0.0f;
+    }
+    if (rt == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            mean_out[(long)g * C + c0 + ct * VEC + j] = mu[j];
+            rstd_out[(long)g * C + c0 + ct * VEC + j] = rs[j];
+        }
+    }
+    T *ob = out + (long)g * R * C + c0 + ct * VEC;
+    const T *sb = skip ? skip + (long)g * R * C + c0 + ct * VEC : nullptr;
+    for (int r = rt; r < R; r += RPP) {
+        float o[VEC], sk[VEC];
+        load_vec<T, VEC>(yb + (long)r * C, v);
+        if (sb) load_vec<T, VEC>(sb + (long)r * C, sk);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float pre = fmaf((v[j] - mu[j]) * rs[j], ww[j], bb[j]);
+            const float a = pre > 0.0f ? pre : pre * slope;
+            o[j] = sb ? (a + sk[j]) * ratio : a;
+        }
+        store_vec<T, VEC>(ob + (long)r * C, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bnlocal_lrelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ y, const float *__restrict__ w,
+                                                                const float *__restrict__ b, const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd, int R, int C, float slope, float ratio,
+                                                                int has_skip, T *__restrict__ g_y, T *__restrict__ g_skip,
+                                                                float *__restrict__ gw_part, float *__restrict__ gb_part) {
+    constexpr int VEC = 16 / sizeof(T), TPR = BN_CH / VEC, RPP = 256 / TPR;
+    __shared__ float red[RPP * BN_CH];
+    __shared__ float stat[2][BN_CH];
+    const int g = blockIdx.y, c0 = blockIdx.x * BN_CH;
+    const int ct = threadIdx.x % TPR, rt = threadIdx.x / TPR;
+    const long off = (long)g * R * C + c0 + ct * VEC;
+    const float scale = has_skip ? ratio : 1.0f;
+    float mu[VEC], rs[VEC], ww[VEC], bb[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = c0 + ct * VEC + j;
+        mu[j] = mean[(long)g * C + c];
+        rs[j] = rstd[(long)g * C + c];
+        ww[j] = w ? w[c] : 1.0f;
+        bb[j] = b ? b[c] : 0.0f;
+        s1[j] = 0.0f;
+        s2[j] = 0.0f;
+    }
+    for (int r = rt; r < R; r += RPP) {
+        float v[VEC], go[VEC];
+        load_vec<T, VEC>(y + off + (long)r * C, v);
+        load_vec<T, VEC>(g_out + off + (long)r * C, go);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float z = (v[j] - mu[j]) * rs[j];
+            const float pre = fmaf(z, ww[j], bb[j]);
+            const float gp = go[j] * scale * (pre > 0.0f ? 1.0f : slope);
+            s1[j] += gp;
+            s2[j] = fmaf(gp, z, s2[j]);
+        }
+    }
+    block_colsum<VEC, TPR, RPP>(s1, red, stat[0]);
+    block_colsum<VEC, TPR, RPP>(s2, red, stat[1]);
+    float m1[VEC], m2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        m1[j] = stat[0][ct * VEC + j] / (float)R;
+        m2[j] = stat[1][ct * VEC + j] / (float)R;
+    }
+    if (rt == 0) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            gb_part[(long)g * C + c0 + ct * VEC + j] = stat[0][ct * VEC + j];
+            gw_part[(long)g * C + c0 + ct * VEC + j] = stat[1][ct * VEC + j];
+        }
+    }
+    for (int r = rt; r < R; r += RPP) {
+        float v[VEC], go[VEC], gy[VEC], gs[VEC];
+        load_vec<T, VEC>(y + off + (long)r * C, v);
+        load_vec<T, VEC>(g_out + off + (long)r * C, go);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float z = (v[j] - mu[j]) * rs[j];
+            const float pre = fmaf(z, ww[j], bb[j]);
+            const float gp = go[j] * scale * (pre > 0.0f ? 1.0f : slope);
+            gy[j] = rs[j] * ww[j] * (gp - m1[j] - z * m2[j]);
+            gs[j] = go[j] * scale;
+        }
+        store_vec<T, VEC>(g_y + off + (long)r * C, gy);
+        if (has_skip) store_vec<T, VEC>(g_skip + off + (long)r * C, gs);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void unfold1d_kernel(const T *__restrict__ h, int B, int L, int C, int K, T *__restrict__ cols) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cv = C / VEC;
+    const long total = (long)B * L * K * cv;
+    const int pad = K / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        long t = i / cv;
+        const int tap = (int)(t % K);
+        t /= K;
+        const int l = (int)(t % L);
+        const long bb = t / L;
+        int ls = l + tap - pad;
+        ls = ls < 0 ? ls + L : (ls >= L ? ls - L : ls);
+        const Pack<T, VEC> v = *reinterpret_cast<const Pack<T, VEC> *>(h + ((bb * L + ls) * C + (long)c * VEC));
+        *reinterpret_cast<Pack<T, VEC> *>(cols + i * VEC) = v;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fold1d_kernel(const T *__restrict__ dcols, int B, int L, int C, int K, T *__restrict__ dh) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cv = C / VEC;
+    const long total = (long)B * L * cv;
+    const int pad = K / 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        long t = i / cv;
+        const int l = (int)(t % L);
+        const long bb = t / L;
+        float acc[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
+        for (int tap = 0; tap < K; ++tap) {
+            int ls = l - tap + pad;
+            ls = ls < 0 ? ls + L : (ls >= L ? ls - L : ls);
+            float v[VEC];
+            load_vec<T, VEC>(dcols + (((bb * L + ls) * K + tap) * C + (long)c * VEC), v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+        }
+        store_vec<T, VEC>(dh + i * VEC, acc);
+    }
+}
+
+static int bn_check(const char *fn, int G, int R, int C) {
+    if (G < 0 || R < 1 || C < 1 || C % BN_CH != 0)
+        return xq_set_error(XQ_EINVAL, "%s: needs rows_per_group >= 1 and C %% 64 == 0 (got %ld, %ld)", fn, (long)R, (long)C);
+    return XQ_OK;
+}
+
+extern "C" int xq_bnlocal_lrelu_forward(const void *y, const float *w, const float *b, const void *skip, int G, int rows_per_group, int C,
+                                        int act_bf16, float eps, float slope, float ratio, void *out, float *mean, float *rstd,
+                                        xq_stream_t stream) {
+    const char *fn = "xq_bnlocal_lrelu_forward";
+    if (int rc = bn_check(fn, G, rows_per_group, C)) return rc;
+    if (G == 0) return XQ_OK;
+    if (!y || !out || !mean || !rstd) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const dim3 grid(C / BN_CH, G);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16)
+        hipLaunchKernelGGL((bnlocal_lrelu_fwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16 *)y, w, b, (const bf16 *)skip, rows_per_group, C, eps,
+                           slope, ratio, (bf16 *)out, mean, rstd);
+    else
+        hipLaunchKernelGGL((bnlocal_lrelu_fwd_kernel<float>), grid, dim3(256), 0, s, (const float *)y, w, b, (const float *)skip, rows_per_group, C,
+                           eps, slope, ratio, (float *)out, mean, rstd);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_bnlocal_lrelu_backward(const void *g_out, const void *y, const float *w, const float *b, const float *mean, const float *rstd,
+                                         int G, int rows_per_group, int C, int act_bf16, float slope, float ratio, int has_skip, void *g_y,
+                                         void *g_skip, float *gw_part, float *gb_part, xq_stream_t stream) {
+    const char *fn = "xq_bnlocal_lrelu_backward";
+    if (int rc = bn_check(fn, G, rows_per_group, C)) return rc;
+    if (G == 0) return XQ_OK;
+    if (!g_out || !y || !mean || !rstd || !g_y || !gw_part || !gb_part || (has_skip && !g_skip))
+        return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const dim3 grid(C / BN_CH, G);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16)
+        hipLaunchKernelGGL((bnlocal_lrelu_bwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16 *)g_out, (const bf16 *)y, w, b, mean, rstd,
+                           rows_per_group, C, slope, ratio, has_skip, (bf16 *)g_y, (bf16 *)g_skip, gw_part, gb_part);
+    else
+        hipLaunchKernelGGL((bnlocal_lrelu_bwd_kernel<float>), grid, dim3(256), 0, s, (const float *)g_out, (const float *)y, w, b, mean, rstd,
+                           rows_per_group, C, slope, ratio, has_skip, (float *)g_y, (float *)g_skip, gw_part, gb_part);
+    return xq_check_launch(fn);
+}
+
+static int fold_check(const char *fn, int B, int L, int C, int K, int act_bf16) {
+    const int vec = act_bf16 ? 8 : 4;
+    if (B < 0 || L < 1 || K < 1 || K > L || C < 1 || C % vec != 0)
+        return xq_set_error(XQ_EINVAL, "%s: needs 1 <= K <= L and C a multiple of the 16-byte vector (K=%ld, C=%ld)", fn, (long)K, (long)C);
+    return XQ_OK;
+}
+
+extern "C" int xq_unfold1d_circular(const void *h, int B, int L, int C, int K, int act_bf16, void *cols, xq_stream_t stream) {
+    const char *fn = "xq_unfold1d_circular";
+    if (int rc = fold_check(fn, B, L, C, K, act_bf16)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!h || !cols) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * L * K * (C / (act_bf16 ? 8 : 4));
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) hipLaunchKernelGGL((unfold1d_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16 *)h, B, L, C, K, (bf16 *)cols);
+    else hipLaunchKernelGGL((unfold1d_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)h, B, L, C, K, (float *)cols);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K, int act_bf16, void *dh, xq_stream_t stream) {
+    const char *fn = "xq_fold1d_circular";
+    if (int rc = fold_check(fn, B, L, C, K, act_bf16)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!dcols || !dh) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * L * (C / (act_bf16 ? 8 : 4));
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) hipLaunchKernelGGL((fold1d_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, s, (const bf16 *)dcols, B, L, C, K, (bf16 *)dh);
+    else hipLaunchKernelGGL((fold1d_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)dcols, B, L, C, K, (float *)dh);
+    return xq_check_launch(fn);
+}

@@ -73,6 +73,13 @@ extern "C" int xq_prof_collect(double *assign_ms_total, int *assign_launches) {
     g_prof_n = 0;
     return XQ_OK;
 }
+// section markers for kernel traces: an empty kernel whose grid size is the section id (tools/rocpd_sections.py)
+__global__ void xq_marker_kernel() {}
+extern "C" int xq_prof_marker(int id, xq_stream_t stream) {
+    if (id < 1) return xq_set_error(XQ_EINVAL, "%s: id must be >= 1", "xq_prof_marker");
+    hipLaunchKernelGGL(xq_marker_kernel, dim3((unsigned)id), dim3(64), 0, (hipStream_t)stream);
+    return xq_check_launch("xq_prof_marker");
+}
 static inline int prof_slot() {
     if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
     if (g_prof_n >= g_prof_created) {

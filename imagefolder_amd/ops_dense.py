@@ -227,7 +227,9 @@ class LinearFn(torch.autograd.Function):
         g_x = torch.mm(g2, W).view(shp) if ctx.needs_input_grad[0] else None
         g_w = _weight_grad(g2, x2, wdtype) if ctx.needs_input_grad[1] else None
         g_b = None
-        if want_bias and ctx.needs_input_grad[2]:
+        if want_bias and ctx.needs_input_grad[2] and g2.shape[1] % (8 if g2.dtype == torch.bfloat16 else 4):
+            g_b = g2.float().sum(0)   # narrow outputs (e.g. the 1-channel logit conv): below the kernel's 16-byte vector
+        elif want_bias and ctx.needs_input_grad[2]:
             H = g2.shape[1]
             g_b = torch.empty(H, dtype=torch.float32, device=g2.device)
             nb = _lib.lib().xq_row_partials_blocks(g2.shape[0] * 4)
@@ -466,3 +468,105 @@ class Conv3x3SmallCinFn(torch.autograd.Function):
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g_b = g.float().sum((0, 2, 3))
         return g_x, g_w, g_b, None
+
+
+# ---- DinoDisc heads (csrc/xq_disc.hip) ------------------------------------------------------------------------------------
+class BNLocalLReLUFn(torch.autograd.Function):
+    """out = LeakyReLU(BatchNormLocal(y)) [+ skip, * ratio] on token-major y (B, L, C): statistics per virtual batch of
+    `virtual_bs` samples and channel over its virtual_bs * L tokens (discriminator_dino.py:127-154, :113-119, :157-166)."""
+
+    @staticmethod
+    def forward(ctx, y, weight, bias, skip, virtual_bs, eps, slope, ratio):
+        B, L, C = y.shape
+        G = -(-B // virtual_bs)
+        if B % G:
+            raise XqError(f"BatchNormLocal: batch {B} does not split into {G} equal virtual batches")
+        yc = y.detach().contiguous()
+        sk = None if skip is None else skip.detach().to(yc.dtype).contiguous()
+        w = None if weight is None else weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        out = torch.empty_like(yc)
+        mean = torch.empty(G, C, dtype=torch.float32, device=yc.device)
+        rstd = torch.empty_like(mean)
+        R = (B // G) * L
+        with torch.cuda.device(yc.device):
+            rc = _lib.lib().xq_bnlocal_lrelu_forward(ptr(yc), ptr(w), ptr(b), ptr(sk), G, R, C, _act_flag(yc.dtype), float(eps), float(slope),
+                                                     float(ratio), ptr(out), ptr(mean), ptr(rstd), _stream(yc))
+        check(rc, "xq_bnlocal_lrelu_forward")
+        ctx.save_for_backward(yc, w, b, mean, rstd)
+        ctx.cfg = (G, R, C, float(slope), float(ratio), skip is not None, weight is not None, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        yc, w, b, mean, rstd = ctx.saved_tensors
+        G, R, C, slope, ratio, has_skip, has_w, has_b = ctx.cfg
+        g = g.detach().to(yc.dtype).contiguous()
+        g_y = torch.empty_like(yc)
+        g_skip = torch.empty_like(yc) if has_skip else None
+        gw = torch.empty(G, C, dtype=torch.float32, device=yc.device)
+        gb = torch.empty_like(gw)
+        with torch.cuda.device(yc.device):
+            rc = _lib.lib().xq_bnlocal_lrelu_backward(ptr(g), ptr(yc), ptr(w), ptr(b), ptr(mean), ptr(rstd), G, R, C, _act_flag(yc.dtype),
+                                                      slope, ratio, int(has_skip), ptr(g_y), ptr(g_skip), ptr(gw), ptr(gb), _stream(yc))
+        check(rc, "xq_bnlocal_lrelu_backward")
+        return (g_y, gw.sum(0) if has_w else None, gb.sum(0) if has_b else None, g_skip, None, None, None, None)
+
+
+class Unfold1dCircularFn(torch.autograd.Function):
+    """(B, L, C) -> (B, L, K*C): the K circularly shifted copies a kernel-K circular Conv1d reduces over, tap-major."""
+
+    @staticmethod
+    def forward(ctx, h, K):
+        B, L, C = h.shape
+        hc = h.detach().contiguous()
+        cols = torch.empty(B, L, K * C, dtype=hc.dtype, device=hc.device)
+        with torch.cuda.device(hc.device):
+            rc = _lib.lib().xq_unfold1d_circular(ptr(hc), B, L, C, K, _act_flag(hc.dtype), ptr(cols), _stream(hc))
+        check(rc, "xq_unfold1d_circular")
+        ctx.K = K
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        B, L, KC = g.shape
+        K = ctx.K
+        g = g.detach().contiguous()
+        dh = torch.empty(B, L, KC // K, dtype=g.dtype, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().xq_fold1d_circular(ptr(g), B, L, KC // K, K, _act_flag(g.dtype), ptr(dh), _stream(g))
+        check(rc, "xq_fold1d_circular")
+        return dh, None
+
+
+def disc_head_supported(a, head):
+    conv9 = head[1].fn[0]
+    return a.is_cuda and a.shape[1] % 64 == 0 and conv9.padding_mode == 'circular' and conv9.kernel_size[0] <= a.shape[2]
+
+
+def disc_head(head, a):
+    """One DinoDisc head (discriminator_dino.py:209-216: make_block(ks=1) -> ResidualBlock(make_block(ks=9)) -> SpectralConv1d(C, 1))
+    on a = (B, C, L) activations, evaluated token-major with the fused kernels; returns the (B, L) logits."""
+    blk1, res, last = head[0], head[1], head[2]
+    conv1, bn1 = blk1[0], blk1[1]
+    conv9, bn9 = res.fn[0], res.fn[1]
+    act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+    B, C, L = a.shape
+    x0 = a.transpose(1, 2).to(act).contiguous()                        # (B, L, C) token-major
+    K = conv9.kernel_size[0]
+    y1 = LinearFn.apply(x0, conv1._normalised_weight()[:, :, 0], conv1.bias, False)
+    h1 = BNLocalLReLUFn.apply(y1, getattr(bn1, "weight", None), getattr(bn1, "bias", None), None, bn1.virtual_bs, bn1.eps,
+                              blk1[2].negative_slope, 1.0)
+    cols = Unfold1dCircularFn.apply(h1, K)
+    W9 = conv9._normalised_weight().permute(0, 2, 1).reshape(conv9.out_channels, K * C)   # [Cout][tap][Cin], as the cols
+    y2 = LinearFn.apply(cols, W9, conv9.bias, False)
+    h2 = BNLocalLReLUFn.apply(y2, getattr(bn9, "weight", None), getattr(bn9, "bias", None), h1, bn9.virtual_bs, bn9.eps,
+                              res.fn[2].negative_slope, float(res.ratio))
+    # the 1-channel logit conv is a matrix-vector product: fp32 gemv outside autocast (a bf16 GEMM with N = 1 takes
+    # milliseconds on this stack, the same pathology as the spectral-norm power iteration)
+    with torch.autocast("cuda", enabled=False):
+        wl = last._normalised_weight()[0, :, 0].float()
+        logit = torch.mv(h2.reshape(B * L, C).float(), wl)
+        if last.bias is not None:
+            logit = logit + last.bias.float()
+    return logit.reshape(B, L).to(act)

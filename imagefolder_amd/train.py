@@ -22,6 +22,7 @@ import torch.distributed as dist
 
 from . import _lib
 from ._lib import check, ptr
+from ._lib import marker as _marker
 
 
 def get_random_ratio(randomness_anneal_start, randomness_anneal_end, end_ratio, cur_step):
@@ -179,12 +180,16 @@ class TokenizerTrainStep:
         with torch.autocast(device_type=dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(imgs, epoch, alpha, beta, delta)
             loss_gen = self.gen_loss_fn(out, imgs)
+        _marker(50)
         loss_gen.backward()
+        _marker(62)
         self.reducer.start()                       # RCCL over xGMI, overlapped with ...
         if self.disc_step_fn is not None:
             self.disc_step_fn(imgs, out[0].detach())   # ... the discriminator step (needs only recons.detach())
         self.reducer.wait()
+        _marker(70)
         self.opt.step()                            # AdamW + EMA + zero_grad + 1/world in one pass
+        _marker(71)
         return loss_gen.detach()
 
 
@@ -207,9 +212,12 @@ class DiscriminatorStep:
         with torch.autocast(device_type=imgs.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             loss_disc = self.vq_loss(None, None, None, None, imgs, recons_detached, optimizer_idx=1,
                                      global_step=self.global_step + 1, fade_blur_schedule=self.fade_blur_schedule)
+        _marker(43)
         loss_disc.backward()
+        _marker(44)
         self.opt.reducer.start()
         self.opt.reducer.wait()
         self.opt.step()
+        _marker(45)
         self.global_step += 1
         return loss_disc.detach()

@@ -403,6 +403,11 @@ class DinoDisc(nn.Module):
     def forward(self, x_in_pm1, grad_ckpt=False):
         acts = self.dino_proxy[0](x_in_pm1.float())
         B = x_in_pm1.shape[0]
+        from . import nn_ops
+        if x_in_pm1.is_cuda and nn_ops.FUSED_BLOCKS:
+            from . import ops_dense
+            if all(ops_dense.disc_head_supported(a, h) for h, a in zip(self.heads, acts)):
+                return torch.cat([ops_dense.disc_head(h, a) for h, a in zip(self.heads, acts)], dim=1)
         return torch.cat([h(a).view(B, -1) for h, a in zip(self.heads, acts)], dim=1)
 
 
@@ -423,6 +428,7 @@ class VQLoss(nn.Module):
         self.discriminator_iter_start = disc_start
         self.disc_weight = disc_weight
         self.disc_adaptive_weight = disc_adaptive_weight
+        self.deposit_disc_grads_in_gen_step = False
         self.perceptual_loss = LPIPS().eval()
         self.perceptual_weight = perceptual_weight
         self.rec_loss = F.l1_loss if reconstruction_loss == "l1" else F.mse_loss
@@ -446,24 +452,31 @@ class VQLoss(nn.Module):
         Here d(nll)/d(recons) and d(adv)/d(recons) are computed once on a detached copy of the reconstruction, the
         last-layer gradient norms come from pushing those two cotangents through the decoder tail only, and the total
         cotangent re-enters the graph through a linear surrogate term whose VALUE equals the upstream loss."""
+        from ._lib import marker
+        marker(30)
         rec_leaf = reconstructions.detach().requires_grad_(True)
         with torch.enable_grad():
             rec_loss = self.rec_loss(inputs.contiguous(), rec_leaf.contiguous())
             p_loss = torch.mean(self.perceptual_loss(inputs.contiguous(), rec_leaf.contiguous()))
             null_loss = self.rec_weight * rec_loss + self.perceptual_weight * p_loss
+            marker(31)
             logits_fake = self.discriminator(self.daug.aug(rec_leaf.contiguous(), fade_blur_schedule))
             generator_adv_loss = self.gen_adv_loss(logits_fake)
-        disc_params = [p for p in self.discriminator.parameters() if p.requires_grad]
+            marker(32)
+        disc_params = [p for p in self.discriminator.parameters() if p.requires_grad] if self.deposit_disc_grads_in_gen_step else []
         g_nll = torch.autograd.grad(null_loss, rec_leaf)[0]
+        marker(33)
         adv_grads = torch.autograd.grad(generator_adv_loss, [rec_leaf] + disc_params, allow_unused=True)
+        marker(34)
         g_adv = adv_grads[0]
         # gradient norms w.r.t. the decoder's last layer: only the graph between last_layer and recons is traversed
         nll_ll, adv_ll = (torch.autograd.grad(reconstructions, last_layer, grad_outputs=g.to(reconstructions.dtype),
                                               retain_graph=True)[0] for g in (g_nll, g_adv))
         d_weight = torch.clamp(torch.norm(nll_ll) / (torch.norm(adv_ll) + 1e-4), 0.0, 1e4).detach()
         disc_weight = adopt_weight(self.disc_weight, global_step, threshold=self.discriminator_iter_start)
-        # upstream's generator backward also deposits d(adv)/d(head params) on the discriminator (discarded by
-        # optimizer_disc.zero_grad(), :465); keep that observable behaviour
+        # upstream's generator backward also deposits d(adv)/d(head params) on the discriminator; they are discarded by
+        # optimizer_disc.zero_grad() (xqgan_train.py:465) before anything reads them, so they are only computed on request
+        # (deposit_disc_grads_in_gen_step = True reproduces that observable state)
         for p, gp in zip(disc_params, adv_grads[1:]):
             if gp is not None:
                 gp = gp * (d_weight * disc_weight)
@@ -472,6 +485,7 @@ class VQLoss(nn.Module):
         value = (null_loss + d_weight * disc_weight * generator_adv_loss).detach()
         surrogate = (reconstructions.float() * cot).sum()
         surrogate = surrogate + (value - surrogate.detach())  # value of the upstream loss, gradient = cot
+        marker(35)
         sem_loss = 0 if sem_loss is None else sem_loss
         detail_loss = 0 if detail_loss is None else detail_loss
         dependency_loss = 0 if dependency_loss is None else dependency_loss
@@ -502,8 +516,12 @@ class VQLoss(nn.Module):
                 disc_adaptive_weight * disc_weight * generator_adv_loss + \
                 codebook_loss[0] + codebook_loss[1] + codebook_loss[2] + sem_loss + detail_loss + dependency_loss
         if optimizer_idx == 1:  # discriminator update (:226-261)
+            from ._lib import marker
+            marker(40)
             logits_fake = self.discriminator(self.daug.aug(reconstructions.contiguous().detach(), fade_blur_schedule))
+            marker(41)
             logits_real = self.discriminator(self.daug.aug(inputs.contiguous().detach(), fade_blur_schedule))
+            marker(42)
             disc_weight = adopt_weight(self.disc_weight, global_step, threshold=self.discriminator_iter_start)
             if self.lecam_loss_weight is not None:
                 self.lecam_ema.update(logits_real, logits_fake)

@@ -299,7 +299,11 @@ class VQModel(nn.Module):
 
     # ---- :268-365 -------------------------------------------------------------------------------------------
     def forward(self, input, epoch, alpha, beta, delta):
+        from ._lib import marker, marker_on_grad   # section boundaries for kernel traces (no-ops unless XQ_MARKERS=1)
+        marker(20)
         h = self.encode(input)
+        marker(21)
+        marker_on_grad(h, 61)       # backward: quantizer done, encoder backward starts
         b, c, l, _ = h.shape
         if len(self.v_patch_nums) == 1:
             dropout_rand = None
@@ -335,7 +339,10 @@ class VQModel(nn.Module):
                                      "lacks: a P=1 multi-scale model cannot run its forward upstream either")
             quant_list = [quant]
 
+        marker(22)
+        marker_on_grad(quant, 60)   # backward: decoder done, quantizer backward starts
         dec = self.decode(quant)
+        marker(23)
 
         if self.semantic_guide != 'none':
             with torch.no_grad():
@@ -364,6 +371,7 @@ class VQModel(nn.Module):
         else:
             sem_loss = None
         detail_loss = None
+        marker(24)
         return dec, (mean_vq_loss, mean_commit_loss, mean_entropy, usages), sem_loss, detail_loss, dependency_loss
 
     # ---- :367-403 -------------------------------------------------------------------------------------------

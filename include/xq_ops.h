@@ -220,11 +220,34 @@ int xq_attn_forward(const void *qkv, int B, int N, int H, int head_dim, float sc
 int xq_attn_backward(const void *qkv, const void *out, const void *dout, const float *lse, int B, int N, int H, int head_dim,
                      float scale, void *dqkv, float *delta, xq_stream_t stream);
 
+/* ---- DinoDisc discriminator heads (discriminator_dino.py:113-166), token-major activations [B][L][C] --------------------
+ * BatchNormLocal (:127-154: statistics over virtual batches of 8 samples, i.e. groups of rows_per_group = 8*L consecutive
+ * token rows, biased variance, eps inside the sqrt) + LeakyReLU(slope) [+ ResidualBlock: (. + skip) * ratio, :113-119]. */
+
+/* y, skip (nullable), out: [G][rows_per_group][C] (bf16 or fp32 by act_bf16); w, b fp32 [C] (nullable = 1 / 0);
+ * mean, rstd: fp32 [G][C] outputs kept for the backward.  C % 64 == 0. */
+int xq_bnlocal_lrelu_forward(const void *y, const float *w, const float *b, const void *skip, int G, int rows_per_group, int C,
+                             int act_bf16, float eps, float slope, float ratio, void *out, float *mean, float *rstd,
+                             xq_stream_t stream);
+/* g_y (and g_skip when has_skip) in the activation dtype; gw_part / gb_part: fp32 [G][C] per-group partial sums of the
+ * affine gradients (the caller sums them over G). */
+int xq_bnlocal_lrelu_backward(const void *g_out, const void *y, const float *w, const float *b, const float *mean, const float *rstd,
+                              int G, int rows_per_group, int C, int act_bf16, float slope, float ratio, int has_skip, void *g_y,
+                              void *g_skip, float *gw_part, float *gb_part, xq_stream_t stream);
+/* im2col of Conv1d(kernel K, padding K/2, padding_mode='circular') (:157-166 make_block with ks = 9):
+ * cols[b][l][tap][c] = h[b][(l + tap - K/2) mod L][c]; the conv is then cols[B*L][K*C] x W[Cout][K*C]^T. */
+int xq_unfold1d_circular(const void *h, int B, int L, int C, int K, int act_bf16, void *cols, xq_stream_t stream);
+/* the transpose: dh[b][l][c] = sum_tap dcols[b][(l - tap + K/2) mod L][tap][c] */
+int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K, int act_bf16, void *dh, xq_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
  *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the
  *      recorded events and returns the summed duration and launch count since arming. ------------------ */
 int xq_prof_enable(int on);
 int xq_prof_collect(double *assign_ms_total, int *assign_launches);
+/* launches an empty kernel (xq_marker_kernel) with `id` workgroups of 64 threads: a section boundary that shows up in a
+ * rocprofv3 kernel trace (tools/rocpd_sections.py attributes the kernels between two markers to a section) */
+int xq_prof_marker(int id, xq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -323,3 +323,51 @@ def test_frozen_dino_trunk_fused_matches_per_op():
         assert (a - r).abs().max().item() <= 3e-2 * max(1.0, r.abs().max().item())
     ga, gr = outs[True][1], outs[False][1]
     assert ((ga - gr).norm() / gr.norm()).item() <= 5e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("autocast", [False, True])
+def test_dinodisc_fused_heads_match_per_op(autocast):
+    """DinoDisc (trunk + heads) on the fused kernels vs its per-op ATen form: logits, input gradient, head gradients"""
+    from imagefolder_amd import nn_ops
+    from imagefolder_amd.vq_loss import DinoDisc
+    torch.manual_seed(21)
+    dev = "cuda"
+    disc = DinoDisc(depth=3, key_depths=(0, 2)).to(dev).train()
+    with torch.no_grad():
+        for p in disc.dino_proxy[0].parameters():
+            if p.dim() > 1:
+                p.copy_(torch.randn_like(p) * 0.05)
+        for n, p in disc.named_parameters():
+            if p.dim() == 1 and "bias" in n:
+                p.copy_(torch.randn_like(p) * 0.1)
+    x0 = torch.rand(16, 3, 224, 224, device=dev) * 2 - 1
+    state = {k: v.clone() for k, v in disc.state_dict().items()}   # the power iteration updates u, v in every training forward
+    res = {}
+    for fused in (True, False):
+        nn_ops.FUSED_BLOCKS = fused
+        disc.load_state_dict(state)
+        try:
+            x = x0.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=autocast):
+                logits = disc(x)
+            w = torch.linspace(-1, 1, logits.numel(), device=dev).view_as(logits)
+            params = [p for p in disc.parameters() if p.requires_grad]
+            grads = torch.autograd.grad((logits.float() * w).sum(), [x] + params, allow_unused=True)
+            res[fused] = (logits.float(), grads)
+        finally:
+            nn_ops.FUSED_BLOCKS = True
+    tol = 4e-2 if autocast else 2e-3
+    la, lr = res[True][0], res[False][0]
+    assert la.shape == lr.shape == (16, 3 * 196)
+    assert (la - lr).abs().max().item() <= tol * max(1.0, lr.abs().max().item())
+    # gradients: relative Frobenius error per tensor (fp32: summation order + LeakyReLU sign flips at |pre| ~ 1e-7;
+    # autocast: both sides are bf16 approximations of the same function); conv biases in front of a BatchNorm have an
+    # exactly-zero gradient (pure rounding noise on both sides) and are skipped
+    scale = max(g.abs().max().item() for g in res[False][1][1:] if g is not None)
+    for ga, gr in zip(res[True][1], res[False][1]):
+        assert (ga is None) == (gr is None)
+        if gr is None or gr.abs().max().item() < 1e-3 * scale:
+            continue
+        rel = ((ga.float() - gr.float()).norm() / gr.float().norm()).item()
+        assert rel <= (0.12 if autocast else 2e-3), (tuple(gr.shape), rel)

@@ -111,6 +111,7 @@ def test_single_backward_generator_loss_equals_upstream_formulation():
     torch.manual_seed(0)
     L = VQLoss(disc_start=0, disc_type='dinodisc', disc_weight=0.5, disc_adaptive_weight=True, lecam_loss_weight=0.001,
                norm_type='bn', aug_prob=0.0).eval()  # aug off + eval: both evaluations see the same network/randomness
+    L.deposit_disc_grads_in_gen_step = True  # also reproduce the (discarded) head gradients of the upstream generator backward
     last = torch.nn.Parameter(torch.randn(3, 3, 1, 1) * 0.2)
     pre = torch.nn.Parameter(torch.rand(4, 3, 64, 64) * 2 - 1)
     imgs = torch.rand(4, 3, 64, 64) * 2 - 1
