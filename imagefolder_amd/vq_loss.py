@@ -153,6 +153,28 @@ class LPIPS(nn.Module):
 
 
 # ---- DiffAug (diffaug.py:22-118) ----------------------------------------------------------------------------------
+def _shift_zero_fill(x, th, tw):
+    """out[b, :, i, j] = x[b, :, i + th[b], j + tw[b]] where that lies inside the image, else 0 (one gather pass)"""
+    B, C, H, W = x.shape
+    ii = torch.arange(H, device=x.device).view(1, H, 1) + th.view(B, 1, 1)
+    jj = torch.arange(W, device=x.device).view(1, 1, W) + tw.view(B, 1, 1)
+    valid = ((ii >= 0) & (ii < H) & (jj >= 0) & (jj < W)).view(B, 1, H * W)
+    lin = (ii.clamp(0, H - 1) * W + jj.clamp(0, W - 1)).view(B, 1, H * W).expand(B, C, H * W)
+    return (x.reshape(B, C, H * W).gather(2, lin) * valid.to(x.dtype)).view(B, C, H, W)
+
+
+class _ShiftZeroFill(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, th, tw):
+        ctx.save_for_backward(th, tw)
+        return _shift_zero_fill(x, th, tw)
+
+    @staticmethod
+    def backward(ctx, g):
+        th, tw = ctx.saved_tensors
+        return _shift_zero_fill(g.contiguous(), -th, -tw), None, None
+
+
 class DiffAug(object):
     def __init__(self, prob=1.0, cutout=0.2):
         self.grids = {}
@@ -196,11 +218,9 @@ class DiffAug(object):
             dh, dw = round(H * 0.125), round(W * 0.125)
             th = rand01[0].mul(2 * dh + 1).floor().long() - dh
             tw = rand01[1].mul(2 * dw + 1).floor().long() - dw
-            gb, gh, gw = self._grids(B, H, W, dev)
-            gh = (gh + th).add(1).clamp(0, H + 1)
-            gw = (gw + tw).add(1).clamp(0, W + 1)
-            pad = F.pad(BCHW, [1, 1, 1, 1, 0, 0, 0, 0])
-            BCHW = pad.permute(0, 2, 3, 1).contiguous()[gb, gh, gw].permute(0, 3, 1, 2).contiguous()
+            # upstream gathers from a zero-padded copy with clamped indices (diffaug.py:72-80): out[b,:,i,j] = x[b,:,i+th,j+tw]
+            # inside the image, 0 outside — a zero-filled shift, whose exact transpose is the opposite shift
+            BCHW = _ShiftZeroFill.apply(BCHW, th.view(B), tw.view(B))
         if color:
             BCHW = BCHW.add(rand01[2].unsqueeze(-1).sub(0.5))
             m = BCHW.mean(dim=1, keepdim=True)
