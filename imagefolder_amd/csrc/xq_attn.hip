@@ -76,6 +76,13 @@ __device__ __forceinline__ uint4 load16_or_zero(const short *p, bool ok) {
     return v;
 }
 
+// v_max3_f32 without the operand canonicalisation that fmaxf() carries under IEEE mode (57 -> 16 instructions per tile)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float d;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 #define AT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -129,7 +136,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const short *__restrict__
     f32x16 o0, o1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o0[r] = 0.0f; o1[r] = 0.0f; }
+    // softmax bookkeeping per query (= per lane): m_run is the reference exponent (log2 units), only moved when a tile's
+    // maximum exceeds it by more than 2^8 ("lazy rescale": P <= 2^8 stays exact in bf16/fp32 and the O / l rescale becomes a
+    // rare wave-uniform branch); the row sums come out of the matrix pipe (ones x P^T) instead of 32 VALU adds per tile.
     float m_run = -INFINITY, l_run = 0.0f;
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const bool wave_live = qb * 128 + wave * 32 < N;   // waves whose 32 queries are all padding only help with staging
 
     const int ntiles = (N + 63) / 64;
     FW_LOAD(0)
@@ -138,60 +150,85 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const short *__restrict__
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1, kv0 = t * 64;
         if (t + 1 < ntiles) FW_LOAD(kv0 + 64)
-        const short *K = Ks[cur], *V = Vs[cur] + troff;
-        f32x16 s0, s1;
+        if (wave_live) {
+            const short *K = Ks[cur], *V = Vs[cur] + troff;
+            const bool wide = kv0 + 32 < N;   // the second 32 keys of the tile hold at least one real key
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            f32x16 s0, s1;
+            {
+                const short *ka = K + li * AT_RP + 8 * hh, *kb = ka + 32 * AT_RP;
+                s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka), qf0, zero16);
+                s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 16), qf1, s0);
+                s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 32), qf2, s0);
+                s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 48), qf3, s0);
+                if (wide) {
+                    s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb), qf0, zero16);
+                    s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 16), qf1, s1);
+                    s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 32), qf2, s1);
+                    s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 48), qf3, s1);
+                } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.0f; s1[r] = 0.0f; }
-        {
-            const short *ka = K + li * AT_RP + 8 * hh, *kb = ka + 32 * AT_RP;
-            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka), qf0, s0);
-            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb), qf0, s1);
-            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 16), qf1, s0);
-            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 16), qf1, s1);
-            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 32), qf2, s0);
-            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 32), qf2, s1);
-            s0 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(ka + 48), qf3, s0);
-            s1 = AT_MFMA(*reinterpret_cast<const bf16x8 *>(kb + 48), qf3, s1);
-        }
-        if (kv0 + 64 > N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (key >= N) s0[r] = -INFINITY;
-                if (key + 32 >= N) s1[r] = -INFINITY;
+                    for (int r = 0; r < 16; ++r) s1[r] = -INFINITY;
+                }
             }
-        }
-        float mx = fmaxf(s0[0], s1[0]);
+            if (kv0 + 64 > N) {
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mn = fmaxf(m_run, mx * c);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - mn);
-        m_run = mn;
-        float rs = 0.0f;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    if (key >= N) s0[r] = -INFINITY;
+                    if (key + 32 >= N) s1[r] = -INFINITY;
+                }
+            }
+            float mx = max3(s0[0], s0[1], s0[2]);
+            mx = max3(mx, s0[3], s0[4]);
+            mx = max3(mx, s0[5], s0[6]);
+            mx = max3(mx, s0[7], s0[8]);
+            mx = max3(mx, s0[9], s0[10]);
+            mx = max3(mx, s0[11], s0[12]);
+            mx = max3(mx, s0[13], s0[14]);
+            mx = max3(mx, s0[15], s1[0]);
+            mx = max3(mx, s1[1], s1[2]);
+            mx = max3(mx, s1[3], s1[4]);
+            mx = max3(mx, s1[5], s1[6]);
+            mx = max3(mx, s1[7], s1[8]);
+            mx = max3(mx, s1[9], s1[10]);
+            mx = max3(mx, s1[11], s1[12]);
+            mx = max3(mx, s1[13], s1[14]);
+            mx = max3(mx, s1[15], s1[15]);
+            mx = max3(mx, __shfl_xor(mx, 32), mx);
+            const float cand = mx * c;
+            if (__any(cand > m_run + 8.0f)) {
+                const float mn = fmaxf(m_run, cand);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - mn);   // first tile: exp2(-inf) = 0 on o = l = 0
+                m_run = mn;
+                l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mn));
-            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mn));
-            rs += s0[r] + s1[r];
-        }
-        l_run = l_run * alpha + rs;
+                for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-        const bf16x8 p00 = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
-        const bf16x8 p01 = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
-        const bf16x8 p10 = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
-        const bf16x8 p11 = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
-        {
+            for (int r = 0; r < 16; ++r) s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -m_run));
+            const bf16x8 p00 = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
+            const bf16x8 p01 = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
             // A = V^T rows d (lane), key slots {4hh..4hh+3, 8+4hh..} of each 16-key step: the order P's registers hold
             o0 = AT_MFMA(AT_TFRAG(V, 0, 0), p00, o0);
             o1 = AT_MFMA(AT_TFRAG(V, 0, 32), p00, o1);
+            f32x16 ls = AT_MFMA(ones, p00, zero16);
             o0 = AT_MFMA(AT_TFRAG(V, 16, 0), p01, o0);
             o1 = AT_MFMA(AT_TFRAG(V, 16, 32), p01, o1);
-            o0 = AT_MFMA(AT_TFRAG(V, 32, 0), p10, o0);
-            o1 = AT_MFMA(AT_TFRAG(V, 32, 32), p10, o1);
-            o0 = AT_MFMA(AT_TFRAG(V, 48, 0), p11, o0);
-            o1 = AT_MFMA(AT_TFRAG(V, 48, 32), p11, o1);
+            ls = AT_MFMA(ones, p01, ls);
+            if (wide) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -m_run));
+                const bf16x8 p10 = pack8(s1[0], s1[1], s1[2], s1[3], s1[4], s1[5], s1[6], s1[7]);
+                const bf16x8 p11 = pack8(s1[8], s1[9], s1[10], s1[11], s1[12], s1[13], s1[14], s1[15]);
+                o0 = AT_MFMA(AT_TFRAG(V, 32, 0), p10, o0);
+                o1 = AT_MFMA(AT_TFRAG(V, 32, 32), p10, o1);
+                ls = AT_MFMA(ones, p10, ls);
+                o0 = AT_MFMA(AT_TFRAG(V, 48, 0), p11, o0);
+                o1 = AT_MFMA(AT_TFRAG(V, 48, 32), p11, o1);
+                ls = AT_MFMA(ones, p11, ls);
+            }
+            l_run += ls[0];   // every row of ones x P^T is the same: sum over the tile's keys of this lane's query
         }
         if (t + 1 < ntiles) FW_STORE(cur ^ 1)
         __syncthreads();
@@ -199,7 +236,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const short *__restrict__
 #undef FW_LOAD
 #undef FW_STORE
 
-    l_run += __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_run;
     if (qn < N) {
         short *op = out + ((long)b * N + qn) * (H * 64) + h * 64 + 4 * hh;
@@ -335,8 +371,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restric
         // keys beyond N were staged as zeros: their dS is finite and multiplies K^T = 0
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -lse2)) * (p0[r] - dq_) * scale;
-            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -lse2)) * (p1[r] - dq_) * scale;
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -lse2)) * (p0[r] - dq_);   // the softmax scale is applied once, to dQ
+            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -lse2)) * (p1[r] - dq_);
         }
         const bf16x8 d00 = pack8(s0[0], s0[1], s0[2], s0[3], s0[4], s0[5], s0[6], s0[7]);
         const bf16x8 d01 = pack8(s0[8], s0[9], s0[10], s0[11], s0[12], s0[13], s0[14], s0[15]);
@@ -362,8 +398,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restric
         short *op = dqkv + ((long)b * N + qn) * RS + h * 64 + 4 * hh;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            uint2 w0 = make_uint2(pack_bf16(a0[4 * r4], a0[4 * r4 + 1]), pack_bf16(a0[4 * r4 + 2], a0[4 * r4 + 3]));
-            uint2 w1 = make_uint2(pack_bf16(a1[4 * r4], a1[4 * r4 + 1]), pack_bf16(a1[4 * r4 + 2], a1[4 * r4 + 3]));
+            uint2 w0 = make_uint2(pack_bf16(a0[4 * r4] * scale, a0[4 * r4 + 1] * scale), pack_bf16(a0[4 * r4 + 2] * scale, a0[4 * r4 + 3] * scale));
+            uint2 w1 = make_uint2(pack_bf16(a1[4 * r4] * scale, a1[4 * r4 + 1] * scale), pack_bf16(a1[4 * r4 + 2] * scale, a1[4 * r4 + 3] * scale));
             *reinterpret_cast<uint2 *>(op + 8 * r4) = w0;
             *reinterpret_cast<uint2 *>(op + 32 + 8 * r4) = w1;
         }
@@ -465,10 +501,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const short *__restr
                 const float4 l4 = *reinterpret_cast<const float4 *>(&Ls[cur][8 * r4 + 4 * hh]);
                 const float4 d4 = *reinterpret_cast<const float4 *>(&Ds[cur][8 * r4 + 4 * hh]);
                 float e;
-                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 0], c, -l4.x)); s[4 * r4 + 0] = e; p[4 * r4 + 0] = e * (p[4 * r4 + 0] - d4.x) * scale;
-                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 1], c, -l4.y)); s[4 * r4 + 1] = e; p[4 * r4 + 1] = e * (p[4 * r4 + 1] - d4.y) * scale;
-                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 2], c, -l4.z)); s[4 * r4 + 2] = e; p[4 * r4 + 2] = e * (p[4 * r4 + 2] - d4.z) * scale;
-                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 3], c, -l4.w)); s[4 * r4 + 3] = e; p[4 * r4 + 3] = e * (p[4 * r4 + 3] - d4.w) * scale;
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 0], c, -l4.x)); s[4 * r4 + 0] = e; p[4 * r4 + 0] = e * (p[4 * r4 + 0] - d4.x);
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 1], c, -l4.y)); s[4 * r4 + 1] = e; p[4 * r4 + 1] = e * (p[4 * r4 + 1] - d4.y);
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 2], c, -l4.z)); s[4 * r4 + 2] = e; p[4 * r4 + 2] = e * (p[4 * r4 + 2] - d4.z);
+                e = __builtin_amdgcn_exp2f(fmaf(s[4 * r4 + 3], c, -l4.w)); s[4 * r4 + 3] = e; p[4 * r4 + 3] = e * (p[4 * r4 + 3] - d4.w);
             }
             const bf16x8 pb0 = pack8(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7]);
             const bf16x8 pb1 = pack8(s[8], s[9], s[10], s[11], s[12], s[13], s[14], s[15]);
@@ -495,8 +531,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const short *__restr
         short *vp = kp + H * 64;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            *reinterpret_cast<uint2 *>(kp + 8 * r4) = make_uint2(pack_bf16(dk0[4 * r4], dk0[4 * r4 + 1]), pack_bf16(dk0[4 * r4 + 2], dk0[4 * r4 + 3]));
-            *reinterpret_cast<uint2 *>(kp + 32 + 8 * r4) = make_uint2(pack_bf16(dk1[4 * r4], dk1[4 * r4 + 1]), pack_bf16(dk1[4 * r4 + 2], dk1[4 * r4 + 3]));
+            *reinterpret_cast<uint2 *>(kp + 8 * r4) = make_uint2(pack_bf16(dk0[4 * r4] * scale, dk0[4 * r4 + 1] * scale),
+                                                                 pack_bf16(dk0[4 * r4 + 2] * scale, dk0[4 * r4 + 3] * scale));   // softmax scale, once
+            *reinterpret_cast<uint2 *>(kp + 32 + 8 * r4) = make_uint2(pack_bf16(dk1[4 * r4] * scale, dk1[4 * r4 + 1] * scale),
+                                                                      pack_bf16(dk1[4 * r4 + 2] * scale, dk1[4 * r4 + 3] * scale));
             *reinterpret_cast<uint2 *>(vp + 8 * r4) = make_uint2(pack_bf16(dv0[4 * r4], dv0[4 * r4 + 1]), pack_bf16(dv0[4 * r4 + 2], dv0[4 * r4 + 3]));
             *reinterpret_cast<uint2 *>(vp + 32 + 8 * r4) = make_uint2(pack_bf16(dv1[4 * r4], dv1[4 * r4 + 1]), pack_bf16(dv1[4 * r4 + 2], dv1[4 * r4 + 3]));
         }
