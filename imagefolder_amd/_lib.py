@@ -67,6 +67,8 @@ SIGNATURES = {
     "xq_fold1d_circular": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "xq_prof_collect_kind": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
+                                            ctypes.POINTER(ctypes.c_double)]),
     "xq_prof_marker": (ctypes.c_int, [ctypes.c_int, vp]),
 }
 

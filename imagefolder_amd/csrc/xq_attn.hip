@@ -553,8 +553,10 @@ extern "C" int xq_attn_forward(const void *qkv, int B, int N, int H, int head_di
     if (B == 0) return XQ_OK;
     if (!qkv || !out || !lse) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     const int nqb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
+    const int pslot = prof_begin(XQ_PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * 64.0, (hipStream_t)stream);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(G8 * nqb)), dim3(256), 0, (hipStream_t)stream, (const short *)qkv, B, N, H,
                        scale * 1.4426950408889634f, (short *)out, lse, nqb);
+    prof_end(pslot, (hipStream_t)stream);
     return xq_check_launch(fn);
 }
 
@@ -566,6 +568,7 @@ extern "C" int xq_attn_backward(const void *qkv, const void *out, const void *do
     if (!qkv || !out || !dout || !lse || !dqkv || !delta) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     hipStream_t s = (hipStream_t)stream;
     const long rows = (long)B * N * H;
+    const int pslot = prof_begin(XQ_PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * 64.0, s);
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const short *)out, (const short *)dout, B, N, H,
                        delta);
     const int nb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
@@ -573,5 +576,6 @@ extern "C" int xq_attn_backward(const void *qkv, const void *out, const void *do
                        H, scale, (short *)dqkv, nb);
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N, H,
                        scale, (short *)dqkv, nb);
+    prof_end(pslot, s);
     return xq_check_launch(fn);
 }

@@ -11,9 +11,9 @@
 // Weights are pre-packed once per update to Wp[n][k] (bf16), the same K order.
 // The data gradient is the same kernel run on dY with Wp'[c][(2-ky)*3+(2-kx)][n] (rotated taps, swapped channels).
 //
-// Tile: 128 pixels x BN channels x 32 K per step, 256 threads = 2x2 waves, each wave 64 x BN/2 through
-// v_mfma_f32_32x32x16_bf16 (fp32 accumulate); A/B tiles staged global -> VGPR -> LDS (row pitch 80 B: conflict-free
-// ds_read_b128 fragments), double-buffered, one barrier per K step.  Epilogue: + bias, optional ReLU, bf16 NHWC store.
+// Tile: 128 pixels x BN channels x 64 K per step (one tap's 64-channel run), 256 threads = 2x2 waves, each wave 64 x BN/2
+// through v_mfma_f32_32x32x16_bf16 (fp32 accumulate); A/B tiles staged global -> VGPR -> LDS (row pitch 144 B:
+// conflict-free ds_read_b128 fragments), double-buffered, one barrier per K step (16 or 8 MFMAs per wave between barriers).  Epilogue: + bias, optional ReLU, bf16 NHWC store.
 #include "xq_common.hpp"
 #include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
@@ -24,16 +24,26 @@ using namespace xq;
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 
-static constexpr int CV_BM = 128, CV_BK = 32, CV_PITCH = 40;  // LDS row pitch in bf16 elements (80 bytes)
+static constexpr int CV_BM = 128;
 
+// 16-byte load whose address is always valid (index clamped by the caller) and whose value is zeroed afterwards: a
+// "cond ? *p : zero" select makes hipcc pick between a global and a private pointer and issue flat loads through scratch
+__device__ __forceinline__ uint4 cv_load16_or_zero(const __hip_bfloat16 *p, bool ok) {
+    uint4 v = *reinterpret_cast<const uint4 *>(p);
+    if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+    return v;
+}
 
-template <int BN, bool RELU>
+// BK = K elements per step: 64 for the 128-channel tile (16 MFMAs per wave between barriers), 32 for the 64-channel tile
+// (small-K layers are latency-bound: the 30 KB footprint keeps 5 blocks per CU in flight instead of 2)
+template <int BN, int BK, bool RELU>
 __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__restrict__ X, const __hip_bfloat16 *__restrict__ Wp,
                                                       const float *__restrict__ bias, long M, int H, int Wd, int Cin, int Cout,
                                                       __hip_bfloat16 *__restrict__ Y) {
     constexpr int WN = BN / 2;          // channels per wave
     constexpr int NT = WN / 32;         // 32-wide N tiles per wave (2 for BN=128, 1 for BN=64)
-    constexpr int B_CHUNKS = BN * 4 / 256;  // 16-byte chunks of the B tile per thread (2 or 1)
+    constexpr int CV_BK = BK, CV_PITCH = BK + 8;   // LDS row pitch in bf16 elements (144 / 80 bytes: conflict-free b128 reads)
+    constexpr int CPT = BK / 32;        // 16-byte chunks per thread and row
     __shared__ __attribute__((aligned(16))) short lds[2][(CV_BM + BN) * CV_PITCH];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -43,8 +53,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__re
     const int K = 9 * Cin;
     const int ksteps = K / CV_BK;
 
-    // ---- A gather bookkeeping: this thread fetches rows ra0 = tid/4 and ra0+64, 16-byte part tid%4 ----
-    const int part = tid & 3;
+    // ---- A gather bookkeeping: this thread fetches pixels ra = tid/4 and ra+64, 32 contiguous bytes (2 chunks) at
+    //      channel offset (tid%4)*16 of the 64-channel K slice; B: weight rows tid/4 (+64), the same 32 bytes ----
+    const int part = (tid & 3) * 8 * CPT;
     const long HWd = (long)H * Wd;
     const long ma = m0 + (tid >> 2), mb = ma + 64;
     const bool ok0 = ma < M, ok1 = mb < M;
@@ -55,37 +66,51 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__re
     const long ab0 = ba * HWd, ab1 = bb * HWd;  // pixel index of (b, 0, 0)
 
     // staged registers (kept as named scalars: arrays captured by lambdas end up in scratch with hipcc)
-    uint4 ra0, ra1, rb0, rb1;
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
 #define CV_LOAD_TILES(KS)                                                                                              \
     {                                                                                                                  \
         const int k0_ = (KS) * CV_BK;                                                                                  \
         const int tap_ = k0_ / Cin, c0_ = k0_ - tap_ * Cin;                                                            \
         const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                                                 \
         {                                                                                                              \
-            const int yy = ay0 + dy_, xx = ax0 + dx_;                                                              \
-            const bool ok = ok0 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                     \
-            ra0 = *reinterpret_cast<const uint4 *>(X + ((ab0 + (ok ? (long)yy * Wd + xx : 0L)) * Cin + c0_ + part * 8)); \
-            if (!ok) ra0 = zero4;                                                                                     \
+            const int yy = ay0 + dy_, xx = ax0 + dx_;                                                                  \
+            const bool ok = ok0 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                            \
+            const __hip_bfloat16 *p_ = X + ((ab0 + (ok ? (long)yy * Wd + xx : 0L)) * Cin + c0_ + part);                \
+            ra0 = cv_load16_or_zero(p_, ok);                                                                           \
+            if (CPT > 1) ra1 = cv_load16_or_zero(p_ + 8, ok);                                                                     \
         }                                                                                                              \
         {                                                                                                              \
-            const int yy = ay1 + dy_, xx = ax1 + dx_;                                                              \
-            const bool ok = ok1 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                     \
-            ra1 = *reinterpret_cast<const uint4 *>(X + ((ab1 + (ok ? (long)yy * Wd + xx : 0L)) * Cin + c0_ + part * 8)); \
-            if (!ok) ra1 = zero4;                                                                                     \
+            const int yy = ay1 + dy_, xx = ax1 + dx_;                                                                  \
+            const bool ok = ok1 && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                            \
+            const __hip_bfloat16 *p_ = X + ((ab1 + (ok ? (long)yy * Wd + xx : 0L)) * Cin + c0_ + part);                \
+            ra2 = cv_load16_or_zero(p_, ok);                                                                           \
+            if (CPT > 1) ra3 = cv_load16_or_zero(p_ + 8, ok);                                                                     \
         }                                                                                                              \
-        rb0 = *reinterpret_cast<const uint4 *>(Wp + ((long)(n0 + (tid >> 2)) * K + k0_ + (tid & 3) * 8));              \
-        if (B_CHUNKS > 1) rb1 = *reinterpret_cast<const uint4 *>(Wp + ((long)(n0 + ((tid + 256) >> 2)) * K + k0_ + (tid & 3) * 8)); \
+        {                                                                                                              \
+            const __hip_bfloat16 *q_ = Wp + ((long)(n0 + (tid >> 2)) * K + k0_ + part);                                \
+            rb0 = *reinterpret_cast<const uint4 *>(q_);                                                                \
+            if (CPT > 1) rb1 = *reinterpret_cast<const uint4 *>(q_ + 8);                                                          \
+            if (BN > 64) {                                                                                             \
+                rb2 = *reinterpret_cast<const uint4 *>(q_ + 64L * K);                                                  \
+                if (CPT > 1) rb3 = *reinterpret_cast<const uint4 *>(q_ + 64L * K + 8);                                            \
+            }                                                                                                          \
+        }                                                                                                              \
     }
 #define CV_STORE_TILES(BUF)                                                                                            \
     {                                                                                                                  \
-        short *A_ = lds[BUF], *B_ = lds[BUF] + CV_BM * CV_PITCH;                                                       \
-        *reinterpret_cast<uint4 *>(A_ + (tid >> 2) * CV_PITCH + part * 8) = ra0;                                       \
-        *reinterpret_cast<uint4 *>(A_ + ((tid >> 2) + 64) * CV_PITCH + part * 8) = ra1;                                \
-        *reinterpret_cast<uint4 *>(B_ + (tid >> 2) * CV_PITCH + (tid & 3) * 8) = rb0;                                  \
-        if (B_CHUNKS > 1) *reinterpret_cast<uint4 *>(B_ + ((tid + 256) >> 2) * CV_PITCH + (tid & 3) * 8) = rb1;        \
+        short *A_ = lds[BUF] + (tid >> 2) * CV_PITCH + part, *B_ = lds[BUF] + (CV_BM + (tid >> 2)) * CV_PITCH + part;  \
+        *reinterpret_cast<uint4 *>(A_) = ra0;                                                                          \
+        if (CPT > 1) *reinterpret_cast<uint4 *>(A_ + 8) = ra1;                                                                    \
+        *reinterpret_cast<uint4 *>(A_ + 64 * CV_PITCH) = ra2;                                                          \
+        if (CPT > 1) *reinterpret_cast<uint4 *>(A_ + 64 * CV_PITCH + 8) = ra3;                                                    \
+        *reinterpret_cast<uint4 *>(B_) = rb0;                                                                          \
+        if (CPT > 1) *reinterpret_cast<uint4 *>(B_ + 8) = rb1;                                                                    \
+        if (BN > 64) {                                                                                                 \
+            *reinterpret_cast<uint4 *>(B_ + 64 * CV_PITCH) = rb2;                                                      \
+            if (CPT > 1) *reinterpret_cast<uint4 *>(B_ + 64 * CV_PITCH + 8) = rb3;                                                \
+        }                                                                                                              \
     }
-    rb1 = zero4;
+    ra1 = ra3 = rb1 = rb2 = rb3 = make_uint4(0u, 0u, 0u, 0u);
 
     f32x16 acc[2][NT];
 #pragma unroll
@@ -172,19 +197,21 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
     const char *fn = "xq_conv3x3_nhwc_bf16";
     if (B == 0) return XQ_OK;
     if (!X || !Wp || !Y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    if (Cin % 32 != 0 || Cout % 64 != 0)
-        return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 32 == 0 and Cout %% 64 == 0 (got %ld, %ld)", fn, Cin, Cout);
+    if (Cin % 64 != 0 || Cout % 64 != 0)
+        return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %ld, %ld)", fn, Cin, Cout);
     const long M = (long)B * H * W;
     hipStream_t s = (hipStream_t)stream;
     const unsigned gx = (unsigned)((M + CV_BM - 1) / CV_BM);
     const __hip_bfloat16 *x = (const __hip_bfloat16 *)X, *w = (const __hip_bfloat16 *)Wp;
     __hip_bfloat16 *y = (__hip_bfloat16 *)Y;
+    const int pslot = prof_begin(XQ_PROF_CONV3X3, 2.0 * (double)M * 9.0 * Cin * Cout, s);
     if (Cout % 128 == 0) {
-        if (relu) hipLaunchKernelGGL((conv3x3_kernel<128, true>), dim3(gx, Cout / 128), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
-        else hipLaunchKernelGGL((conv3x3_kernel<128, false>), dim3(gx, Cout / 128), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+        if (relu) hipLaunchKernelGGL((conv3x3_kernel<128, 64, true>), dim3(gx, Cout / 128), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+        else hipLaunchKernelGGL((conv3x3_kernel<128, 64, false>), dim3(gx, Cout / 128), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
     } else {
-        if (relu) hipLaunchKernelGGL((conv3x3_kernel<64, true>), dim3(gx, Cout / 64), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
-        else hipLaunchKernelGGL((conv3x3_kernel<64, false>), dim3(gx, Cout / 64), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+        if (relu) hipLaunchKernelGGL((conv3x3_kernel<64, 32, true>), dim3(gx, Cout / 64), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
+        else hipLaunchKernelGGL((conv3x3_kernel<64, 32, false>), dim3(gx, Cout / 64), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
     }
+    prof_end(pslot, s);
     return xq_check_launch(fn);
 }

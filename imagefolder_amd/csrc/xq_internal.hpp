@@ -46,3 +46,10 @@ enum { XQI_PREP = 1, XQI_SEARCH = 2 };
 // prep: E -> fragment-ordered (normalised) codebook + |e|^2 in ws; search: keys[n] = min over codes of (ord(d)<<32 | code)
 int launch_assign(int mode, int C, const float *z, long N, int HW, const float *E, int V, const AssignWs &ws, hipStream_t s,
                   int what = XQI_PREP | XQI_SEARCH);
+
+// measurement hooks (xq_vq.hip): start/stop HIP events around an instrumented launch when xq_prof_enable(1) is armed;
+// `work` = algorithmic flops (or bytes) of the launch, `kind` one of XQ_PROF_* (include/xq_ops.h)
+namespace xq {
+int prof_begin(int kind, double work, hipStream_t s);
+void prof_end(int slot, hipStream_t s);
+}

@@ -48,11 +48,14 @@ extern "C" const char *xq_last_error(void) { return g_err; }
 extern "C" int xq_abi_version(void) { return XQ_ABI_VERSION; }
 
 // ------------------------------------------------------------------------------------------------
-// measurement hooks: HIP events around assign_kernel on its launch stream (bench.py roofline leg)
+// measurement hooks: HIP events around the hand-written hot kernels on their launch stream (bench.py roofline leg).
+// Every instrumented launch records (kind, algorithmic work) and a start/stop event pair.
 // ------------------------------------------------------------------------------------------------
 static bool g_prof_on = false;
-static constexpr int PROF_MAX = 8192;
+static constexpr int PROF_MAX = 16384;
 static hipEvent_t g_prof_ev[PROF_MAX][2];
+static int g_prof_kind[PROF_MAX];
+static double g_prof_work[PROF_MAX];
 static int g_prof_n = 0, g_prof_created = 0;
 
 extern "C" int xq_prof_enable(int on) {
@@ -60,18 +63,42 @@ extern "C" int xq_prof_enable(int on) {
     g_prof_n = 0;
     return XQ_OK;
 }
-extern "C" int xq_prof_collect(double *assign_ms_total, int *assign_launches) {
-    double tot = 0.0;
+extern "C" int xq_prof_collect_kind(int kind, double *ms_total, int *launches, double *work_total) {
+    double tot = 0.0, work = 0.0;
+    int n = 0;
     for (int i = 0; i < g_prof_n; ++i) {
+        if (g_prof_kind[i] != kind) continue;
         float ms = 0.f;
         if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipEventSynchronize failed");
         if (hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipEventElapsedTime failed");
         tot += ms;
+        work += g_prof_work[i];
+        ++n;
     }
-    if (assign_ms_total) *assign_ms_total = tot;
-    if (assign_launches) *assign_launches = g_prof_n;
-    g_prof_n = 0;
+    if (ms_total) *ms_total = tot;
+    if (launches) *launches = n;
+    if (work_total) *work_total = work;
     return XQ_OK;
+}
+extern "C" int xq_prof_collect(double *assign_ms_total, int *assign_launches) {
+    const int rc = xq_prof_collect_kind(XQ_PROF_ASSIGN, assign_ms_total, assign_launches, nullptr);
+    g_prof_n = 0;
+    return rc;
+}
+int xq::prof_begin(int kind, double work, hipStream_t s) {
+    if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
+    if (g_prof_n >= g_prof_created) {
+        if (hipEventCreate(&g_prof_ev[g_prof_created][0]) != hipSuccess || hipEventCreate(&g_prof_ev[g_prof_created][1]) != hipSuccess) return -1;
+        ++g_prof_created;
+    }
+    const int slot = g_prof_n++;
+    g_prof_kind[slot] = kind;
+    g_prof_work[slot] = work;
+    (void)hipEventRecord(g_prof_ev[slot][0], s);
+    return slot;
+}
+void xq::prof_end(int slot, hipStream_t s) {
+    if (slot >= 0) (void)hipEventRecord(g_prof_ev[slot][1], s);
 }
 // section markers for kernel traces: an empty kernel whose grid size is the section id (tools/rocpd_sections.py)
 __global__ void xq_marker_kernel() {}
@@ -79,14 +106,6 @@ extern "C" int xq_prof_marker(int id, xq_stream_t stream) {
     if (id < 1) return xq_set_error(XQ_EINVAL, "%s: id must be >= 1", "xq_prof_marker");
     hipLaunchKernelGGL(xq_marker_kernel, dim3((unsigned)id), dim3(64), 0, (hipStream_t)stream);
     return xq_check_launch("xq_prof_marker");
-}
-static inline int prof_slot() {
-    if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
-    if (g_prof_n >= g_prof_created) {
-        if (hipEventCreate(&g_prof_ev[g_prof_created][0]) != hipSuccess || hipEventCreate(&g_prof_ev[g_prof_created][1]) != hipSuccess) return -1;
-        ++g_prof_created;
-    }
-    return g_prof_n++;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -479,7 +498,6 @@ static int launch_assign_t(const float *z, long N, int HW, const float *E, int V
         hipLaunchKernelGGL((prep_codebook_kernel<C, MODE>), dim3((Vpad + 255) / 256), dim3(256), 0, s, E, V, Vpad, ws.wb, ws.ee);
     if (!(what & XQI_SEARCH)) return xq_check_launch("prep_codebook_kernel");
     if (hipMemsetAsync(ws.keys, 0xFF, (size_t)N * 8, s) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s", "hipMemsetAsync(keys) failed");
-    const int pslot = prof_slot();
     {
         const int n_chunks = Vpad / TL::CH;
         const int tok_blocks = (int)((N + TOK_PER_BLOCK - 1) / TOK_PER_BLOCK);
@@ -495,10 +513,10 @@ static int launch_assign_t(const float *z, long N, int HW, const float *E, int V
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_set = true;
         }
-        if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][0], s);
+        const int pslot = prof_begin(XQ_PROF_ASSIGN, 2.0 * (double)N * Vpad * C, s);
         hipLaunchKernelGGL((assign_kernel<C, MODE>), dim3(tok_blocks, splits), dim3(ASSIGN_THREADS), lds, s, z, N, HW, ws.wb, ws.ee,
                            n_chunks, cps, ws.keys);
-        if (pslot >= 0) (void)hipEventRecord(g_prof_ev[pslot][1], s);
+        prof_end(pslot, s);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "assign_kernel<C=%d>: %s", C, hipGetErrorString(e)); return XQ_ELAUNCH; }

@@ -204,7 +204,7 @@ int xq_lpips_level_backward(const void *f0, const void *f1, const float *w, cons
 int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad, void *Wp, xq_stream_t stream);
 
 /* Y[b,y,x,n] = act(bias[n] + sum_{ky,kx,c} X[b,y+ky-1,x+kx-1,c] * W[n][c][ky][kx]); X [B][H][W][Cin], Y [B][H][W][Cout]
- * bf16 NHWC (= torch channels_last); bias fp32 [Cout] nullable; relu != 0 fuses ReLU.  Cin % 32 == 0, Cout % 64 == 0. */
+ * bf16 NHWC (= torch channels_last); bias fp32 [Cout] nullable; relu != 0 fuses ReLU.  Cin % 64 == 0, Cout % 64 == 0. */
 int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
                          void *Y, xq_stream_t stream);
 
@@ -240,10 +240,16 @@ int xq_unfold1d_circular(const void *h, int B, int L, int C, int K, int act_bf16
 /* the transpose: dh[b][l][c] = sum_tap dcols[b][(l - tap + K/2) mod L][tap][c] */
 int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K, int act_bf16, void *dh, xq_stream_t stream);
 
-/* ---- measurement hooks (bench.py): HIP events recorded around the dominant kernel (assign_kernel) on the
- *      stream it is launched on.  xq_prof_enable(1) resets and arms, xq_prof_collect synchronises the
- *      recorded events and returns the summed duration and launch count since arming. ------------------ */
+/* ---- measurement hooks (bench.py): HIP events recorded around the instrumented hand-written kernels on the stream they
+ *      are launched on.  xq_prof_enable(1) resets and arms; xq_prof_collect_kind synchronises the recorded events of one
+ *      kernel kind and returns their summed duration, launch count and summed algorithmic work (flops) since arming;
+ *      xq_prof_collect = the XQ_PROF_ASSIGN kind + reset (kept for older callers). ------------------------------------ */
+#define XQ_PROF_ASSIGN 0     /* assign_kernel: 2*N*Vpad*C flops per launch                                        */
+#define XQ_PROF_CONV3X3 1    /* conv3x3_kernel: 2*B*H*W*9*Cin*Cout flops per launch                               */
+#define XQ_PROF_ATTN_FWD 2   /* attn_fwd_kernel: 4*B*H*N*N*64 flops per launch (2 tile products)                  */
+#define XQ_PROF_ATTN_BWD 3   /* delta + dK/dV + dQ kernels: 10*B*H*N*N*64 algorithmic flops (5 products; 7 are run) */
 int xq_prof_enable(int on);
+int xq_prof_collect_kind(int kind, double *ms_total, int *launches, double *work_total);
 int xq_prof_collect(double *assign_ms_total, int *assign_launches);
 /* launches an empty kernel (xq_marker_kernel) with `id` workgroups of 64 threads: a section boundary that shows up in a
  * rocprofv3 kernel trace (tools/rocpd_sections.py attributes the kernels between two markers to a section) */
