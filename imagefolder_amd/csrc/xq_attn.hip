@@ -89,7 +89,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 // forward: out[b, n, h, :] = softmax(q k^T * scale) v ; lse[b, h, n] = log sum exp (natural log, scaled scores)
 // block = 128 queries of one (b, h) (4 waves x 32), loop over 64-key tiles: K row-major + V transposed in LDS, 2 buffers.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const short *__restrict__ qkv, int B, int N, int H, float c, short *__restrict__ out,
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const short *__restrict__ qkv, int B, int N, int H, float c, short *__restrict__ out,
                                                        float *__restrict__ lse, int nqb) {
     __shared__ __attribute__((aligned(16))) short Ks[2][64 * AT_RP];
     __shared__ __attribute__((aligned(16))) short Vs[2][64 * AT_RP];
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const short *__restrict
 // dQ: one query per lane (as the forward).  Per 64-key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP - delta) scale,
 // dQ^T += K^T dS^T.  LDS per buffer: K and V row-major (K^T fragments through transpose reads).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
                                                           const float *__restrict__ lse, const float *__restrict__ delta, int B, int N, int H,
                                                           float scale, short *__restrict__ dqkv, int nqb) {
     __shared__ __attribute__((aligned(16))) short Ks[2][64 * AT_RP];
@@ -337,6 +337,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restric
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
 
+    const bool wave_live = qb * 128 + wave * 32 < N;   // waves whose 32 queries are all padding only help with staging
     const int ntiles = (N + 63) / 64;
     DQ_LOAD(0)
     DQ_STORE(0)
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restric
     for (int t = 0; t < ntiles; ++t) {
         const int cur = t & 1, kv0 = t * 64;
         if (t + 1 < ntiles) DQ_LOAD(kv0 + 64)
+        if (wave_live) {
         const short *K = Ks[cur], *V = Vs[cur], *T = Ks[cur] + troff;
         f32x16 s0, s1, p0, p1;
 #pragma unroll
@@ -388,6 +390,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restric
             a0 = AT_MFMA(AT_TFRAG(T, 48, 0), d11, a0);
             a1 = AT_MFMA(AT_TFRAG(T, 48, 32), d11, a1);
         }
+        }
         if (t + 1 < ntiles) DQ_STORE(cur ^ 1)
         __syncthreads();
     }
@@ -411,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const short *__restric
 // P = exp2(S c - lse2), dS = P (dP - delta) scale, dV^T += dO^T P, dK^T += Q^T dS.
 // LDS per buffer: Q, dO row-major [32][72]; Q, dO transposed [64][36]; lse2, delta [32].
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
                                                             const float *__restrict__ lse, const float *__restrict__ delta, int B, int N, int H,
                                                             float scale, short *__restrict__ dqkv, int nkb) {
     __shared__ __attribute__((aligned(16))) short Qs[2][32 * AT_RP];
