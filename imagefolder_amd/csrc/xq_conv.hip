@@ -215,3 +215,126 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
     prof_end(pslot, s);
     return xq_check_launch(fn);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// MaxPool2d(kernel 2, stride 2) on NHWC bf16 (the four pools of the VGG16 trunk, lpips.py:118-155 via torchvision's cfg).
+// Forward: 4 x 16-byte reads -> one 16-byte write per 8 channels.  Backward: recomputes the arg-max from the saved input
+// (first maximum in (0,0),(0,1),(1,0),(1,1) order, as ATen's strict '>' scan) instead of reading an int64 index per
+// element (ATen stores 8 bytes of index for every 2-byte output: 4x the traffic of the data itself).
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float bfbits_to_f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+
+__global__ __launch_bounds__(256) void maxpool2x2_fwd_kernel(const unsigned short *__restrict__ X, int B, int Ho, int Wo, int C,
+                                                             unsigned short *__restrict__ Y) {
+    const int cv = C / 8;
+    const long total = (long)B * Ho * Wo * cv;
+    const long Wi = 2L * Wo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        long t = i / cv;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const long b = t / Ho;
+        const unsigned short *p = X + (((b * 2 * Ho + 2 * yo) * Wi + 2 * xo) * C + c * 8);
+        const uint4 v00 = *reinterpret_cast<const uint4 *>(p), v01 = *reinterpret_cast<const uint4 *>(p + C);
+        const uint4 v10 = *reinterpret_cast<const uint4 *>(p + Wi * C), v11 = *reinterpret_cast<const uint4 *>(p + Wi * C + C);
+        const unsigned short *a = reinterpret_cast<const unsigned short *>(&v00), *bq = reinterpret_cast<const unsigned short *>(&v01);
+        const unsigned short *cq = reinterpret_cast<const unsigned short *>(&v10), *d = reinterpret_cast<const unsigned short *>(&v11);
+        uint4 o;
+        unsigned short *oo = reinterpret_cast<unsigned short *>(&o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            unsigned short m = a[j];
+            float mv = bfbits_to_f(m);
+            float f = bfbits_to_f(bq[j]);
+            if (f > mv) { mv = f; m = bq[j]; }
+            f = bfbits_to_f(cq[j]);
+            if (f > mv) { mv = f; m = cq[j]; }
+            f = bfbits_to_f(d[j]);
+            if (f > mv) { mv = f; m = d[j]; }
+            oo[j] = m;
+        }
+        *reinterpret_cast<uint4 *>(Y + i * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2x2_bwd_kernel(const unsigned short *__restrict__ X, const unsigned short *__restrict__ G,
+                                                             int B, int Ho, int Wo, int C, unsigned short *__restrict__ GX) {
+    const int cv = C / 8;
+    const long total = (long)B * Ho * Wo * cv;
+    const long Wi = 2L * Wo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        long t = i / cv;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const long b = t / Ho;
+        const long off = ((b * 2 * Ho + 2 * yo) * Wi + 2 * xo) * C + c * 8;
+        const unsigned short *p = X + off;
+        const uint4 v00 = *reinterpret_cast<const uint4 *>(p), v01 = *reinterpret_cast<const uint4 *>(p + C);
+        const uint4 v10 = *reinterpret_cast<const uint4 *>(p + Wi * C), v11 = *reinterpret_cast<const uint4 *>(p + Wi * C + C);
+        const uint4 gv = *reinterpret_cast<const uint4 *>(G + i * 8);
+        const unsigned short *a = reinterpret_cast<const unsigned short *>(&v00), *bq = reinterpret_cast<const unsigned short *>(&v01);
+        const unsigned short *cq = reinterpret_cast<const unsigned short *>(&v10), *d = reinterpret_cast<const unsigned short *>(&v11);
+        const unsigned short *gg = reinterpret_cast<const unsigned short *>(&gv);
+        uint4 o00, o01, o10, o11;
+        unsigned short *q00 = reinterpret_cast<unsigned short *>(&o00), *q01 = reinterpret_cast<unsigned short *>(&o01);
+        unsigned short *q10 = reinterpret_cast<unsigned short *>(&o10), *q11 = reinterpret_cast<unsigned short *>(&o11);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            int arg = 0;
+            float mv = bfbits_to_f(a[j]);
+            float f = bfbits_to_f(bq[j]);
+            if (f > mv) { mv = f; arg = 1; }
+            f = bfbits_to_f(cq[j]);
+            if (f > mv) { mv = f; arg = 2; }
+            f = bfbits_to_f(d[j]);
+            if (f > mv) { mv = f; arg = 3; }
+            q00[j] = arg == 0 ? gg[j] : (unsigned short)0;
+            q01[j] = arg == 1 ? gg[j] : (unsigned short)0;
+            q10[j] = arg == 2 ? gg[j] : (unsigned short)0;
+            q11[j] = arg == 3 ? gg[j] : (unsigned short)0;
+        }
+        unsigned short *gp = GX + off;
+        *reinterpret_cast<uint4 *>(gp) = o00;
+        *reinterpret_cast<uint4 *>(gp + C) = o01;
+        *reinterpret_cast<uint4 *>(gp + Wi * C) = o10;
+        *reinterpret_cast<uint4 *>(gp + Wi * C + C) = o11;
+    }
+}
+
+static int pool_check(const char *fn, int B, int Ho, int Wo, int C) {
+    if (B < 0 || Ho < 1 || Wo < 1 || C < 8 || C % 8 != 0)
+        return xq_set_error(XQ_EINVAL, "%s: needs C %% 8 == 0 and a non-empty output (Wo=%ld, C=%ld)", fn, (long)Wo, (long)C);
+    return XQ_OK;
+}
+
+extern "C" int xq_maxpool2x2_nhwc_bf16_forward(const void *X, int B, int Ho, int Wo, int C, void *Y, xq_stream_t stream) {
+    const char *fn = "xq_maxpool2x2_nhwc_bf16_forward";
+    if (int rc = pool_check(fn, B, Ho, Wo, C)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!X || !Y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * Ho * Wo * (C / 8);
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(maxpool2x2_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)X, B, Ho, Wo, C,
+                       (unsigned short *)Y);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_maxpool2x2_nhwc_bf16_backward(const void *X, const void *G, int B, int Ho, int Wo, int C, void *GX, xq_stream_t stream) {
+    const char *fn = "xq_maxpool2x2_nhwc_bf16_backward";
+    if (int rc = pool_check(fn, B, Ho, Wo, C)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!X || !G || !GX) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * Ho * Wo * (C / 8);
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)X,
+                       (const unsigned short *)G, B, Ho, Wo, C, (unsigned short *)GX);
+    return xq_check_launch(fn);
+}

@@ -160,6 +160,11 @@ __global__ __launch_bounds__(ROW_THREADS) void res_ln_bwd_kernel(const T *__rest
 // flight per thread), then the 16 lanes are combined through LDS in a fixed order.  (The earlier 64-column x 4-lane shape
 // left 128 serial loads per thread and only ~48 blocks: 42 us per call, 6 ms per train step.)
 static constexpr int FIN_COLS = 16, FIN_LANES = 16;
+// block size of the column kernels: one thread per 16-byte column vector, whole waves, at most 1024
+static inline int col_threads(int vectors_per_row) {
+    int t = (vectors_per_row + 63) / 64 * 64;
+    return t < 64 ? 64 : (t > 1024 ? 1024 : t);
+}
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float *__restrict__ partials, int nblocks, int nq, int D,
                                                               float *o0, float *o1, float *o2, float *o3, int accumulate) {
     const int cx = threadIdx.x % FIN_COLS, ry = threadIdx.x / FIN_COLS;
@@ -245,11 +250,12 @@ __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ h, 
 
 // g_h = g_out * gelu'(h); column partial sums of g_h (fc1 bias gradient): partials[block][H]
 template <typename T, bool TANH>
-__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ h, long rows, int H,
+__global__ __launch_bounds__(1024) void gelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ h, long rows, int H,
                                                        T *__restrict__ g_h, float *__restrict__ partials) {
     constexpr int VEC = 16 / sizeof(T);
-    // thread t owns columns [t*VEC, t*VEC+VEC) + k*256*VEC; rows strided over blocks
-    for (int c0 = threadIdx.x * VEC; c0 < H; c0 += 256 * VEC) {
+    // thread t owns columns [t*VEC, t*VEC+VEC) (+ k*blockDim*VEC); rows strided over blocks.  The launcher sizes the block to
+    // H/VEC threads (one pass, every thread busy: with 256-thread blocks H = 3072 left half of them idle on the tail pass)
+    for (int c0 = threadIdx.x * VEC; c0 < H; c0 += blockDim.x * VEC) {
         float acc[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
@@ -273,9 +279,9 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T *__restrict__ g_o
 
 // plain column sum of a [rows][H] matrix of T (qkv bias gradient): partials[block][H]
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T *__restrict__ g, long rows, int H, float *__restrict__ partials) {
+__global__ __launch_bounds__(1024) void colsum_kernel(const T *__restrict__ g, long rows, int H, float *__restrict__ partials) {
     constexpr int VEC = 16 / sizeof(T);
-    for (int c0 = threadIdx.x * VEC; c0 < H; c0 += 256 * VEC) {
+    for (int c0 = threadIdx.x * VEC; c0 < H; c0 += blockDim.x * VEC) {
         float acc[VEC];
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] = 0.0f;
@@ -383,7 +389,8 @@ extern "C" int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, 
     if (g_bias && !partials) return xq_set_error(XQ_EINVAL, "%s: partials workspace required for the bias gradient", fn);
     const int blocks = row_blocks(rows * 4);
     hipStream_t s = (hipStream_t)stream;
-#define GELU_BWD(T, TANH) hipLaunchKernelGGL((gelu_bwd_kernel<T, TANH>), dim3(blocks), dim3(256), 0, s, (const T *)g_out, (const T *)h, (long)rows, H, \
+    const int threads = col_threads(H / vec);
+#define GELU_BWD(T, TANH) hipLaunchKernelGGL((gelu_bwd_kernel<T, TANH>), dim3(blocks), dim3(threads), 0, s, (const T *)g_out, (const T *)h, (long)rows, H, \
                                              (T *)g_h, g_bias ? partials : nullptr)
     if (act_bf16) { if (approximate_tanh) GELU_BWD(bf16, true); else GELU_BWD(bf16, false); }
     else { if (approximate_tanh) GELU_BWD(float, true); else GELU_BWD(float, false); }
@@ -402,8 +409,9 @@ extern "C" int xq_colsum(const void *g, int64_t rows, int H, int act_bf16, float
     if (H % vec) return xq_set_error(XQ_EINVAL, "%s: H=%ld must be a multiple of the 16-byte vector", fn, H);
     const int blocks = row_blocks(rows * 4);
     hipStream_t s = (hipStream_t)stream;
-    if (act_bf16) hipLaunchKernelGGL((colsum_kernel<bf16>), dim3(blocks), dim3(256), 0, s, (const bf16 *)g, (long)rows, H, partials);
-    else hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)g, (long)rows, H, partials);
+    const int threads = col_threads(H / vec);
+    if (act_bf16) hipLaunchKernelGGL((colsum_kernel<bf16>), dim3(blocks), dim3(threads), 0, s, (const bf16 *)g, (long)rows, H, partials);
+    else hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(threads), 0, s, (const float *)g, (long)rows, H, partials);
     hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, s, partials, blocks, 1, H, out, nullptr, nullptr, nullptr, accumulate);
     return xq_check_launch(fn);
 }

@@ -144,6 +144,15 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
     return torch.relu(y) if relu else y
 
 
+def max_pool2x2(x):
+    """MaxPool2d(kernel_size=2, stride=2): hand-written NHWC bf16 kernels (csrc/xq_conv.hip) when the layout allows."""
+    if x.is_cuda:
+        from . import ops_dense
+        if ops_dense.maxpool2x2_supported(x):
+            return ops_dense.MaxPool2x2Fn.apply(x)
+    return F.max_pool2d(x, kernel_size=2, stride=2)
+
+
 def _conv2d_library(x, weight, bias, stride=1, padding=0):
     if CHANNELS_LAST and x.is_cuda and x.dim() == 4 and weight.shape[-1] > 1:
         x = x.contiguous(memory_format=torch.channels_last)

@@ -596,3 +596,33 @@ class RowDotFn(torch.autograd.Function):
                 rc = _lib.lib().xq_colsum(ptr(prod), rows, C, 0, ptr(g_w), 0, ptr(part), _stream(prod))
             check(rc, "xq_colsum")
         return g_h, g_w
+
+
+# ---- MaxPool2d(2, 2) on channels-last bf16 (VGG16 trunk) ----------------------------------------------------------------
+def maxpool2x2_supported(x):
+    return (x.is_cuda and x.dim() == 4 and x.dtype == torch.bfloat16 and x.shape[1] % 8 == 0 and x.shape[2] % 2 == 0
+            and x.shape[3] % 2 == 0 and x.is_contiguous(memory_format=torch.channels_last))
+
+
+class MaxPool2x2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        xc = x.detach()
+        y = torch.empty((B, C, H // 2, W // 2), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().xq_maxpool2x2_nhwc_bf16_forward(ptr(xc), B, H // 2, W // 2, C, ptr(y), _stream(x))
+        check(rc, "xq_maxpool2x2_nhwc_bf16_forward")
+        ctx.save_for_backward(xc)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        B, C, H, W = xc.shape
+        g = g.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        gx = torch.empty_like(xc)
+        with torch.cuda.device(xc.device):
+            rc = _lib.lib().xq_maxpool2x2_nhwc_bf16_backward(ptr(xc), ptr(g), B, H // 2, W // 2, C, ptr(gx), _stream(xc))
+        check(rc, "xq_maxpool2x2_nhwc_bf16_backward")
+        return gx

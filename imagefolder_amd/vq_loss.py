@@ -93,8 +93,8 @@ class _VGG16Slices(nn.Module):
                 if isinstance(m, nn.Conv2d):  # conv + the ReLU that always follows it, as one op (fused epilogue on the HIP path)
                     x = nn_ops.conv2d(x, m.weight, m.bias, stride=1, padding=1, relu=True)
                     i += 2
-                else:
-                    x = m(x)
+                else:  # MaxPool2d(2, 2)
+                    x = nn_ops.max_pool2x2(x) if (m.kernel_size, m.stride) in ((2, 2), ((2, 2), (2, 2))) else m(x)
                     i += 1
             outs.append(x)
         return outs

@@ -208,6 +208,12 @@ int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad
 int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
                          void *Y, xq_stream_t stream);
 
+/* MaxPool2d(kernel_size=2, stride=2) of the VGG16 trunk (lpips.py:118-155), NHWC bf16, even input height/width:
+ * X [B][2*Ho][2*Wo][C] -> Y [B][Ho][Wo][C]; the backward recomputes the arg-max from X (first maximum in row-major window
+ * order, as ATen) and writes every element of GX [B][2*Ho][2*Wo][C].  C % 8 == 0. */
+int xq_maxpool2x2_nhwc_bf16_forward(const void *X, int B, int Ho, int Wo, int C, void *Y, xq_stream_t stream);
+int xq_maxpool2x2_nhwc_bf16_backward(const void *X, const void *G, int B, int Ho, int Wo, int C, void *GX, xq_stream_t stream);
+
 /* ---- multi-head self-attention on the packed qkv projection (dino_enc/vision_transformer.py:175-195: qkv.reshape(B,N,3,H,hd)
  *      .permute(2,0,3,1,4) -> F.scaled_dot_product_attention -> transpose(1,2).reshape(B,N,C); discriminator_dino.py:28).
  *      bf16 MFMA, fp32 softmax statistics, head_dim 64 only, no mask, no dropout. ------------------------------------------ */

@@ -371,3 +371,20 @@ def test_dinodisc_fused_heads_match_per_op(autocast):
             continue
         rel = ((ga.float() - gr.float()).norm() / gr.float().norm()).item()
         assert rel <= (0.12 if autocast else 2e-3), (tuple(gr.shape), rel)
+
+
+@pytest.mark.gpu
+def test_maxpool2x2_nhwc_matches_aten():
+    from imagefolder_amd import nn_ops, ops_dense
+    torch.manual_seed(2)
+    x = torch.relu(torch.randn(3, 64, 12, 20, device="cuda")).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    assert ops_dense.maxpool2x2_supported(x)
+    y = nn_ops.max_pool2x2(x)
+    g = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, g)
+    xr = x.detach().clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    (gr,) = torch.autograd.grad(yr, xr, g)
+    assert torch.equal(y, yr)
+    assert torch.equal(gx, gr)   # ties (post-ReLU zeros) go to the first window element, as ATen
