@@ -1,49 +1,32 @@
 """Dense-layer op table for the encoder/decoder (E1-E4 of SURVEY.md §8a).
 
-Every tensor op of the ViT / CNN encoder-decoder goes through one of these functions so that the
-implementation behind each can be swapped per op:
-  * "hip"  — hand-written gfx950 kernel from libxq_ops.so (through autograd Functions in ops_dense.py);
-  * "aten" — PyTorch-ROCm library op (hipBLASLt / MIOpen / CK); used for plain library GEMMs and as the
-             stand-in for ops whose HIP kernel has not landed yet.
-`IMPL[name]` says which one each op currently uses; `bench.py` reports the table in its config so a number is
+Every tensor op of the ViT / CNN encoder-decoder (and of the VQLoss networks) goes through one of these functions:
+  * "hip"     — hand-written gfx950 kernel from libxq_ops.so (through autograd Functions in ops_dense.py);
+  * "library" — PyTorch-ROCm library op (hipBLASLt / MIOpen / ATen): plain GEMMs by design, and the ops whose HIP
+                kernel has not landed yet (fp32 parity path, unsupported shapes).
+`IMPL[name]` records what each op last ran on; `bench.py` reports the table in its config so a number is
 never quoted without saying which ops were hand-written.  The fp32 numerics reference for every HIP op here is the
 ATen implementation of the same op (tests/test_dense_ops_gpu.py).
 """
 import torch
 import torch.nn.functional as F
 
-# op name -> "hip" | "aten"
+# op name -> what ran last ("hip": hand-written gfx950 kernel; "library": PyTorch-ROCm op = hipBLASLt / MIOpen / ATen).
+# Filled in by the dispatchers below as they execute, so bench.py reports what the timed step actually used.
 IMPL = {
-    "layer_norm": "aten",
-    "linear": "aten",            # plain GEMM (+bias): library GEMM (hipBLASLt) by design
-    "linear_gelu": "aten",
-    "attention": "aten",
-    "residual_scale_add": "aten",
-    "patch_embed": "aten",
-    "group_norm_silu": "aten",
-    "conv2d": "aten",
+    "layer_norm": "library",
+    "linear": "library (hipBLASLt GEMM)",   # plain GEMM (+bias): a library call by design
+    "gelu": "library",
+    "attention": "library (SDPA)",
+    "residual_scale_add": "library",
+    "patch_embed": "library (GEMM over patchified pixels)",
+    "group_norm_silu": "library",
+    "conv2d": "library (MIOpen)",
+    "max_pool2x2": "library",
 }
 
-_HIP = {}
-
-# ViT blocks as fused HIP row kernels + library GEMMs/SDPA (ops_dense.run_blocks) instead of per-op ATen calls
+# ViT blocks as fused HIP row kernels + attention kernels + library GEMMs (ops_dense.run_blocks) instead of per-op ATen calls
 FUSED_BLOCKS = True
-
-
-def register_hip(name, fn):
-    """ops_dense.py registers its autograd Functions here when libxq_ops.so provides the kernel."""
-    _HIP[name] = fn
-    IMPL[name] = "hip"
-
-
-def use(name, impl):
-    if impl == "hip" and name not in _HIP:
-        raise RuntimeError(f"no HIP kernel registered for {name}")
-    IMPL[name] = impl
-
-
-def _hip(name):
-    return _HIP[name] if IMPL.get(name) == "hip" else None
 
 
 def vit_blocks(blocks, x, final_norm):
@@ -53,16 +36,16 @@ def vit_blocks(blocks, x, final_norm):
         if ops_dense.fused_supported(x, blocks):
             act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
             IMPL["vit_block_rows"] = "hip"
+            IMPL["layer_norm"] = IMPL["residual_scale_add"] = "hip (fused residual + LayerScale + DropPath + LayerNorm rows)"
+            IMPL["gelu"] = "hip"
+            IMPL["linear"] = "library (hipBLASLt GEMM; split-K weight grads, bias grads from the hip row kernels)"
             return ops_dense.run_blocks(list(blocks), x, final_norm, act)
-    IMPL["vit_block_rows"] = "aten"
+    IMPL["vit_block_rows"] = "library (per-op)"
     x = blocks(x)
     return layer_norm(x, final_norm.weight, final_norm.bias, final_norm.eps)
 
 
 def layer_norm(x, weight, bias, eps):
-    f = _hip("layer_norm")
-    if f is not None and x.is_cuda:
-        return f(x, weight, bias, eps)
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
@@ -71,9 +54,6 @@ def linear(x, weight, bias=None):
 
 
 def linear_gelu(x, weight, bias=None):
-    f = _hip("linear_gelu")
-    if f is not None and x.is_cuda:
-        return f(x, weight, bias)
     return F.gelu(F.linear(x, weight, bias))
 
 
@@ -93,9 +73,6 @@ def attention_qkvpacked(qkv, num_heads):
 
 def residual_scale_add(x, y, gamma=None, mask=None):
     """x + drop_path_mask * (gamma * y)   (LayerScale + DropPath + residual of one transformer branch)"""
-    f = _hip("residual_scale_add")
-    if f is not None and x.is_cuda:
-        return f(x, y, gamma, mask)
     if gamma is not None:
         y = y * gamma
     if mask is not None:
@@ -136,7 +113,7 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
     if x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled("cuda")):
         from . import ops_dense
         if ops_dense.conv3x3_supported(x, weight, stride, padding):
-            IMPL["conv2d"] = "hip(3x3 s1 p1, C%64==0) + aten(rest)"
+            IMPL["conv2d"] = "hip (3x3 s1 p1, C % 64 == 0: fwd + data grad) + library (rest, weight grad)"
             return ops_dense.Conv3x3Fn.apply(x, weight, bias, relu)
         if ops_dense.conv3x3_small_cin_supported(x, weight, stride, padding):
             return ops_dense.Conv3x3SmallCinFn.apply(x, weight, bias, relu)
@@ -149,6 +126,7 @@ def max_pool2x2(x):
     if x.is_cuda:
         from . import ops_dense
         if ops_dense.maxpool2x2_supported(x):
+            IMPL["max_pool2x2"] = "hip"
             return ops_dense.MaxPool2x2Fn.apply(x)
     return F.max_pool2d(x, kernel_size=2, stride=2)
 
