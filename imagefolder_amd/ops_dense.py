@@ -281,8 +281,11 @@ def attention_supported(qkv, num_heads):
 def attention_qkvpacked(qkv, num_heads):
     """(B, N, 3*C) -> (B, N, C).  bf16 with head_dim 64: the hand-written kernels on the packed projection; anything else
     (the fp32 parity path): library SDPA on strided q/k/v views."""
+    from . import nn_ops
     if attention_supported(qkv, num_heads):
+        nn_ops.IMPL["attention"] = "hip"
         return AttentionFn.apply(qkv, num_heads)
+    nn_ops.IMPL["attention"] = "library (SDPA)"
     B, N, C3 = qkv.shape
     C = C3 // 3
     q, k, v = qkv.view(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)
