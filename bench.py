@@ -248,6 +248,21 @@ def main():
             entries.append({"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "flops_per_launch": work / n,
                             "avg_launch_ms": t_ms / n, "launches": n, "ms_per_step": t_ms / args.steps})
+        # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE, separate
+        # passes, gfx950 read correction applied: tools/pmc_traffic.py); null when that profile does not cover the kernel
+        traffic = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_kernel_hbm_traffic.json")) as fh:
+                traffic = json.load(fh).get("kernels", {})
+        except (OSError, ValueError):
+            pass
+        if full and CFG["name"] == "VQ-8192" and B == 128:   # the profile was taken on this workload
+            for e in entries:
+                keys = (["conv3x3"] if e["kernel"].startswith("conv3x3") else ["attn_fwd"] if e["kernel"].startswith("attn_fwd")
+                        else ["attn_bwd_dkdv", "attn_bwd_dq"] if e["kernel"].startswith("attn_delta") else ["assign"])
+                if all(k in traffic for k in keys):
+                    e["traffic"] = sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)
+                    e["traffic_source"] = "profiles/r01_kernel_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
         entries.sort(key=lambda e: -e["ms_per_step"])
         out["roofline"] = dict(entries[0], note="hand-written kernel with the most GPU time in the timed region "
                                                 "(HIP events on its launch stream); algorithmic flops / measured time")
