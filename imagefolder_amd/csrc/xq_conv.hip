@@ -226,6 +226,150 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 convolution: dWp[n][tap*Cin + c] += sum_m dY[m][n] * X[m shifted by tap][c]  (fp32).
+// GEMM view per tap: rows n (Cout), columns c (Cin), reduction over the pixels m.  Both operands are stored pixel-major
+// ([m][channels], NHWC), i.e. with the REDUCTION index as the slow axis; the MFMA wants 8 consecutive reduction indices
+// per lane, so both fragments come out of the row-major LDS tiles through the transpose read ds_read_b64_tr_b16 (lane =
+// channel, 4 consecutive pixels per read; the same register <-> pixel order on both operands).
+// Block = one tap x 128 n x 128 c over a contiguous range of 64-pixel tiles; 2 x 2 waves of 64 x 64; the partial tile is
+// added to dWp with fp32 atomics (dWp zero-initialised by the caller).  The shifted X rows use the forward's halo logic.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef short wg_s4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wg_s4 wg_tr4(const short *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s4 __attribute__((address_space(3))) *)p);
+}
+static constexpr int WG_PITCH = 136;   // 128 channels + 8: LDS row pitch in bf16 elements (272 bytes)
+#define WG_TFRAG(TRP, ROW0, COL0) __builtin_shufflevector(wg_tr4((TRP) + (ROW0) * WG_PITCH + (COL0)), wg_tr4((TRP) + ((ROW0) + 8) * WG_PITCH + (COL0)), 0, 1, 2, 3, 4, 5, 6, 7)
+
+__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16 *__restrict__ X, const __hip_bfloat16 *__restrict__ dY, long M,
+                                                            int H, int Wd, int Cin, int Cout, int tiles_per_split, int nsplit,
+                                                            float *__restrict__ dWp) {
+    __shared__ __attribute__((aligned(16))) short lds[2][2 * 64 * WG_PITCH];   // [buffer][dY tile | X tile], 64 pixels each
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int gn = Cout / 128, gc = Cin / 128;
+    // XCD-aware order: XCD k walks a contiguous range of work items; within a pixel split the 9 taps x channel tiles run
+    // back to back, so the dY / X rows of that pixel range stay in one L2
+    const long T = (long)nsplit * 9 * gn * gc, per_xcd = (T + 7) / 8;
+    const long tl = (long)(blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (tl >= T) return;
+    int rest = (int)(tl % (9 * gn * gc));
+    const int split = (int)(tl / (9 * gn * gc));
+    const int tap = rest / (gn * gc);
+    rest -= tap * gn * gc;
+    const int n0 = (rest / gc) * 128, c0 = (rest % gc) * 128;
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const long ntiles = (M + 63) / 64;
+    const long t_begin = (long)split * tiles_per_split;
+    long t_end = t_begin + tiles_per_split;
+    if (t_end > ntiles) t_end = ntiles;
+    if (t_begin >= t_end) return;
+
+    // staging: thread -> rows (tid/16) + 16*i (i = 0..3) of the 64-pixel tile, 16-byte chunk tid%16 of the 128 channels
+    const int srow = tid >> 4, spart = (tid & 15) * 8;
+    const int HWi = H * Wd;
+    uint4 ry0, ry1, ry2, ry3, rx0, rx1, rx2, rx3;
+    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+#define WG_LOAD_ROW(RY, RX, I, TILE)                                                                                   \
+    {                                                                                                                  \
+        const long m_ = (TILE) * 64 + srow + 16 * (I);                                                                 \
+        const bool okm = m_ < M;                                                                                       \
+        const long mm = okm ? m_ : 0;                                                                                  \
+        RY = *reinterpret_cast<const uint4 *>(dY + mm * Cout + n0 + spart);                                            \
+        if (!okm) RY = zero4;                                                                                          \
+        const int b_ = (int)mm / HWi;             /* M < 2^31 (checked by the launcher): 32-bit divisions */          \
+        const int rem_ = (int)mm - b_ * HWi;                                                                           \
+        const int y_ = rem_ / Wd, x_ = rem_ - y_ * Wd;                                                                 \
+        const int yy = y_ + dy, xx = x_ + dx;                                                                          \
+        const bool ok = okm && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                                \
+        RX = *reinterpret_cast<const uint4 *>(X + (((long)b_ * HWi + (ok ? yy * Wd + xx : 0)) * Cin + c0 + spart));    \
+        if (!ok) RX = zero4;                                                                                           \
+    }
+#define WG_LOAD(TILE) { WG_LOAD_ROW(ry0, rx0, 0, TILE) WG_LOAD_ROW(ry1, rx1, 1, TILE) WG_LOAD_ROW(ry2, rx2, 2, TILE) WG_LOAD_ROW(ry3, rx3, 3, TILE) }
+#define WG_STORE(BUF)                                                                                                  \
+    {                                                                                                                  \
+        short *Yt = lds[BUF] + srow * WG_PITCH + spart, *Xt = Yt + 64 * WG_PITCH;                                      \
+        *reinterpret_cast<uint4 *>(Yt) = ry0;                                                                          \
+        *reinterpret_cast<uint4 *>(Yt + 16 * WG_PITCH) = ry1;                                                          \
+        *reinterpret_cast<uint4 *>(Yt + 32 * WG_PITCH) = ry2;                                                          \
+        *reinterpret_cast<uint4 *>(Yt + 48 * WG_PITCH) = ry3;                                                          \
+        *reinterpret_cast<uint4 *>(Xt) = rx0;                                                                          \
+        *reinterpret_cast<uint4 *>(Xt + 16 * WG_PITCH) = rx1;                                                          \
+        *reinterpret_cast<uint4 *>(Xt + 32 * WG_PITCH) = rx2;                                                          \
+        *reinterpret_cast<uint4 *>(Xt + 48 * WG_PITCH) = rx3;                                                          \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const int hh = lane >> 5;
+    const int troff = (4 * hh + ((lane & 15) >> 2)) * WG_PITCH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    WG_LOAD(t_begin)
+    WG_STORE(0)
+    __syncthreads();
+    for (long t = t_begin; t < t_end; ++t) {
+        const int cur = (int)((t - t_begin) & 1);
+        if (t + 1 < t_end) WG_LOAD(t + 1)
+        const short *Yt = lds[cur] + troff + wn * 64, *Xt = lds[cur] + 64 * WG_PITCH + troff + wc * 64;
+#pragma unroll
+        for (int kk = 0; kk < 64; kk += 16) {
+            const bf16x8 a0 = WG_TFRAG(Yt, kk, 0), a1 = WG_TFRAG(Yt, kk, 32);
+            const bf16x8 b0 = WG_TFRAG(Xt, kk, 0), b1 = WG_TFRAG(Xt, kk, 32);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (t + 1 < t_end) WG_STORE(cur ^ 1)
+        __syncthreads();
+    }
+#undef WG_LOAD_ROW
+#undef WG_LOAD
+#undef WG_STORE
+
+    // D[i = n][j = c]: column c = lane & 31, row n = (r & 3) + 8 * (r >> 2) + 4 * hh
+    const long K9 = 9L * Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = c0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + wn * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                atomicAdd(dWp + (long)n * K9 + (long)tap * Cin + c, acc[i][j][r]);
+            }
+        }
+}
+
+extern "C" int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, int H, int W, int Cin, int Cout, float *dWp,
+                                          xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_wgrad_nhwc_bf16";
+    if (B == 0) return XQ_OK;
+    if (!X || !dY || !dWp) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (Cin % 128 != 0 || Cout % 128 != 0)
+        return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 128 == 0 and Cout %% 128 == 0 (got %ld, %ld)", fn, Cin, Cout);
+    const long M = (long)B * H * W;
+    if (M >= (1L << 31)) return xq_set_error(XQ_EINVAL, "%s: B*H*W must be below 2^31", fn);
+    const long ntiles = (M + 63) / 64;
+    const long base = 9L * (Cout / 128) * (Cin / 128);
+    long nsplit = (4L * num_cus() + base - 1) / base;   // ~4 blocks per CU in total
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    const long tps = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + tps - 1) / tps;
+    const long T = nsplit * base;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(((T + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, H, W, Cin, Cout, (int)tps, (int)nsplit, dWp);
+    return xq_check_launch(fn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // MaxPool2d(kernel 2, stride 2) on NHWC bf16 (the four pools of the VGG16 trunk, lpips.py:118-155 via torchvision's cfg).
 // Forward: 4 x 16-byte reads -> one 16-byte write per 8 channels.  Backward: recomputes the arg-max from the saved input
 // (first maximum in (0,0),(0,1),(1,0),(1,1) order, as ATen's strict '>' scan) instead of reading an int64 index per

@@ -398,6 +398,22 @@ def _conv3x3_call(x_cl, wp, bias, Cout, relu):
     return y
 
 
+def conv3x3_weight_grad(x_cl, g, weight):
+    """dW of the 3x3 / stride 1 / pad 1 conv from channels-last bf16 x and dY: the hand-written transpose-read MFMA kernel
+    (fp32 accumulation, csrc/xq_conv.hip) when both channel counts are multiples of 128, else the library wgrad."""
+    Cout, Cin = weight.shape[0], weight.shape[1]
+    if Cin % 128 == 0 and Cout % 128 == 0:
+        B, _, H, W = x_cl.shape
+        dwp = torch.zeros(Cout, 9 * Cin, dtype=torch.float32, device=x_cl.device)
+        with torch.cuda.device(x_cl.device):
+            rc = _lib.lib().xq_conv3x3_wgrad_nhwc_bf16(ptr(x_cl), ptr(g), B, H, W, Cin, Cout, ptr(dwp), _stream(x_cl))
+        check(rc, "xq_conv3x3_wgrad_nhwc_bf16")
+        return dwp.view(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3).to(weight.dtype)
+    _, g_w, _ = torch.ops.aten.convolution_backward(g, x_cl, weight.detach().to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
+                                                    False, [0, 0], 1, [False, True, False])
+    return g_w.to(weight.dtype)
+
+
 class Conv3x3Fn(torch.autograd.Function):
     """y = [relu](conv3x3(x, W) + b), stride 1, pad 1, bf16 NHWC, hand-written implicit-GEMM kernel both ways for the
     activations; the weight gradient (only needed for the trainable CNN encoder/decoder) uses the library wgrad."""
@@ -423,9 +439,7 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             g_x = _conv3x3_call(g, _packed_conv_weight(weight, True), None, weight.shape[1], False).to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            _, g_w, _ = torch.ops.aten.convolution_backward(g, x_cl, weight.detach().to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
-                                                            False, [0, 0], 1, [False, True, False])
-            g_w = g_w.to(weight.dtype)
+            g_w = conv3x3_weight_grad(x_cl, g, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g_b = g.float().sum((0, 2, 3))
         return g_x, g_w, g_b, None
@@ -465,9 +479,7 @@ class Conv3x3SmallCinFn(torch.autograd.Function):
             wp = _packed_conv_weight(weight, True)
             g_x = _conv3x3_call(g, wp, None, wp.shape[0], False)[:, :Cin].to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            _, g_w, _ = torch.ops.aten.convolution_backward(g, x_cl, weight.detach().to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
-                                                            False, [0, 0], 1, [False, True, False])
-            g_w = g_w.to(weight.dtype)
+            g_w = conv3x3_weight_grad(x_cl, g, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             g_b = g.float().sum((0, 2, 3))
         return g_x, g_w, g_b, None

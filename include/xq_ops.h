@@ -208,6 +208,13 @@ int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad
 int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
                          void *Y, xq_stream_t stream);
 
+/* Weight gradient of the same convolution (the trainable CNN encoder/decoder, xqgan_model.py:454-622):
+ * dWp fp32 [Cout][9*Cin], k = (ky*3+kx)*Cin + c (the forward's packed order), ACCUMULATED with fp32 atomics — the caller
+ * zero-initialises it and permutes to [Cout][Cin][3][3].  X [B][H][W][Cin], dY [B][H][W][Cout] bf16 NHWC.
+ * Cin % 128 == 0, Cout % 128 == 0. */
+int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, int H, int W, int Cin, int Cout, float *dWp,
+                               xq_stream_t stream);
+
 /* MaxPool2d(kernel_size=2, stride=2) of the VGG16 trunk (lpips.py:118-155), NHWC bf16, even input height/width:
  * X [B][2*Ho][2*Wo][C] -> Y [B][Ho][Wo][C]; the backward recomputes the arg-max from X (first maximum in row-major window
  * order, as ATen) and writes every element of GX [B][2*Ho][2*Wo][C].  C % 8 == 0. */

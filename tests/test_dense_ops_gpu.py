@@ -388,3 +388,22 @@ def test_maxpool2x2_nhwc_matches_aten():
     (gr,) = torch.autograd.grad(yr, xr, g)
     assert torch.equal(y, yr)
     assert torch.equal(gx, gr)   # ties (post-ReLU zeros) go to the first window element, as ATen
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 12, 12), (1, 256, 128, 7, 9), (3, 128, 256, 16, 8)])
+def test_conv3x3_weight_grad_kernel(B, Cin, Cout, H, W):
+    """the transpose-read MFMA weight-gradient kernel vs fp32 autograd on the same bf16-rounded operands"""
+    from imagefolder_amd import ops_dense
+    torch.manual_seed(B * 100 + Cin)
+    dev = "cuda"
+    x = torch.randn(B, Cin, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    g = torch.randn(B, Cout, H, W, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev)
+    gw = ops_dense.conv3x3_weight_grad(x, g, w)
+    wr = w.clone().requires_grad_(True)
+    y = F.conv2d(x.float(), wr, None, padding=1)
+    (gr,) = torch.autograd.grad(y, wr, g.float())
+    assert gw.shape == gr.shape
+    err = (gw - gr).abs().max().item()
+    assert err <= 2e-3 * max(1.0, gr.abs().max().item()), (err, gr.abs().max().item())

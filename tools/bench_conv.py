@@ -20,3 +20,16 @@ for B, Cin, Cout, HW in shapes:
         t1 = bench(lambda: Conv3x3Fn.apply(x, w, b, True))
         t2 = bench(lambda: torch.relu(F.conv2d(x, wb, b.to(torch.bfloat16), padding=1)))
     print(f"B{B} {Cin}->{Cout} @{HW}: xq {t1*1e3:7.3f} ms {fl/t1/1e12:6.1f} TF/s | miopen {t2*1e3:7.3f} ms {fl/t2/1e12:6.1f} TF/s", flush=True)
+
+# weight gradient: hand-written transpose-read kernel vs the library wgrad (CNN encoder/decoder shapes)
+from imagefolder_amd.ops_dense import conv3x3_weight_grad
+if "--wgrad" in sys.argv:
+    for B, Cin, Cout, HW in [(8, 128, 128, 256), (8, 128, 256, 128), (8, 256, 256, 128), (16, 256, 256, 64), (16, 512, 512, 32), (16, 512, 512, 16)]:
+        x = torch.randn(B, Cin, HW, HW, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        g = torch.randn(B, Cout, HW, HW, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05
+        wb = w.to(torch.bfloat16)
+        fl = 2.0 * B * HW * HW * Cin * Cout * 9
+        t1 = bench(lambda: conv3x3_weight_grad(x, g, w))
+        t2 = bench(lambda: torch.ops.aten.convolution_backward(g, x, wb, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+        print(f"wgrad B{B} {Cin}->{Cout} @{HW}: xq {t1*1e3:7.3f} ms {fl/t1/1e12:6.1f} TF/s | miopen {t2*1e3:7.3f} ms {fl/t2/1e12:6.1f} TF/s", flush=True)
