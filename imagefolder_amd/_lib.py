@@ -62,6 +62,11 @@ SIGNATURES = {
     "xq_attn_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
     "xq_attn_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                         vp, vp, vp]),
+    "xq_groupnorm_workspace_floats": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "xq_groupnorm_silu_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+                                                 ctypes.c_int, vp, vp, vp, vp, vp]),
+    "xq_groupnorm_silu_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, vp, vp, ctypes.POINTER(ctypes.c_int), vp, vp]),
     "xq_bnlocal_lrelu_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float,
                                                 ctypes.c_float, ctypes.c_float, vp, vp, vp, vp]),
     "xq_bnlocal_lrelu_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,

@@ -98,6 +98,12 @@ def conv1x1(x, weight, bias=None):
 
 
 def group_norm_silu(x, groups, weight, bias, eps, silu=True):
+    """GroupNorm [+ x * sigmoid(x)]: hand-written NHWC bf16 kernels (csrc/xq_gn.hip) under bf16 autocast on the GPU."""
+    if x.is_cuda:
+        from . import ops_dense
+        if ops_dense.groupnorm_supported(x, groups):
+            IMPL["group_norm_silu"] = "hip"
+            return ops_dense.GroupNormSiluFn.apply(x, groups, weight, bias, eps, silu)
     y = F.group_norm(x, groups, weight, bias, eps)
     return y * torch.sigmoid(y) if silu else y
 

@@ -641,3 +641,53 @@ class MaxPool2x2Fn(torch.autograd.Function):
             rc = _lib.lib().xq_maxpool2x2_nhwc_bf16_backward(ptr(xc), ptr(g), B, H // 2, W // 2, C, ptr(gx), _stream(xc))
         check(rc, "xq_maxpool2x2_nhwc_bf16_backward")
         return gx
+
+
+# ---- GroupNorm (+ SiLU) on channels-last bf16 (CNN encoder/decoder, csrc/xq_gn.hip) --------------------------------------
+def groupnorm_supported(x, groups):
+    if not (x.is_cuda and x.dim() == 4):
+        return False
+    C = x.shape[1]
+    return (C % 8 == 0 and C <= 1024 and 256 % (C // 8) == 0 and C % groups == 0 and (C // groups) % 4 == 0 and groups <= 64
+            and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled("cuda")))
+
+
+class GroupNormSiluFn(torch.autograd.Function):
+    """y = [silu](GroupNorm(x)) with fp32 statistics, bf16 channels-last in and out (xqgan_model.py Normalize + nonlinearity)."""
+
+    @staticmethod
+    def forward(ctx, x, groups, weight, bias, eps, silu):
+        B, C, H, W = x.shape
+        x_cl = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        w = None if weight is None else weight.detach().float().contiguous()
+        b = None if bias is None else bias.detach().float().contiguous()
+        dev = x.device
+        y = torch.empty_like(x_cl)
+        mean = torch.empty(B * groups, dtype=torch.float32, device=dev)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(_lib.lib().xq_groupnorm_workspace_floats(B, H * W, C, groups), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().xq_groupnorm_silu_forward(ptr(x_cl), ptr(w), ptr(b), B, H * W, C, groups, float(eps), int(bool(silu)), ptr(y),
+                                                      ptr(mean), ptr(rstd), ptr(ws), _stream(x_cl))
+        check(rc, "xq_groupnorm_silu_forward")
+        ctx.save_for_backward(x_cl, w, b, mean, rstd)
+        ctx.cfg = (groups, bool(silu), x.dtype, weight is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x_cl, w, b, mean, rstd = ctx.saved_tensors
+        groups, silu, in_dtype, has_w, has_b = ctx.cfg
+        B, C, H, W = x_cl.shape
+        dev = x_cl.device
+        g = g.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(x_cl)
+        part = torch.empty(B * 64, 2, C, dtype=torch.float32, device=dev)
+        ws = torch.empty(_lib.lib().xq_groupnorm_workspace_floats(B, H * W, C, groups), dtype=torch.float32, device=dev)
+        rows = ctypes.c_int(0)
+        with torch.cuda.device(dev):
+            rc = _lib.lib().xq_groupnorm_silu_backward(ptr(x_cl), ptr(g), ptr(w), ptr(b), ptr(mean), ptr(rstd), B, H * W, C, groups, int(silu),
+                                                       ptr(dx), ptr(part), ctypes.byref(rows), ptr(ws), _stream(x_cl))
+        check(rc, "xq_groupnorm_silu_backward")
+        sums = part[:rows.value].sum(0)
+        return dx.to(in_dtype), None, (sums[1] if has_w else None), (sums[0] if has_b else None), None, None

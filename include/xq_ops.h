@@ -233,6 +233,19 @@ int xq_attn_forward(const void *qkv, int B, int N, int H, int head_dim, float sc
 int xq_attn_backward(const void *qkv, const void *out, const void *dout, const float *lse, int B, int N, int H, int head_dim,
                      float scale, void *dqkv, float *delta, xq_stream_t stream);
 
+/* ---- GroupNorm (+ SiLU) of the CNN encoder/decoder (xqgan_model.py:625-672 Normalize + nonlinearity), NHWC bf16 ---------------
+ * y = silu?((x - mean_{b,g}) * rstd_{b,g} * w_c + b_c), statistics in fp32 over HW x (C/G) elements (biased variance, two-pass).
+ * x, y: bf16 [B][HW][C]; w, b fp32 [C] (nullable); mean, rstd: fp32 [B][G] outputs kept for the backward.
+ * Geometry: C % 8 == 0, 256 % (C/8) == 0, C <= 1024, (C/G) % 4 == 0, G <= 64.  workspace: xq_groupnorm_workspace_floats floats. */
+size_t xq_groupnorm_workspace_floats(int B, int HW, int C, int G);
+int xq_groupnorm_silu_forward(const void *x, const float *w, const float *bias, int B, int HW, int C, int G, float eps, int silu,
+                              void *y, float *mean, float *rstd, float *workspace, xq_stream_t stream);
+/* dx bf16 [B][HW][C]; g_wb_partials fp32 [rows][2][C] with rows = *n_partial_rows <= B * 64: row-wise partial sums of the bias
+ * ([.][0][c]) and weight ([.][1][c]) gradients, to be summed over the first axis by the caller. */
+int xq_groupnorm_silu_backward(const void *x, const void *dy, const float *w, const float *bias, const float *mean,
+                               const float *rstd, int B, int HW, int C, int G, int silu, void *dx, float *g_wb_partials,
+                               int *n_partial_rows, float *workspace, xq_stream_t stream);
+
 /* ---- DinoDisc discriminator heads (discriminator_dino.py:113-166), token-major activations [B][L][C] --------------------
  * BatchNormLocal (:127-154: statistics over virtual batches of 8 samples, i.e. groups of rows_per_group = 8*L consecutive
  * token rows, biased variance, eps inside the sqrt) + LeakyReLU(slope) [+ ResidualBlock: (. + skip) * ratio, :113-119]. */

@@ -407,3 +407,28 @@ def test_conv3x3_weight_grad_kernel(B, Cin, Cout, H, W):
     assert gw.shape == gr.shape
     err = (gw - gr).abs().max().item()
     assert err <= 2e-3 * max(1.0, gr.abs().max().item()), (err, gr.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W,silu", [(2, 128, 16, 12, True), (3, 256, 9, 7, True), (1, 512, 8, 8, False), (2, 128, 64, 64, True)])
+def test_groupnorm_silu_kernels(B, C, H, W, silu):
+    from imagefolder_amd import nn_ops
+    torch.manual_seed(C + H)
+    dev = "cuda"
+    x = (torch.randn(B, C, H, W, device=dev) * 1.5 + 0.3).requires_grad_(True)
+    w = (1 + 0.2 * torch.randn(C, device=dev)).requires_grad_(True)
+    b = (0.1 * torch.randn(C, device=dev)).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = nn_ops.group_norm_silu(x, 32, w, b, 1e-6, silu=silu)
+    assert y.dtype == torch.bfloat16 and nn_ops.IMPL["group_norm_silu"] == "hip"
+    g = torch.randn_like(y, dtype=torch.float32)
+    gx, gw, gb = torch.autograd.grad(y.float(), (x, w, b), g)
+    xr = x.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr, br = w.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = F.group_norm(xr, 32, wr, br, 1e-6)
+    yr = yr * torch.sigmoid(yr) if silu else yr
+    gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), g.to(torch.bfloat16).float())
+    assert (y.float() - yr).abs().max().item() <= 2e-2 * max(1.0, yr.abs().max().item())
+    assert (gx - gxr).abs().max().item() <= 2e-2 * max(1.0, gxr.abs().max().item())
+    assert ((gw - gwr).norm() / gwr.norm()).item() <= 1e-2
+    assert ((gb - gbr).norm() / gbr.norm()).item() <= 1e-2
