@@ -45,6 +45,8 @@ CONFIGS = {
     "VQ-4096": dict(name="VQ-4096", B=128, C=64, V=4096, L=256, P=1, pns=[16], enc="dinov2", drop=0.0, half_sem=False, alpha=0.0, beta_lp=0.0, delta=100),
     "VP2-16384": dict(name="VP2-16384", B=128, C=32, V=16384, L=256, P=2, pns=[16], enc="dinov2", drop=0.1, half_sem=True, alpha=0.0, beta_lp=0.0, delta=100),
     "MSVR10P2-4096": dict(name="MSVR10P2-4096", B=128, C=32, V=4096, L=121, P=2, pns=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11], enc="dinov2", drop=0.1, half_sem=True, alpha=0.0, beta_lp=0.0, delta=100),
+    # not a BASELINE.json config: the reference's MSBR10P2-4096.yaml (LFQ / BSQ sign quantizer, 12 bit channels)
+    "MSBR10P2-4096": dict(name="MSBR10P2-4096", B=128, C=12, V=4096, L=121, P=2, pns=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11], enc="dinov2", drop=0.1, half_sem=True, alpha=0.0, beta_lp=0.0, delta=100, lfq=True),
     "RobustTok": dict(name="RobustTok", B=128, C=64, V=4096, L=256, P=1, pns=[16], enc="dinov2", drop=0.0, half_sem=False, alpha=1.0, beta_lp=0.1, delta=100),
 }
 CFG = dict(CONFIGS["VQ-8192"], beta=0.25)
@@ -98,7 +100,8 @@ def build_train_step(args, dev, world):
                                num_latent_tokens=CFG["L"], encoder_model="vit_base_patch14_dinov2.lvd142m",
                                decoder_model="vit_base_patch14_dinov2.lvd142m", abs_pos_embed=True, product_quant=CFG["P"],
                                share_quant_resi=4, codebook_drop=CFG["drop"], half_sem=CFG["half_sem"], start_drop=3,
-                               sem_loss_weight=0.1, guide_type_1="class").to(dev).train()
+                               sem_loss_weight=0.1, guide_type_1="class", lfq=bool(CFG.get("lfq", False)),
+                               entropy_loss_ratio=0.1 if CFG.get("lfq") else 0.0).to(dev).train()
     gbs = args.batch * world
     lr, disc_lr = 3e-5 * gbs / 128, 1e-4 * gbs / 128  # yaml lr 3e-5, default disc_lr 1e-4, both x global_batch/128 (:338-339)
     if args.loss == "full":

@@ -205,6 +205,19 @@ extern "C" size_t xq_msvq_workspace_bytes(int B, int C, int H, int W, int V) {
     return ms_ws_layout(B, C, H, W, V, nullptr, nullptr);
 }
 
+// LFQ code of every token: bit c of idx = [tok_c > 0]; tok is [B][C][tHW]
+__global__ __launch_bounds__(256) void lfq_sign_idx_kernel(const float *__restrict__ tok, long Ns, int C, int tHW, int bits,
+                                                           int64_t *__restrict__ idx, float *__restrict__ hist) {
+    const long n = (long)blockIdx.x * 256 + threadIdx.x;
+    if (n >= Ns) return;
+    const long b = n / tHW, p = n - b * tHW;
+    int64_t id = 0;
+    for (int c = 0; c < bits; ++c)
+        if (tok[((size_t)b * C + c) * tHW + p] > 0.0f) id |= ((int64_t)1 << c);
+    idx[n] = id;
+    if (hist) atomicAdd(hist + id, 1.0f);
+}
+
 extern "C" int xq_msvq_forward(const float *f, int B, int C, int H, int W, const float *E, int V, int using_znorm,
                                const int32_t *patch_nums, int SN, const int32_t *phi_sel, const float *phi_w,
                                const float *phi_b, float phi_ratio, int n_phi, const float *n_quant, int skip_last_pool,
@@ -234,8 +247,17 @@ extern "C" int xq_msvq_forward(const float *f, int B, int C, int H, int W, const
     const int mode = using_znorm ? XQ_MODE_COSINE : XQ_MODE_L2_RAW;
 
     hipLaunchKernelGGL(ms_init_kernel, dim3(eb), dim3(256), 0, s, f, total, ws.f_rest, f_hat, ws.sq_acc, SN);
-    rc = launch_assign(mode, C, f, 0, 1, E, V, ws.aw, s, XQI_PREP);  // codebook prepared once for all scales
-    if (rc) return rc;
+    // using_znorm == 2: LFQ sign quantisation (lookup_free_quantize.py:182-183): the code is the sign pattern of the pooled
+    // residual, idx = sum_c [x_c > 0] << c over the log2(V) bit channels; E holds the +-scale corners in that order
+    const bool sign_mode = using_znorm == 2;
+    int sign_bits = 0;
+    while ((1 << sign_bits) < V) ++sign_bits;
+    if (sign_mode && ((1 << sign_bits) != V || sign_bits > C))
+        return xq_set_error(XQ_EINVAL, "%s: sign quantisation needs V = 2^bits with bits <= C (V=%ld, C=%ld)", "xq_msvq_forward", V, C);
+    if (!sign_mode) {
+        rc = launch_assign(mode, C, f, 0, 1, E, V, ws.aw, s, XQI_PREP);  // codebook prepared once for all scales
+        if (rc) return rc;
+    }
     size_t ioff = 0;
     for (int si = 0; si < SN; ++si) {
         const int pn = patch_nums[si];
@@ -248,10 +270,15 @@ extern "C" int xq_msvq_forward(const float *f, int B, int C, int H, int W, const
             tok = ws.pooled;
             tHW = pn * pn;
         }
-        rc = launch_assign(mode, C, tok, Ns, tHW, E, V, ws.aw, s, XQI_SEARCH);
-        if (rc) return rc;
-        hipLaunchKernelGGL(ms_keys_to_idx_kernel, dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s, ws.aw.keys, Ns, idx_all + ioff,
-                           hist ? hist + (size_t)si * V : nullptr);
+        if (sign_mode) {
+            hipLaunchKernelGGL(lfq_sign_idx_kernel, dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s, tok, Ns, C, tHW, sign_bits,
+                               idx_all + ioff, hist ? hist + (size_t)si * V : nullptr);
+        } else {
+            rc = launch_assign(mode, C, tok, Ns, tHW, E, V, ws.aw, s, XQI_SEARCH);
+            if (rc) return rc;
+            hipLaunchKernelGGL(ms_keys_to_idx_kernel, dim3((unsigned)((Ns + 255) / 256)), dim3(256), 0, s, ws.aw.keys, Ns, idx_all + ioff,
+                               hist ? hist + (size_t)si * V : nullptr);
+        }
         Taps ty, tx;
         const int bic = (si != SN - 1);
         if (bic) { make_taps(pn, H, &ty); make_taps(pn, W, &tx); } else { ty = Taps(); tx = Taps(); }

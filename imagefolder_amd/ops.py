@@ -217,7 +217,7 @@ def msvq_forward_raw(f, codebook, patch_nums, phi_sel, phi_w, phi_b, phi_ratio, 
     nbytes = _lib.lib().xq_msvq_workspace_bytes(B, C, H, W, V)
     ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        rc = _lib.lib().xq_msvq_forward(ptr(f32), B, C, H, W, ptr(E), V, int(bool(using_znorm)), _i32_array(patch_nums), SN,
+        rc = _lib.lib().xq_msvq_forward(ptr(f32), B, C, H, W, ptr(E), V, (2 if using_znorm == 2 else int(bool(using_znorm))), _i32_array(patch_nums), SN,
                                         _i32_array(phi_sel if n_phi else [0] * SN), ptr(pw), ptr(pb),
                                         ctypes.c_float(float(phi_ratio)), n_phi, ptr(nq), int(bool(skip_last_pool)),
                                         ptr(out["idx_all"]), ptr(out["f_hat"]), ptr(out["f_hat_ste"]), ptr(out["h_scales"]),
@@ -251,10 +251,14 @@ class MSVQLadder(torch.autograd.Function):
             saved.append(n_quant.detach().float().contiguous().to(f.device))
         ctx.save_for_backward(*saved)
         ctx.mark_non_differentiable(r["idx_all"], r["hist"])
+        if cfg.get("return_h"):   # the (detached) per-scale contributions h_s, for losses built on f_hat of earlier scales (LFQ)
+            h = r["h_scales"].detach()
+            ctx.mark_non_differentiable(h)
+            return r["f_hat_ste"], r["sq_sum"], r["sq_sum"].clone(), r["idx_all"], r["hist"], h
         return r["f_hat_ste"], r["sq_sum"], r["sq_sum"].clone(), r["idx_all"], r["hist"]
 
     @staticmethod
-    def backward(ctx, g_out, g_sq_vq, g_sq_commit, _gi, _gh):
+    def backward(ctx, g_out, g_sq_vq, g_sq_commit, _gi, _gh, *_unused):
         saved = list(ctx.saved_tensors)
         f32, weight, idx_all, h_scales = saved[:4]
         pos = 4

@@ -159,7 +159,8 @@ class _Affine(nn.Module):
 class VQModel(nn.Module):
     """Drop-in for reference VQModel (xqgan_model.py:75-451): encoder -> quant_conv -> (product) quantizer(s)
     [+ latent perturbation] -> post_quant_conv -> decoder, plus the frozen-DINOv2 semantic regulariser.
-    Not mirrored (never enabled by the BASELINE yamls): lfq=True (LFQ/BSQ), detail_guide != 'none'
+    lfq=True builds the LFQ/BSQ sign quantizer (lookup_free_quantize.py).
+    Not mirrored (never enabled by the BASELINE yamls): detail_guide != 'none'
     (needs the CLIP ViT-B checkpoint)."""
 
     def __init__(self, config: ModelArgs):
@@ -197,8 +198,12 @@ class VQModel(nn.Module):
                                          cond_latent=False, abs_pos_embed=config.abs_pos_embed)
             self.post_quant_conv = nn.Conv2d(config.codebook_embed_dim, self.decoder.embed_dim, 1)
 
-        if config.lfq:
-            raise NotImplementedError("LFQ/BSQ quantizer (MSBR yamls) is not on the BASELINE hot path yet (SURVEY §8a Q7)")
+        def make_lfq(num_latent_tokens):   # xqgan_model.py:136-144 / :157-165
+            from .lookup_free_quantize import LFQ
+            return LFQ(config.codebook_size, config.codebook_embed_dim, v_patch_nums=config.v_patch_nums,
+                       num_latent_tokens=num_latent_tokens, share_quant_resi=config.share_quant_resi,
+                       codebook_drop=config.codebook_drop, using_znorm=config.codebook_l2_norm, scale=config.scale,
+                       entropy_weight=config.entropy_loss_ratio, soft_entropy=config.soft_entropy)
         self.V = self.vocab_size = config.codebook_size * self.product_quant
         self.Cvae = config.codebook_embed_dim * self.product_quant
         single_scale = len(config.v_patch_nums) == 1
@@ -207,23 +212,28 @@ class VQModel(nn.Module):
                 self.quantizes = nn.ModuleList([
                     VectorQuantizer(config.codebook_size, config.codebook_embed_dim, config.commit_loss_beta,
                                     config.codebook_l2_norm) for _ in range(self.product_quant)])
-            else:
+            elif not config.lfq:
                 self.quantizes = nn.ModuleList([
                     VectorQuantizer2(config.codebook_size, config.codebook_embed_dim, v_patch_nums=config.v_patch_nums,
                                      num_latent_tokens=config.num_latent_tokens // self.product_quant,
                                      share_quant_resi=config.share_quant_resi, codebook_drop=config.codebook_drop)
                     for _ in range(self.product_quant)])
+            else:
+                self.quantizes = nn.ModuleList([make_lfq(config.num_latent_tokens // self.product_quant)
+                                                for _ in range(self.product_quant)])
             out_dim = self.decoder.embed_dim if config.dec_type == 'dinov2' else config.z_channels
             self.post_quant_conv = nn.Conv2d(config.codebook_embed_dim * self.product_quant, out_dim, 1)
         else:
             if single_scale:
                 self.quantize = VectorQuantizer(config.codebook_size, config.codebook_embed_dim, config.commit_loss_beta,
                                                 config.codebook_l2_norm)
-            else:
+            elif not config.lfq:
                 self.quantize = VectorQuantizer2(config.codebook_size, config.codebook_embed_dim,
                                                  v_patch_nums=config.v_patch_nums,
                                                  num_latent_tokens=config.num_latent_tokens,
                                                  share_quant_resi=config.share_quant_resi)
+            else:
+                self.quantize = make_lfq(config.num_latent_tokens)
 
         self.codebook_embed_dim = config.codebook_embed_dim
         self.v_patch_nums = config.v_patch_nums

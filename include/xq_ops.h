@@ -117,6 +117,8 @@ size_t xq_msvq_workspace_bytes(int B, int C, int H, int W, int V);
  *   post-/pre-Phi maps kept for the backward; sq_sum (nullable) [SN] = sum mask*(f_hat_s - f)^2 (:131-132 numerators);
  *   hist (nullable) [SN][V] ACCUMULATES bincounts (:102); f_hat_scales (nullable) [SN][B][C][H][W] cumulative f_hat (:221).
  */
+/* using_znorm: 0 = nearest code in raw L2 (quant.py:96-101), 1 = cosine (:93-94), 2 = LFQ sign quantisation
+ * (lookup_free_quantize.py:182-183, :254-268): idx = sum_c [x_c > 0] << c over log2(V) bit channels, E = the +-scale corners. */
 int xq_msvq_forward(const float *f, int B, int C, int H, int W, const float *E, int V, int using_znorm,
                     const int32_t *patch_nums, int SN, const int32_t *phi_sel, const float *phi_w, const float *phi_b,
                     float phi_ratio, int n_phi, const float *n_quant, int skip_last_pool, int64_t *idx_all, float *f_hat,

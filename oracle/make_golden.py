@@ -120,6 +120,39 @@ def gen_msvq(name, V, C, B, pns, seed, codebook_drop=0.1, start_drop=3, using_zn
     print("wrote", name, "vq", vq.item(), "commit", float(commit), "usages", [round(u, 2) for u in usages][:4])
 
 
+def gen_lfq(name, Cbits, B, pns, seed, codebook_drop=0.1, start_drop=3, using_znorm=True, share=4, entropy_weight=0.1):
+    """LFQ.forward/backward (lookup_free_quantize.py:149-250) in train mode with quantizer dropout + f_to_idxBl_or_fhat."""
+    R = load_reference()
+    torch.manual_seed(seed)
+    H = W = pns[-1]
+    V = 2 ** Cbits
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):   # the constructor prints the scaler
+        q = R["LFQ"](V, Cbits, using_znorm=using_znorm, v_patch_nums=list(pns), num_latent_tokens=H * W, share_quant_resi=share,
+                     codebook_drop=codebook_drop, scale=1.0, entropy_weight=entropy_weight, soft_entropy=True).train()
+    f = (torch.randn(B, Cbits, H, W) * 0.6).requires_grad_(True)
+    dropout = torch.randint(start_drop, len(pns) + 1, (B,))
+    f_hat, usages, vq, commit, ent = q(f, ret_usages=True, dropout=dropout)
+    g_out = torch.randn_like(f_hat) * 0.05
+    g_vq, g_commit, g_ent = 1.3, 0.7, 0.9
+    ((f_hat * g_out).sum() + vq * g_vq + commit * g_commit + ent * g_ent).backward()
+    with torch.no_grad():
+        idx_list = q.f_to_idxBl_or_fhat(f.detach(), to_fhat=False, v_patch_nums=None)
+        fhat_list = q.f_to_idxBl_or_fhat(f.detach(), to_fhat=True, v_patch_nums=None)
+    convs = list(q.quant_resi.qresi_ls)
+    np.savez(os.path.join(OUT, name + ".npz"), f=f.detach().numpy(), Cbits=np.int32(Cbits), pns=np.array(pns, np.int32),
+             using_znorm=np.int32(using_znorm), codebook_drop=np.float32(codebook_drop), share=np.int32(share),
+             entropy_weight=np.float32(entropy_weight), dropout=dropout.numpy().astype(np.int32),
+             phi_w=np.stack([c.weight.detach().numpy() for c in convs]), phi_b=np.stack([c.bias.detach().numpy() for c in convs]),
+             f_hat=f_hat.detach().numpy(), vq_loss=np.float32(vq.item()), commit_loss=np.float32(commit.item()),
+             entropy_loss=np.float32(ent.item()), usages=np.array(usages, np.float32), ema_hit=q.ema_vocab_hit_SV.numpy(),
+             idx=np.concatenate([i.reshape(-1).numpy() for i in idx_list]), fhat_last=fhat_list[-1].numpy(),
+             g_out=g_out.numpy(), g_vq=np.float32(g_vq), g_commit=np.float32(g_commit), g_ent=np.float32(g_ent),
+             g_f=f.grad.numpy(), g_phi_w=np.stack([c.weight.grad.numpy() for c in convs]),
+             g_phi_b=np.stack([c.bias.grad.numpy() for c in convs]), meta=np.array(str(meta())))
+    print("wrote", name, "vq", vq.item(), "commit", float(commit), "entropy", float(ent), "usages", [round(u, 2) for u in usages][:4])
+
+
 def gen_model(name, kw, seed):
     """VQModel.img_to_reconstructed_img + code indices (xqgan_model.py:367-403) with deterministic weights
     (oracle/det_init.py); eval mode (no DropPath), fp32 CPU = the reference CPU path of BASELINE config 1/2."""
@@ -156,6 +189,13 @@ def main():
                                                  num_latent_tokens=256, product_quant=1, abs_pos_embed=True,
                                                  encoder_model="vit_base_patch14_dinov2.lvd142m",
                                                  decoder_model="vit_base_patch14_dinov2.lvd142m"), seed=32)
+        if only:
+            return
+    if only in ("lfq", ""):
+        # MSBR10P2-4096 geometry (12 bit channels, 1x1 -> 11x11 ladder, codebook_l2_norm, codebook_drop 0.1, start_drop 3)
+        gen_lfq("lfq_msbr_c12_11grid_b6", 12, 6, [1, 1, 2, 3, 3, 4, 5, 6, 8, 11], seed=40)
+        # no z-norm, 14 bits (MSBR10P2-16384 width), heavier dropout, 16x16 grid (skips the last area-pool)
+        gen_lfq("lfq_raw_c14_16grid_b4", 14, 4, [1, 2, 3, 4, 6, 8, 11, 16], seed=41, using_znorm=False, codebook_drop=0.5, start_drop=2)
         if only:
             return
     if only in ("msvq", ""):

@@ -56,6 +56,7 @@ def load_reference():
         from tokenizer.tokenizer_image import xqgan_model as ref_model
         from tokenizer.tokenizer_image import quant as ref_quant
         from tokenizer.tokenizer_image import latent_perturbation as ref_lp
+        from tokenizer.tokenizer_image import lookup_free_quantize as ref_lfq
     spec = importlib.util.spec_from_file_location(
         "ref_models_quant", os.path.join(REF_ROOT, "models", "quant.py"))
     ref_var_quant = importlib.util.module_from_spec(spec)
@@ -68,6 +69,7 @@ def load_reference():
         VectorQuantizer=ref_model.VectorQuantizer, VectorQuantizer2=ref_quant.VectorQuantizer2,
         add_perturbation=ref_lp.add_perturbation, VQ_models=ref_model.VQ_models,
         Encoder=ref_model.Encoder, Decoder=ref_model.Decoder, VQModel=ref_model.VQModel,
+        lookup_free_quantize=ref_lfq, LFQ=ref_lfq.LFQ,
     )
     # keep the reference dirs on sys.path only as long as needed for lazy imports inside the
     # reference; restore ordering so HF `datasets` & co. are reachable again for other code.

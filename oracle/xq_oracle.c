@@ -382,7 +382,21 @@ void xqo_msvq_forward(const float *f, long B, int C, int H, int W, const float *
             xqo_area_pool(f_rest, B * C, H, W, pn, pn, pooled);
             tok = pooled; tHW = pn * pn;
         }
-        xqo_assign(tok, Ns, C, tHW, E, V, using_znorm ? XQ_MODE_COSINE : XQ_MODE_L2_RAW, idx_all + ioff, NULL);
+        if (using_znorm == 2) {
+            /* LFQ (lookup_free_quantize.py:182-183 / :254-268): code = sign pattern of the pooled residual,
+               idx = sum_c [x_c > 0] << c over the log2(V) bit channels; E holds the +-scale corners in that order */
+            int bits = 0;
+            while ((1 << bits) < V) ++bits;
+            for (long n = 0; n < Ns; ++n) {
+                const long b = n / tHW, p = n % tHW;
+                int64_t id = 0;
+                for (int c = 0; c < bits && c < C; ++c)
+                    if (tok[((size_t)b * C + c) * tHW + p] > 0.0f) id |= ((int64_t)1 << c);
+                idx_all[ioff + n] = id;
+            }
+        } else {
+            xqo_assign(tok, Ns, C, tHW, E, V, using_znorm ? XQ_MODE_COSINE : XQ_MODE_L2_RAW, idx_all + ioff, NULL);
+        }
         if (hist) for (long n = 0; n < Ns; ++n) hist[(size_t)si * V + idx_all[ioff + n]] += 1.0f;
         xqo_gather_nchw(E, C, idx_all + ioff, B, pn * pn, gath);
         if (si != SN - 1) xqo_bicubic_up(gath, B * C, pn, pn, H, W, hbuf);

@@ -6,7 +6,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name,batch", [("VQ-8192", 8), ("VQ-4096-cnn", 2), ("VP2-16384", 10), ("MSVR10P2-4096", 10), ("RobustTok", 10)])
+@pytest.mark.parametrize("name,batch", [("VQ-8192", 8), ("VQ-4096-cnn", 2), ("VP2-16384", 10), ("MSVR10P2-4096", 10), ("RobustTok", 10),
+                                        ("MSBR10P2-4096", 10)])
 def test_one_full_train_step(name, batch):
     import bench
 
