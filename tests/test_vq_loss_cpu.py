@@ -142,3 +142,25 @@ def test_single_backward_generator_loss_equals_upstream_formulation():
     scale = max(b.abs().max().item() for b in res[1][3])  # conv biases in front of a BatchNorm have an exactly-zero gradient:
     for a, b in zip(res[0][3], res[1][3]):                  # compare against the global head-gradient scale, not per tensor
         assert (a - b).abs().max().item() <= 1e-4 * scale
+
+
+def test_diffaug_translation_is_the_upstream_padded_gather():
+    """the zero-filled shift (one gather forward, the opposite shift backward) == upstream's pad + clamped advanced indexing
+    (diffaug.py:72-80), values and gradients bit for bit"""
+    import torch.nn.functional as F
+    from imagefolder_amd.vq_loss import _ShiftZeroFill
+    torch.manual_seed(0)
+    B, C, H, W = 5, 3, 16, 12
+    x = torch.randn(B, C, H, W, requires_grad=True)
+    th = torch.randint(-3, 4, (B, 1, 1))
+    tw = torch.randint(-3, 4, (B, 1, 1))
+    gb, gh, gw = torch.meshgrid(torch.arange(B), torch.arange(H), torch.arange(W), indexing='ij')
+    gh2 = (gh + th).add(1).clamp(0, H + 1)
+    gw2 = (gw + tw).add(1).clamp(0, W + 1)
+    pad = F.pad(x, [1, 1, 1, 1, 0, 0, 0, 0])
+    ref = pad.permute(0, 2, 3, 1).contiguous()[gb, gh2, gw2].permute(0, 3, 1, 2).contiguous()
+    g = torch.randn_like(ref)
+    (gr,) = torch.autograd.grad(ref, x, g)
+    out = _ShiftZeroFill.apply(x, th.view(B), tw.view(B))
+    (go,) = torch.autograd.grad(out, x, g)
+    assert torch.equal(out, ref) and torch.equal(go, gr)
