@@ -49,3 +49,30 @@ def test_product_never_imports_oracle():
             if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dp, fn)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, fn
+
+
+def test_argument_validation_returns_errors_without_a_gpu():
+    """every entry point rejects unsupported geometry / null pointers with an error code and a message before it touches the
+    device (no kernel is launched here: this runs on the CPU box)"""
+    from imagefolder_amd import _lib
+    l = _lib.lib()
+    one = ctypes.c_void_p(16)   # a non-null dummy pointer: validation must fail before it would be dereferenced
+    f1 = ctypes.c_float(0.125)
+
+    def err():
+        return l.xq_last_error().decode()
+
+    assert l.xq_attn_forward(one, 2, 16, 4, 32, f1, one, one, None) != 0 and "head_dim" in err()
+    assert l.xq_attn_forward(None, 2, 16, 4, 64, f1, one, one, None) != 0 and "null" in err()
+    assert l.xq_attn_forward(None, 0, 16, 4, 64, f1, None, None, None) == 0          # empty batch is a no-op
+    assert l.xq_attn_backward(one, one, one, one, 2, 0, 4, 64, f1, one, one, None) != 0
+    assert l.xq_conv3x3_nhwc_bf16(one, one, None, 1, 8, 8, 48, 64, 0, one, None) != 0 and "Cin" in err()
+    assert l.xq_conv3x3_wgrad_nhwc_bf16(one, one, 1, 8, 8, 64, 128, one, None) != 0 and "128" in err()
+    assert l.xq_maxpool2x2_nhwc_bf16_forward(one, 1, 4, 4, 12, one, None) != 0
+    assert l.xq_groupnorm_silu_forward(one, None, None, 1, 16, 96, 32, ctypes.c_float(1e-6), 1, one, one, one, one, None) != 0
+    assert "geometry" in err()
+    assert l.xq_bnlocal_lrelu_forward(one, None, None, None, 2, 8, 100, 1, ctypes.c_float(1e-6), ctypes.c_float(0.2), ctypes.c_float(1.0),
+                                      one, one, one, None) != 0
+    assert l.xq_unfold1d_circular(one, 1, 4, 64, 9, 1, one, None) != 0               # kernel longer than the sequence
+    assert l.xq_gelu_forward(one, 7, 1, 0, one, None) != 0                          # not a multiple of the 16-byte vector
+    assert l.xq_prof_marker(0, None) != 0
