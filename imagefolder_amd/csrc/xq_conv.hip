@@ -42,7 +42,12 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__re
                                                       __hip_bfloat16 *__restrict__ Y) {
     constexpr int WN = BN / 2;          // channels per wave
     constexpr int NT = WN / 32;         // 32-wide N tiles per wave (2 for BN=128, 1 for BN=64)
-    constexpr int CV_BK = BK, CV_PITCH = BK + 8;   // LDS row pitch in bf16 elements (144 / 80 bytes: conflict-free b128 reads)
+    // LDS rows: BK = 64 -> 144-byte pitch (padded: conflict-free 16-byte stores and ds_read_b128 fragment groups);
+    // BK = 32 -> unpadded 64-byte rows with the 16-byte chunk index XOR-ed by (row >> 2) & 3: with any padded pitch the two
+    // 64-byte rows of one 8-lane store group overlap by 4 banks (33 % of the LDS cycles were conflicts, profiles/r01_conv3x3_pmc.txt);
+    // the swizzle makes both the stores and the fragment-read lane groups {0-3,12-15,20-27}, ... hit 16 distinct bank quads
+    constexpr bool SWZ = (BK == 32);
+    constexpr int CV_BK = BK, CV_PITCH = SWZ ? BK : BK + 8;
     constexpr int CPT = BK / 32;        // 16-byte chunks per thread and row
     __shared__ __attribute__((aligned(16))) short lds[2][(CV_BM + BN) * CV_PITCH];
 
@@ -107,7 +112,8 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__re
     }
 #define CV_STORE_TILES(BUF)                                                                                            \
     {                                                                                                                  \
-        short *A_ = lds[BUF] + (tid >> 2) * CV_PITCH + part, *B_ = lds[BUF] + (CV_BM + (tid >> 2)) * CV_PITCH + part;  \
+        const int sp_ = SWZ ? 8 * ((tid & 3) ^ ((tid >> 4) & 3)) : part;                                              \
+        short *A_ = lds[BUF] + (tid >> 2) * CV_PITCH + sp_, *B_ = lds[BUF] + (CV_BM + (tid >> 2)) * CV_PITCH + sp_;    \
         *reinterpret_cast<uint4 *>(A_) = ra0;                                                                          \
         if (CPT > 1) *reinterpret_cast<uint4 *>(A_ + 8) = ra1;                                                                    \
         *reinterpret_cast<uint4 *>(A_ + 64 * CV_PITCH) = ra2;                                                          \
@@ -134,6 +140,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__re
     __syncthreads();
 
     const int frow = lane & 31, fk = (lane >> 5) * 8;  // fragment: row/col = lane%32, k offset = 8*(lane/32)
+    const int fsw = (frow >> 2) & 3;                   // swizzle key of this lane's fragment row (tile bases are multiples of 16 rows)
     for (int ks = 0; ks < ksteps; ++ks) {
         const int cur = ks & 1;
         if (ks + 1 < ksteps) CV_LOAD_TILES(ks + 1)  // global -> VGPR, lands under the MFMAs below
@@ -143,9 +150,9 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const __hip_bfloat16 *__re
         for (int kk = 0; kk < CV_BK; kk += 16) {
             bf16x8 af[2], bfr[NT];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(A + (i * 32 + frow) * CV_PITCH + kk + fk);
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const bf16x8 *>(A + (i * 32 + frow) * CV_PITCH + (SWZ ? 8 * ((((kk + fk) >> 3)) ^ fsw) : kk + fk));
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + frow) * CV_PITCH + kk + fk);
+            for (int j = 0; j < NT; ++j) bfr[j] = *reinterpret_cast<const bf16x8 *>(Bs + (j * 32 + frow) * CV_PITCH + (SWZ ? 8 * ((((kk + fk) >> 3)) ^ fsw) : kk + fk));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
