@@ -121,3 +121,52 @@ def test_perturbation_schedule_matches_reference_formula():
     assert get_random_ratio(40, 120, 0.5, 10) == 1.0
     assert get_random_ratio(40, 120, 0.5, 200) == 0.5
     assert abs(get_random_ratio(40, 120, 0.5, 80) - 0.75) < 1e-12
+
+
+class _TinyLoss(torch.nn.Module):
+    """stand-in for VQLoss(optimizer_idx=1): a 'discriminator' with parameters and a loss that is a mean over the batch"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(3)
+        self.discriminator = torch.nn.Sequential(torch.nn.Linear(5, 4), torch.nn.Tanh(), torch.nn.Linear(4, 1))
+
+    def forward(self, codebook_loss, sem_loss, detail_loss, dependency_loss, inputs, reconstructions, optimizer_idx, global_step,
+                last_layer=None, fade_blur_schedule=0):
+        assert optimizer_idx == 1
+        real, fake = self.discriminator(inputs), self.discriminator(reconstructions)
+        return torch.relu(1.0 - real).mean() + torch.relu(1.0 + fake).mean()
+
+
+def _disc_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imagefolder_amd.train import DiscriminatorStep
+    L = _TinyLoss()
+    ds = DiscriminatorStep(L, lr=5e-3, betas=(0.9, 0.95), weight_decay=0.01, amp_dtype=None)
+    assert ds.opt.world == world
+    g = torch.Generator().manual_seed(7)
+    imgs, rec = torch.randn(3, world * 4, 5, generator=g), torch.randn(3, world * 4, 5, generator=g)
+    for it in range(3):
+        ds(imgs[it, rank * 4:(rank + 1) * 4], rec[it, rank * 4:(rank + 1) * 4])
+    if rank == 0:
+        torch.save({k: v.clone() for k, v in L.state_dict().items()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_discriminator_step_two_ranks_equals_single_process_on_the_global_batch(tmp_path):
+    """the discriminator half-step (xqgan_train.py:464-475) under data parallelism: head gradients all-reduced once and averaged"""
+    world, port, out = 2, _free_port(), str(tmp_path / "disc.pt")
+    mp.spawn(_disc_worker, args=(world, port, out), nprocs=world, join=True)
+    dp = torch.load(out)
+    from imagefolder_amd.train import DiscriminatorStep
+    L = _TinyLoss()
+    ds = DiscriminatorStep(L, lr=5e-3, betas=(0.9, 0.95), weight_decay=0.01, amp_dtype=None)
+    g = torch.Generator().manual_seed(7)
+    imgs, rec = torch.randn(3, world * 4, 5, generator=g), torch.randn(3, world * 4, 5, generator=g)
+    for it in range(3):
+        ds(imgs[it], rec[it])
+    for k, v in L.state_dict().items():
+        assert torch.allclose(v, dp[k], atol=1e-6, rtol=1e-5), k
