@@ -1,0 +1,541 @@
+// xq_gemm.hip — bf16 GEMMs of the ViT encoder / decoder blocks on gfx950 MFMA (fp32 accumulate), hand-written.
+//
+// Replaces the cuBLAS / hipBLASLt calls behind nn.Linear in the reference's transformer blocks
+// (tokenizer/tokenizer_image/dino_enc/vision_transformer.py:145-197 Attention.qkv / proj, :295-339 Block -> timm Mlp.fc1 / fc2,
+// patch embedding :684-692, dino_enc/to_pixel.py:70-86) in all three passes:
+//     NT  y[M,N]   = x[M,K] . W[N,K]^T + b[N]          forward            (both operands K-major)
+//     NN  gx[M,N]  = g[M,K] . W[K,N]                   data gradient      (A K-major, B K-strided)
+//     TN  gW[P,Q]  = g[R,P]^T . x[R,Q]                 weight gradient    (both K-strided; split over R, fp32 slabs)
+// One tile engine serves the three: 256 x BN x 64 block tile (BN = 256 or 128), 512 threads = 8 waves as 2 x 4, each wave
+// 128 x BN/4 through v_mfma_f32_32x32x16_bf16.  Operand tiles come in by LDS-DMA (global_load_lds_dwordx4: no staging
+// registers, no ds_write pass) in 16 KiB pieces laid out for conflict-free fragment reads (xq_gemm_map.hpp); K-strided operands
+// are read with the gfx950 transpose read ds_read_b64_tr_b16, so no operand is ever transposed in memory.
+//
+// Two schedules:
+//   gemm_simple_kernel : 2 LDS buffers, one vmcnt(0) + barrier per K tile; any BN; the reference schedule of the tests.
+//   gemm_ring_kernel   : BN = 256.  8-slot piece ring, one piece (2 LDS-DMA instructions per wave) issued per phase, 6 pieces
+//                        ahead of the reads, counted s_waitcnt vmcnt(8) (never 0 in the loop), 4 phases of 8 MFMAs per K tile
+//                        and wave; the two wave rows run one barrier interval apart, so that on every SIMD one wave is in its
+//                        MFMA segment while the other issues its LDS reads / DMA (cdna_hip_programming.md §5 "8-phase").
+// Epilogue: accumulators (+ bias) -> bf16 through a wave-private LDS region -> full-row 16-byte stores; TN: fp32 float4 stores
+// into the split's slab, summed by splitk_reduce_kernel (which also folds the < 64-row remainder of R).
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "xq_gemm_map.hpp"
+#include "../../include/xq_ops.h"
+
+#include <hip/hip_bf16.h>
+
+using namespace xq;
+
+namespace {
+
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bfv2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) void gbl_void;
+
+constexpr int GT = 512;               // threads per block
+enum { EPI_BF16 = 0, EPI_F32_SLAB = 1 };
+
+struct GemmArgs {
+    const char *A, *B;      // bf16
+    const float *bias;      // [N] or null (EPI_BF16)
+    char *C;                // bf16 [M][ldc] or fp32 slabs [splits][M][ldc]
+    long M, N;              // output rows, columns
+    long lda, ldb, ldc;     // leading dimensions (elements)
+    int ktiles;             // 64-deep K tiles per split (split s < kt_rem runs one more)
+    int kt_rem;
+    int tiles_m, tiles_n, splits;
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    const bfv2 r = __builtin_convertvector(v, bfv2);   // v_cvt_pk_bf16_f32 (RNE)
+    return __builtin_bit_cast(unsigned, r);
+}
+
+__device__ __forceinline__ bf16x4 tr4(const char *p) {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((bf16x4 __attribute__((address_space(3))) *)p);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// per-thread staging state of one operand: byte offsets (relative to the operand's tile base) of this lane's 16-byte chunk
+// in the two LDS-DMA instructions of each half piece
+// ---------------------------------------------------------------------------------------------------------------------
+template <int KIND, bool IS_A>
+struct Stager {
+    unsigned off[2][2];     // [half][i]
+    const char *base;       // tile base at K tile 0 (wave-uniform)
+    long adv;               // bytes per K tile
+    // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
+    __device__ __forceinline__ void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn,
+                                         int halves) {
+        const long avail = rc_count - rc0;          // valid rows / columns from the tile origin
+        if (KIND == gm::KMAJOR) {
+            base = mat + (rc0 * ld + k0) * 2;
+            adv = gm::BKT * 2;
+        } else {
+            base = mat + (k0 * ld + rc0) * 2;
+            adv = (long)gm::BKT * ld * 2;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (h >= halves) { off[h][i] = 0; continue; }
+                const gm::StageSrc s = gm::stage_src<KIND, IS_A>(h, wave, i, lane, wtn);
+                if (KIND == gm::KMAJOR) {
+                    long rc = s.rc;
+                    if (rc > avail - 1) rc = avail - 1;
+                    off[h][i] = (unsigned)((rc * ld + s.k) * 2);
+                } else {
+                    long rc = s.rc;
+                    if (rc > avail - 8) rc = avail - 8;     // 8 consecutive columns (dimension is a multiple of 8)
+                    off[h][i] = (unsigned)(((long)s.k * ld + rc) * 2);
+                }
+            }
+    }
+    // issue the two LDS-DMA instructions of piece `half` of K tile `kt` into LDS `dst` (wave-uniform piece base)
+    __device__ __forceinline__ void issue(int half, long kt, char *dst, int wave) const {
+        const char *b = base + kt * adv;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+    }
+};
+
+// fragment of 8 reduction indices for row / column (lane & 31) out of a piece
+template <int KIND, bool IS_A>
+__device__ __forceinline__ bf16x8 read_frag(const char *piece, int w, int f, int s, int lane) {
+    if (KIND == gm::KMAJOR) {
+        return *reinterpret_cast<const bf16x8 *>(piece + gm::frag_off_kmajor<IS_A>(w, f, s, lane));
+    } else {
+        const bf16x4 lo = tr4(piece + gm::frag_off_kstrided<IS_A>(w, f, s, 0, lane));
+        const bf16x4 hi = tr4(piece + gm::frag_off_kstrided<IS_A>(w, f, s, 1, lane));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// epilogues
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NFJ>
+__device__ __forceinline__ void epilogue_bf16(const f32x16 (&acc)[4][NFJ], const GemmArgs &g, char *region, long m0, long n0,
+                                              int wr, int wc, int lane) {
+    constexpr int WTN = 32 * NFJ;
+    const int h = lane >> 5;
+    const long ncol0 = n0 + (long)WTN * wc;
+#pragma unroll
+    for (int fj = 0; fj < NFJ; ++fj) {
+        float4 bv[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            long n = ncol0 + 32 * fj + 8 * q + 4 * h;
+            if (n > g.N - 4) n = g.N - 4;
+            bv[q] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 pk;
+                pk.x = pack_bf16(acc[fi][fj][4 * q + 0] + bv[q].x, acc[fi][fj][4 * q + 1] + bv[q].y);
+                pk.y = pack_bf16(acc[fi][fj][4 * q + 2] + bv[q].z, acc[fi][fj][4 * q + 3] + bv[q].w);
+                *reinterpret_cast<uint2 *>(region + gm::epi_write_off(fi, fj, q, lane, WTN)) = pk;
+            }
+    }
+    // same wave wrote and reads the region: LDS operations of one wave complete in order
+    constexpr int PASSES = 128 / (64 / (WTN / 8));
+    __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+        int row, c, off;
+        gm::epi_read_map(it, lane, WTN, &row, &c, &off);
+        const uint4 v = *reinterpret_cast<const uint4 *>(region + off);
+        const long gr = m0 + 128 * wr + row;
+        const long gc = ncol0 + 8 * c;
+        if (gr < g.M && gc + 8 <= g.N) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
+    }
+}
+
+template <int NFJ>
+__device__ __forceinline__ void epilogue_f32_slab(const f32x16 (&acc)[4][NFJ], const GemmArgs &g, long split, long m0, long n0,
+                                                  int wr, int wc, int lane) {
+    constexpr int WTN = 32 * NFJ;
+    float *C = reinterpret_cast<float *>(g.C) + (size_t)split * g.M * g.ldc;
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fi = 0; fi < 4; ++fi) {
+        const long gr = m0 + 128 * wr + 32 * fi + (lane & 31);
+#pragma unroll
+        for (int fj = 0; fj < NFJ; ++fj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const long gc = n0 + (long)WTN * wc + 32 * fj + 8 * q + 4 * h;
+                if (gr < g.M && gc + 4 <= g.N)
+                    *reinterpret_cast<float4 *>(C + gr * g.ldc + gc) =
+                        make_float4(acc[fi][fj][4 * q + 0], acc[fi][fj][4 * q + 1], acc[fi][fj][4 * q + 2], acc[fi][fj][4 * q + 3]);
+            }
+    }
+}
+
+// tile -> (m0, n0, split) with the XCD-aware order; column tiles of one row tile (and the splits of one tile) back to back
+__device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int BN, long &m0, long &n0, long &split) {
+    const long total = (long)g.tiles_m * g.tiles_n * g.splits;
+    const long id = blockIdx.x;
+    if (id >= total) return false;
+    const long pos = gm::xcd_order(id, total);
+    split = pos % g.splits;
+    const long t = pos / g.splits;
+    m0 = (t / g.tiles_n) * gm::BM;
+    n0 = (t % g.tiles_n) * BN;
+    return true;
+}
+
+// =====================================================================================================================
+// simple schedule: stage tile t+1, compute tile t, vmcnt(0) + barrier
+// =====================================================================================================================
+template <int AK, int BK, int BN, int EPI>
+__global__ __launch_bounds__(GT) void gemm_simple_kernel(const GemmArgs g) {
+    constexpr int NFJ = BN / 128;            // 32-wide column fragments per wave (2 or 1)
+    constexpr int WTN = BN / 4;
+    constexpr int NPB = 2 + NFJ;             // pieces of B... A-top, A-bottom, B-left (, B-right)
+    constexpr int BUF = NPB * gm::PIECE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    long m0, n0, split;
+    if (!tile_of_block(g, BN, m0, n0, split)) return;
+    const long k0 = (split * (long)g.ktiles + (split < g.kt_rem ? split : g.kt_rem)) * gm::BKT;
+    const int KT = g.ktiles + (split < g.kt_rem ? 1 : 0);
+
+    Stager<AK, true> sa;
+    Stager<BK, false> sb;
+    sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
+    sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, NFJ);
+
+    f32x16 acc[4][NFJ];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NFJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto stage_tile = [&](long kt, int buf) {
+        char *b = smem + buf * BUF;
+        sa.issue(0, kt, b, wave);
+        sa.issue(1, kt, b + gm::PIECE_BYTES, wave);
+        sb.issue(0, kt, b + 2 * gm::PIECE_BYTES, wave);
+        if (NFJ > 1) sb.issue(1, kt, b + 3 * gm::PIECE_BYTES, wave);
+    };
+
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < KT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < KT) stage_tile(t + 1, cur ^ 1);
+        const char *b = smem + cur * BUF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 bf[NFJ];
+#pragma unroll
+            for (int fj = 0; fj < NFJ; ++fj) bf[fj] = read_frag<BK, false>(b + (2 + fj) * gm::PIECE_BYTES, wc, 0, s, lane);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const bf16x8 af = read_frag<AK, true>(b + (fi >> 1) * gm::PIECE_BYTES, wr, fi & 1, s, lane);
+#pragma unroll
+                for (int fj = 0; fj < NFJ; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[fj], af, acc[fi][fj], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    if (EPI == EPI_BF16) epilogue_bf16<NFJ>(acc, g, smem + wave * (2 * WTN * 128), m0, n0, wr, wc, lane);
+    else epilogue_f32_slab<NFJ>(acc, g, split, m0, n0, wr, wc, lane);
+}
+
+// =====================================================================================================================
+// ring schedule (BN = 256).  Piece x = 4 t + q of K tile t: q = 0 A-top, 1 B-left, 2 B-right, 3 A-bottom; LDS slot x & 7.
+//   phase p of K tile t (phase index j = 4 t + p):  reads   p = 0: A-top + B-left, 1: B-right, 2: A-bottom, 3: -
+//                                                   MFMAs   p = 0: top x left, 1: top x right, 2: bottom x right, 3: bottom x left
+//                                                   stages  piece j + 6 (its slot held piece j - 2, last read in phase <= j - 2)
+//                                                   waits   vmcnt(8): pieces <= j + 2 have landed (read in phase >= j + 1,
+//                                                           i.e. after the barrier that follows every wave's wait)
+//   each phase = [reads, DMA issue, vmcnt] barrier [8 MFMAs] barrier; wave row 1 runs one barrier behind wave row 0.
+// =====================================================================================================================
+#define GR_BARRIER()                                   \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("s_barrier" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+#define GR_VMCNT(N)                                                \
+    do {                                                           \
+        asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory");      \
+    } while (0)
+
+template <int AK, int BK, int EPI>
+__global__ __launch_bounds__(GT) void gemm_ring_kernel(const GemmArgs g) {
+    constexpr int BN = 256, WTN = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    long m0, n0, split;
+    if (!tile_of_block(g, BN, m0, n0, split)) return;
+    const long k0 = (split * (long)g.ktiles + (split < g.kt_rem ? split : g.kt_rem)) * gm::BKT;
+    const int KT = g.ktiles + (split < g.kt_rem ? 1 : 0);     // >= 2 (checked by the launcher)
+
+    Stager<AK, true> sa;
+    Stager<BK, false> sb;
+    sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
+    sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, 2);
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // piece (kt, q) -> LDS slot
+#define GR_SLOT(KT_, Q) (smem + ((((KT_) & 1) << 2) + (Q)) * gm::PIECE_BYTES)
+#define GR_STAGE(KT_, Q)                                                      \
+    do {                                                                      \
+        if ((Q) == 0) sa.issue(0, (KT_), GR_SLOT(KT_, 0), wave);              \
+        else if ((Q) == 1) sb.issue(0, (KT_), GR_SLOT(KT_, 1), wave);         \
+        else if ((Q) == 2) sb.issue(1, (KT_), GR_SLOT(KT_, 2), wave);         \
+        else sa.issue(1, (KT_), GR_SLOT(KT_, 3), wave);                       \
+    } while (0)
+
+    bf16x8 af[2][4], bl[4], br[4];
+#define GR_READ_A(KT_, Q)                                                                                     \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                        \
+        af[0][s_] = read_frag<AK, true>(GR_SLOT(KT_, Q), wr, 0, s_, lane);                                    \
+        af[1][s_] = read_frag<AK, true>(GR_SLOT(KT_, Q), wr, 1, s_, lane);                                    \
+    }
+#define GR_READ_B(DST, KT_, Q) \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) DST[s_] = read_frag<BK, false>(GR_SLOT(KT_, Q), wc, 0, s_, lane);
+    // MFMAs are register-only: neither the "memory" clobber of the barrier nor sched_barrier keeps instruction selection from
+    // moving them into another phase.  The empty volatile asm statements pin the two accumulators of the phase on both sides
+    // (volatile asm statements, the barriers included, keep their program order).
+#define GR_PIN(X) asm volatile("" : "+v"(X))
+#define GR_MFMA(FI0, FJ, BFR)                                                                                          \
+    do {                                                                                                               \
+        GR_PIN(acc[FI0][FJ]);                                                                                          \
+        GR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                             \
+            acc[FI0][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[0][s_], acc[FI0][FJ], 0, 0, 0);         \
+            acc[FI0 + 1][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[1][s_], acc[FI0 + 1][FJ], 0, 0, 0); \
+        }                                                                                                              \
+        GR_PIN(acc[FI0][FJ]);                                                                                          \
+        GR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+    } while (0)
+
+    // one K tile; ST = number of pieces still to be staged from this tile's phases (4 in the steady state, 2 / 0 at the end);
+    // V0..V3 = vmcnt immediates of the four phases
+#define GR_TILE(T_, ST, V0, V1, V2, V3)                                       \
+    do {                                                                      \
+        /* phase 0 */                                                         \
+        GR_READ_B(bl, T_, 1)                                                  \
+        GR_READ_A(T_, 0)                                                      \
+        if ((ST) > 0) GR_STAGE((T_) + 1, 2);                                  \
+        GR_VMCNT(V0);                                                         \
+        GR_BARRIER();                                                         \
+        GR_MFMA(0, 0, bl);                                                    \
+        GR_BARRIER();                                                         \
+        /* phase 1 */                                                         \
+        GR_READ_B(br, T_, 2)                                                  \
+        if ((ST) > 1) GR_STAGE((T_) + 1, 3);                                  \
+        GR_VMCNT(V1);                                                         \
+        GR_BARRIER();                                                         \
+        GR_MFMA(0, 1, br);                                                    \
+        GR_BARRIER();                                                         \
+        /* phase 2 */                                                         \
+        GR_READ_A(T_, 3)                                                      \
+        if ((ST) > 2) GR_STAGE((T_) + 2, 0);                                  \
+        GR_VMCNT(V2);                                                         \
+        GR_BARRIER();                                                         \
+        GR_MFMA(2, 1, br);                                                    \
+        GR_BARRIER();                                                         \
+        /* phase 3 */                                                         \
+        if ((ST) > 3) GR_STAGE((T_) + 2, 1);                                  \
+        GR_VMCNT(V3);                                                         \
+        GR_BARRIER();                                                         \
+        GR_MFMA(2, 0, bl);                                                    \
+        GR_BARRIER();                                                         \
+    } while (0)
+
+    // prologue: pieces 0..5 (all of K tile 0, A-top + B-left of K tile 1); the first two must have landed
+    GR_STAGE(0, 0);
+    GR_STAGE(0, 1);
+    GR_STAGE(0, 2);
+    GR_STAGE(0, 3);
+    GR_STAGE(1, 0);
+    GR_STAGE(1, 1);
+    GR_VMCNT(8);
+    GR_BARRIER();
+    if (wr == 1) GR_BARRIER();     // wave row 1 runs one barrier interval behind wave row 0
+
+    int t = 0;
+    for (; t < KT - 2; ++t) GR_TILE(t, 4, 8, 8, 8, 8);
+    // K tile KT-2 stages the last two pieces (B-right, A-bottom of K tile KT-1); K tile KT-1 stages nothing
+    GR_TILE(t, 2, 8, 8, 6, 4);
+    ++t;
+    GR_TILE(t, 0, 2, 0, 0, 0);
+    if (wr == 0) GR_BARRIER();     // re-align: every wave has passed a barrier after the last LDS read of the other row
+
+    if (EPI == EPI_BF16) epilogue_bf16<2>(acc, g, smem + wave * gm::PIECE_BYTES, m0, n0, wr, wc, lane);
+    else epilogue_f32_slab<2>(acc, g, split, m0, n0, wr, wc, lane);
+#undef GR_TILE
+#undef GR_MFMA
+#undef GR_PIN
+#undef GR_READ_A
+#undef GR_READ_B
+#undef GR_STAGE
+#undef GR_SLOT
+}
+
+// sum of the split-K slabs (+ the < 64-row remainder of the reduction, folded in here so the tile kernels only see whole K tiles)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slabs, int splits, long P, long Q,
+                                                            const __hip_bfloat16 *__restrict__ G, const __hip_bfloat16 *__restrict__ X,
+                                                            long r_begin, long r_end, float *__restrict__ out) {
+    const long e = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= P * Q) return;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < splits; ++k) {
+        const float4 v = *reinterpret_cast<const float4 *>(slabs + (size_t)k * P * Q + e);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (r_begin < r_end) {
+        const long p = e / Q, q = e - p * Q;
+        for (long r = r_begin; r < r_end; ++r) {
+            const float gv = __bfloat162float(G[r * P + p]);
+            const __hip_bfloat16 *x = X + r * Q + q;
+            s.x = __builtin_fmaf(gv, __bfloat162float(x[0]), s.x);
+            s.y = __builtin_fmaf(gv, __bfloat162float(x[1]), s.y);
+            s.z = __builtin_fmaf(gv, __bfloat162float(x[2]), s.z);
+            s.w = __builtin_fmaf(gv, __bfloat162float(x[3]), s.w);
+        }
+    }
+    *reinterpret_cast<float4 *>(out + e) = s;
+}
+
+template <void (*KERNEL)(const GemmArgs)>
+int set_lds(int bytes) {
+    static bool done = false;   // one static per kernel instantiation
+    if (!done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+            return -1;
+        done = true;
+    }
+    return 0;
+}
+
+template <int AK, int BK, int EPI>
+int launch_tiles(const GemmArgs &g, int BN, int impl, hipStream_t s, const char *fn) {
+    const long total = (long)g.tiles_m * g.tiles_n * g.splits;
+    if (total <= 0) return XQ_OK;
+    if (total > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: too many tiles", fn);
+    const bool ring = (impl == XQ_GEMM_RING) || (impl == XQ_GEMM_AUTO && BN == 256 && g.ktiles >= 2);
+    const double kdepth = ((double)g.ktiles * g.splits + g.kt_rem) * 64.0;
+    const int pslot = prof_begin(XQ_PROF_GEMM, 2.0 * (double)g.M * (double)g.N * kdepth, s);
+    if (ring) {
+        if (BN != 256 || g.ktiles < 2) return xq_set_error(XQ_EINVAL, "%s: the ring schedule needs 256-column tiles and K >= 128", fn);
+        const int lds = 8 * gm::PIECE_BYTES;
+        if (set_lds<gemm_ring_kernel<AK, BK, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+        hipLaunchKernelGGL((gemm_ring_kernel<AK, BK, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+    } else if (BN == 256) {
+        const int lds = 8 * gm::PIECE_BYTES;
+        if (set_lds<gemm_simple_kernel<AK, BK, 256, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+        hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 256, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+    } else {
+        const int lds = 6 * gm::PIECE_BYTES;
+        if (set_lds<gemm_simple_kernel<AK, BK, 128, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+        hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 128, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+    }
+    prof_end(pslot, s);
+    return xq_check_launch(fn);
+}
+
+int pick_bn(long N) { return N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : (N >= 1024 ? 256 : 128)); }
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C-ABI
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y, int impl,
+                               xq_stream_t stream) {
+    const char *fn = "xq_gemm_bf16_nt";
+    if (M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
+    if (M == 0 || N == 0) return XQ_OK;
+    if (!x || !w || !y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (K < 64 || K % 64 || N % 8 || N < 32) return xq_set_error(XQ_EINVAL, "%s: needs K %% 64 == 0, N %% 8 == 0, N >= 32 (K=%ld N=%ld)", fn, (long)K, (long)N);
+    const int BN = pick_bn(N);
+    GemmArgs g{(const char *)x, (const char *)w, bias, (char *)y, M, N, K, K, N, (int)(K / 64), 0,
+               (int)((M + 255) / 256), (int)((N + BN - 1) / BN), 1};
+    return launch_tiles<gm::KMAJOR, gm::KMAJOR, EPI_BF16>(g, BN, impl, (hipStream_t)stream, fn);
+}
+
+extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_t K, void *g_x, int impl, xq_stream_t stream) {
+    const char *fn = "xq_gemm_bf16_nn";
+    if (M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
+    if (M == 0 || N == 0) return XQ_OK;
+    if (!g_y || !w || !g_x) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (K < 64 || K % 64 || N % 8 || N < 32) return xq_set_error(XQ_EINVAL, "%s: needs K %% 64 == 0, N %% 8 == 0, N >= 32 (K=%ld N=%ld)", fn, (long)K, (long)N);
+    const int BN = pick_bn(N);
+    GemmArgs g{(const char *)g_y, (const char *)w, nullptr, (char *)g_x, M, N, K, N, N, (int)(K / 64), 0,
+               (int)((M + 255) / 256), (int)((N + BN - 1) / BN), 1};
+    return launch_tiles<gm::KMAJOR, gm::KSTRIDED, EPI_BF16>(g, BN, impl, (hipStream_t)stream, fn);
+}
+
+static int tn_splits(int64_t R, int64_t P, int64_t Q, int BN) {
+    const long tiles = ((P + 255) / 256) * ((Q + BN - 1) / BN);
+    const long kt = R / 64;
+    long s = num_cus() / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    if (s > kt / 2) s = kt / 2;       // >= 2 K tiles per split
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+extern "C" size_t xq_gemm_bf16_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q) {
+    if (R <= 0 || P <= 0 || Q <= 0) return 0;
+    return (size_t)tn_splits(R, P, Q, pick_bn(Q)) * P * Q * 4;
+}
+
+extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_t Q, float *g_w, void *ws, size_t ws_bytes,
+                               int impl, xq_stream_t stream) {
+    const char *fn = "xq_gemm_bf16_tn";
+    if (R < 0 || P < 0 || Q < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
+    if (P == 0 || Q == 0) return XQ_OK;
+    if (!g_w || (R > 0 && (!g_y || !x))) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (P % 8 || Q % 8 || P < 32 || Q < 32) return xq_set_error(XQ_EINVAL, "%s: needs P, Q multiples of 8 and >= 32 (P=%ld Q=%ld)", fn, (long)P, (long)Q);
+    hipStream_t s = (hipStream_t)stream;
+    const int BN = pick_bn(Q);
+    int splits = 0;
+    const long kt_all = R / 64;
+    if (kt_all >= 2) {
+        splits = tn_splits(R, P, Q, BN);
+        if (ws_bytes < (size_t)splits * P * Q * 4 || !ws) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
+        GemmArgs g{(const char *)g_y, (const char *)x, nullptr, (char *)ws, P, Q, P, Q, Q, (int)(kt_all / splits), (int)(kt_all % splits),
+                   (int)((P + 255) / 256), (int)((Q + BN - 1) / BN), splits};
+        const int rc = launch_tiles<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, s, fn);
+        if (rc) return rc;
+    }
+    const long done = splits ? kt_all * 64 : 0;   // rows covered by whole K tiles
+    const long quads = (P * Q) / 4;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float *)ws, splits, (long)P,
+                       (long)Q, (const __hip_bfloat16 *)g_y, (const __hip_bfloat16 *)x, done, (long)R, g_w);
+    return xq_check_launch(fn);
+}

@@ -1,0 +1,103 @@
+// xq_gemm_map.hpp — index maps of the bf16 GEMM kernels (csrc/xq_gemm.hip): which 16 bytes every LDS-DMA lane fetches, where
+// they land in LDS, and which LDS bytes every MFMA fragment read touches.  Host + device: tests/gemm_map_emulator.cpp replays
+// one K tile through exactly these functions on the CPU (LDS-DMA = lane-linear image, ds_read_b128, ds_read_b64_tr_b16 and the
+// v_mfma_f32_32x32x16_bf16 lane layouts as measured on gfx950, profiles/r01_ds_read_tr_probe.txt) and compares with a plain
+// matrix product, so that an indexing mistake is caught without a GPU.
+//
+// Block tile 256 x BN x 64 (BN = 256 or 128), 8 waves as 2 (rows) x 4 (columns): wave (wr, wc) owns rows [128 wr, +128) and
+// columns [WTN wc, +WTN), WTN = BN / 4 (64 or 32).  A K tile of one operand is cut into 16 KiB PIECES by the order in which
+// the waves consume them (a wave works through its 128 x WTN tile in 64 x 32 quadrants):
+//     A-top   : rows {128 wr + 0..63}          A-bottom : rows {128 wr + 64..127}        (both wave rows in one piece)
+//     B-left  : columns {WTN wc + 0..31}       B-right  : columns {WTN wc + 32..63}      (all four wave columns; BN = 256 only)
+// An operand is K-MAJOR when its reduction index is the fast (contiguous) axis in memory (x[M][K], W[N][K]) and K-STRIDED
+// when the reduction index is the slow axis (W[K][N] in the data gradient, both operands of the weight gradient):
+//   K-major   piece = [128 rows][64 k]  bf16, 128-byte LDS rows; fragment = one ds_read_b128 (8 consecutive k of one row);
+//             16-byte chunk c of LDS row R holds source chunk c ^ ((R >> 1) & 7)            (conflict-free b128 lane groups)
+//   K-strided piece = [64 k][128 cols] bf16, 256-byte LDS rows; fragment = two ds_read_b64_tr_b16 (4 consecutive k each);
+//             16-byte chunk c of LDS row kr holds source chunk c ^ (4 * (kr & 3))           (conflict-free transpose reads)
+// The XOR is applied to the SOURCE address of the LDS-DMA (its destination is lane-linear by construction) and again on the read.
+#pragma once
+
+#if defined(__HIPCC__) || defined(__CUDACC__)
+#define GM_HD __host__ __device__ __forceinline__
+#else
+#define GM_HD inline
+#endif
+
+namespace gm {
+
+enum { KMAJOR = 0, KSTRIDED = 1 };
+constexpr int PIECE_BYTES = 16384;
+constexpr int BM = 256, BKT = 64;   // block rows, reduction depth of one K tile
+
+// tile-local row of the A operand / column of the B operand held by piece-row R (0..127); half = 0 (top/left), 1 (bottom/right)
+GM_HD int a_rc(int half, int R) { return (R >> 6) * 128 + half * 64 + (R & 63); }
+GM_HD int b_rc(int half, int R, int wtn) { return (R >> 5) * wtn + half * 32 + (R & 31); }
+
+// One LDS-DMA wave instruction moves 64 lanes x 16 B = 1 KiB to piece offset (2 * wave + i) * 1024 + lane * 16 (i = 0, 1).
+struct StageSrc {
+    int rc;   // K-major: the row (A) / column (B) of the 8 elements;  K-strided: the first of 8 consecutive rows / columns
+    int k;    // K-major: the first of 8 consecutive k;                K-strided: the k of the 8 elements
+};
+template <int KIND, bool IS_A>
+GM_HD StageSrc stage_src(int half, int wave, int i, int lane, int wtn) {
+    StageSrc s;
+    if (KIND == KMAJOR) {
+        const int R = 16 * wave + 8 * i + (lane >> 3);
+        const int c = (lane & 7) ^ ((R >> 1) & 7);
+        s.k = 8 * c;
+        s.rc = IS_A ? a_rc(half, R) : b_rc(half, R, wtn);
+    } else {
+        const int kr = 4 * (2 * wave + i) + (lane >> 4);
+        const int c = (lane & 15) ^ (4 * (kr & 3));
+        s.k = kr;
+        s.rc = IS_A ? ((c >> 3) * 128 + half * 64 + 8 * (c & 7)) : ((c >> 2) * wtn + half * 32 + 8 * (c & 3));
+    }
+    return s;
+}
+GM_HD int stage_dst(int wave, int i, int lane) { return (2 * wave + i) * 1024 + lane * 16; }
+
+// Fragment reads.  w = wave row (A) or wave column (B), f = 32-wide fragment inside the 64-row half (A: 0, 1; B: 0), s = 16-deep
+// k slice (0..3).  The lane ends up with the 8 reduction indices k = 16 s + 8 (lane >> 5) + 0..7 of row / column (lane & 31).
+template <bool IS_A>
+GM_HD int frag_off_kmajor(int w, int f, int s, int lane) {
+    const int R = (IS_A ? 64 * w + 32 * f : 32 * w) + (lane & 31);
+    const int chunk = 2 * s + (lane >> 5);
+    return R * 128 + ((chunk ^ ((R >> 1) & 7)) << 4);
+}
+// u = 0, 1: the two 8-byte transpose reads (k = 16 s + 8 (lane >> 5) + 4 u + 0..3)
+template <bool IS_A>
+GM_HD int frag_off_kstrided(int w, int f, int s, int u, int lane) {
+    const int kr = 16 * s + 8 * (lane >> 5) + 4 * u + ((lane & 15) >> 2);
+    const int col = (IS_A ? 64 * w + 32 * f : 32 * w) + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+    return kr * 256 + (((col >> 3) ^ (4 * (kr & 3))) << 4) + ((col & 7) << 1);
+}
+
+// Accumulators: acc = mfma(B fragment, A fragment, acc) ("swapped": the MFMA's row index is the output COLUMN), so lane l,
+// register r of a 32 x 32 fragment hold output row (l & 31), output column (r & 3) + 8 (r >> 2) + 4 (l >> 5): four consecutive
+// columns per register quad -> 8-byte bf16 / 16-byte fp32 stores.
+GM_HD int acc_col(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+// bf16 epilogue: every wave stages its 128 x WTN tile in a private LDS region, [128 rows][WTN] bf16 (2 WTN-byte rows; chunks
+// XOR-ed with (row >> 1) & 7 resp. & 3), then streams it out in full rows.  Offsets are bytes inside the region.
+GM_HD int epi_write_off(int fi, int fj, int g, int lane, int wtn) {   // 8 bytes: columns 32 fj + 8 g + 4 (lane >> 5) + 0..3
+    const int row = 32 * fi + (lane & 31);
+    const int chunk = 4 * fj + g;
+    const int cmask = wtn / 8 - 1;
+    return row * (2 * wtn) + ((chunk ^ ((row >> 1) & cmask)) << 4) + 8 * (lane >> 5);
+}
+// pass `it`: lane reads 16 bytes = columns 8 c .. 8 c + 7 of row `row`
+GM_HD void epi_read_map(int it, int lane, int wtn, int *row, int *c, int *off) {
+    const int cpr = wtn / 8;            // 16-byte chunks per row (8 or 4)
+    *row = it * (64 / cpr) + lane / cpr;
+    *c = lane % cpr;
+    *off = *row * (2 * wtn) + (((*c) ^ ((*row >> 1) & (cpr - 1))) << 4);
+}
+
+// XCD-aware, bijective tile order: workgroup id -> position in the tile sequence (XCD k = id % 8 walks a contiguous range)
+GM_HD long xcd_order(long id, long total) {
+    const long q = total / 8, r = total % 8, x = id % 8;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
+}
+
+}  // namespace gm

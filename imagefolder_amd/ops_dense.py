@@ -197,22 +197,82 @@ def _weight_grad(g2, x2, wdtype):
         return torch.mm(g2.t(), x2).to(wdtype)
 
 
+# "hip": the hand-written MFMA GEMMs of csrc/xq_gemm.hip for every bf16 Linear whose shape they accept (all ViT-B / DINO-S
+# layers); "library": hipBLASLt through torch.addmm / mm (kept for A/B timing: XQ_GEMM=library).  fp32 operands (the parity
+# path of tests/test_model_parity.py) and shapes outside the kernels' contract always take the library call.
+import os as _os
+GEMM_IMPL = _os.environ.get("XQ_GEMM", "hip")
+GEMM_SCHEDULE = int(_os.environ.get("XQ_GEMM_SCHEDULE", "0"))   # 0 auto, 1 simple, 2 ring (include/xq_ops.h XQ_GEMM_*)
+
+
+def _gemm_ok(rows, n_out, k_red):
+    return rows > 0 and k_red >= 64 and k_red % 64 == 0 and n_out % 8 == 0 and n_out >= 32
+
+
+def gemm_nt(x2, W, bias32):
+    """y = x2 @ W^T (+ bias) — bf16 [M][K], [N][K] -> bf16 [M][N] on xq_gemm_bf16_nt."""
+    M, K = x2.shape
+    N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    with torch.cuda.device(x2.device):
+        rc = _lib.lib().xq_gemm_bf16_nt(ptr(x2), ptr(W), ptr(bias32), M, N, K, ptr(y), GEMM_SCHEDULE, _stream(x2))
+    check(rc, "xq_gemm_bf16_nt")
+    return y
+
+
+def gemm_nn(g2, W):
+    """g_x = g2 @ W — bf16 [M][N_out], W [N_out][K_in] read in place -> bf16 [M][K_in] on xq_gemm_bf16_nn."""
+    M, Kr = g2.shape
+    N = W.shape[1]
+    gx = torch.empty(M, N, dtype=torch.bfloat16, device=g2.device)
+    with torch.cuda.device(g2.device):
+        rc = _lib.lib().xq_gemm_bf16_nn(ptr(g2), ptr(W), M, N, Kr, ptr(gx), GEMM_SCHEDULE, _stream(g2))
+    check(rc, "xq_gemm_bf16_nn")
+    return gx
+
+
+def gemm_tn(g2, x2):
+    """g_W = g2^T @ x2 — bf16 [R][P], [R][Q] -> fp32 [P][Q] on xq_gemm_bf16_tn (split over R, deterministic slab sum)."""
+    R, P = g2.shape
+    Q = x2.shape[1]
+    gw = torch.empty(P, Q, dtype=torch.float32, device=g2.device)
+    nbytes = _lib.lib().xq_gemm_bf16_tn_workspace_bytes(R, P, Q)
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g2.device)
+    with torch.cuda.device(g2.device):
+        rc = _lib.lib().xq_gemm_bf16_tn(ptr(g2), ptr(x2), R, P, Q, ptr(gw), ptr(ws), nbytes, GEMM_SCHEDULE, _stream(g2))
+    check(rc, "xq_gemm_bf16_tn")
+    return gw
+
+
 class LinearFn(torch.autograd.Function):
-    """y = x @ W^T + b as library GEMMs (hipBLASLt through torch.addmm / mm): plain GEMMs are library calls by design.
-    bf16 activations read the bf16 weight shadow; weight gradients are produced in fp32 straight from the GEMM.
+    """y = x @ W^T + b.  bf16 activations: the hand-written MFMA GEMMs (csrc/xq_gemm.hip) in all three passes — forward NT
+    with the bias in the epilogue, data gradient NN on the weight as stored (transpose reads), weight gradient TN split over
+    the token axis with fp32 output — reading the bf16 weight shadow the optimizer kernel maintains.  fp32 activations
+    (parity path) and shapes outside the kernels' contract: library GEMMs.
     bias_grad_external: the bias gradient is delivered by the fused kernel that consumes/produces g_y."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, bias_grad_external):
+        from . import nn_ops
         shp = x.shape
         x2 = x.detach().reshape(-1, shp[-1])
+        hip = False
         if x2.dtype == torch.bfloat16:
             W = _w16(weight)
-            b = None if bias is None else bias.detach().to(torch.bfloat16)
+            hip = (GEMM_IMPL == "hip" and x2.is_cuda and W.is_contiguous() and _gemm_ok(x2.shape[0], W.shape[0], W.shape[1]))
+            if hip:
+                if not x2.is_contiguous():
+                    x2 = x2.contiguous()
+                b32 = None if bias is None else bias.detach().float().contiguous()
+                y = gemm_nt(x2, W, b32)
+                nn_ops.IMPL["linear"] = "hip (xq_gemm_bf16_nt / nn / tn: MFMA GEMMs, bias epilogue, split-K weight grads)"
+            else:
+                b = None if bias is None else bias.detach().to(torch.bfloat16)
         else:
             W = weight.detach()
             b = None if bias is None else bias.detach()
-        y = torch.addmm(b, x2, W.t()) if b is not None else torch.mm(x2, W.t())
+        if not hip:
+            y = torch.addmm(b, x2, W.t()) if b is not None else torch.mm(x2, W.t())
         ctx.save_for_backward(x2, W)
         ctx.meta = (shp, weight.dtype, bias is not None and not bias_grad_external, bias is not None)
         return y.view(*shp[:-1], W.shape[0])
@@ -224,8 +284,19 @@ class LinearFn(torch.autograd.Function):
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        g_x = torch.mm(g2, W).view(shp) if ctx.needs_input_grad[0] else None
-        g_w = _weight_grad(g2, x2, wdtype) if ctx.needs_input_grad[1] else None
+        hip = (GEMM_IMPL == "hip" and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
+               and W.dtype == torch.bfloat16 and W.is_contiguous() and x2.is_contiguous())
+        g_x = g_w = None
+        if ctx.needs_input_grad[0]:
+            if hip and _gemm_ok(g2.shape[0], W.shape[1], W.shape[0]):
+                g_x = gemm_nn(g2, W).view(shp)
+            else:
+                g_x = torch.mm(g2, W).view(shp)
+        if ctx.needs_input_grad[1]:
+            if hip and W.shape[0] % 8 == 0 and W.shape[1] % 8 == 0 and min(W.shape) >= 32:
+                g_w = gemm_tn(g2, x2).to(wdtype)
+            else:
+                g_w = _weight_grad(g2, x2, wdtype)
         g_b = None
         if want_bias and ctx.needs_input_grad[2] and g2.shape[1] % (8 if g2.dtype == torch.bfloat16 else 4):
             g_b = g2.float().sum(0)   # narrow outputs (e.g. the 1-channel logit conv): below the kernel's 16-byte vector

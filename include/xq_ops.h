@@ -268,6 +268,27 @@ int xq_unfold1d_circular(const void *h, int B, int L, int C, int K, int act_bf16
 /* the transpose: dh[b][l][c] = sum_tap dcols[b][(l - tap + K/2) mod L][tap][c] */
 int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K, int act_bf16, void *dh, xq_stream_t stream);
 
+/* ---- bf16 GEMMs of the transformer blocks (csrc/xq_gemm.hip; replaces the cuBLAS / hipBLASLt calls behind nn.Linear:
+ *      dino_enc/vision_transformer.py:145-197 Attention.qkv / proj, :295-339 Block -> Mlp.fc1 / fc2, :684-692 patch embedding,
+ *      dino_enc/to_pixel.py:70-86).  bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16.
+ *      All matrices row-major and contiguous.  impl selects the schedule (tests / benchmarks); use XQ_GEMM_AUTO. ---------- */
+#define XQ_GEMM_AUTO 0
+#define XQ_GEMM_SIMPLE 1 /* two LDS buffers, one barrier per K tile (any shape the op accepts)                      */
+#define XQ_GEMM_RING 2   /* 8-slot LDS-DMA ring, counted vmcnt, staggered wave rows (256-column tiles, K >= 128)   */
+#define XQ_PROF_GEMM 4   /* gemm_*_kernel: 2*M*N*K flops per launch (xq_prof_collect_kind)                          */
+/* forward: y[M][N] = x[M][K] . w[N][K]^T (+ bias[N], fp32, nullable).  K % 64 == 0, N % 8 == 0, N >= 32. */
+int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y, int impl,
+                    xq_stream_t stream);
+/* data gradient: g_x[M][N] = g_y[M][K] . w[K][N]  (w = the forward's weight [out = K][in = N], read in place with
+ * transpose reads: no transposed copy of the weights exists).  K % 64 == 0, N % 8 == 0, N >= 32. */
+int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_t K, void *g_x, int impl, xq_stream_t stream);
+/* weight gradient: g_w[P][Q] (fp32) = g_y[R][P]^T . x[R][Q], the token axis R split over the chip into fp32 slabs in
+ * `workspace` (xq_gemm_bf16_tn_workspace_bytes) that a second kernel sums in a fixed order (deterministic, no atomics).
+ * P, Q multiples of 8 and >= 32; any R >= 0. */
+size_t xq_gemm_bf16_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q);
+int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_t Q, float *g_w, void *workspace,
+                    size_t workspace_bytes, int impl, xq_stream_t stream);
+
 /* ---- measurement hooks (bench.py): HIP events recorded around the instrumented hand-written kernels on the stream they
  *      are launched on.  xq_prof_enable(1) resets and arms; xq_prof_collect_kind synchronises the recorded events of one
  *      kernel kind and returns their summed duration, launch count and summed algorithmic work (flops) since arming;

@@ -1,0 +1,183 @@
+// gemm_map_emulator.cpp — CPU replay of one K tile of csrc/xq_gemm.hip through the index maps of csrc/xq_gemm_map.hpp.
+// Test infrastructure (built and run by tests/test_gemm_map_cpu.py with g++; no GPU).  Emulated hardware semantics:
+//   * LDS-DMA (global_load_lds_dwordx4): lane l of a wave instruction copies 16 source bytes to LDS base + 16 l;
+//   * ds_read_b128: 16 bytes at the lane's address; ds_read_b64_tr_b16: within a 16-lane group, result lane L receives
+//     element (L % 4) of the 4-element rows addressed by lanes (L / 4) + 4 j, j = 0..3 (profiles/r01_ds_read_tr_probe.txt);
+//   * v_mfma_f32_32x32x16_bf16 D = A.B + C: operand lane l holds row/column (l & 31), k = 8 (l >> 5) + 0..7; D register r of
+//     lane l is D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]  (cdna_hip_programming.md §3).
+// It also counts LDS bank conflicts of every fragment read with the gfx950 lane grouping (MI355X_MICROARCH.md §LDS).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <set>
+#include <vector>
+
+#include "../imagefolder_amd/csrc/xq_gemm_map.hpp"
+
+using namespace gm;
+
+static int g_fail = 0;
+static long g_conf_b128 = 0, g_conf_tr = 0;
+
+struct Piece {
+    int16_t e[PIECE_BYTES / 2];
+};
+
+// src(rc, k) value tables: small integers (exact in bf16 and in fp32 sums)
+struct Operand {
+    int rows;                       // 256 (A) or BN (B)
+    std::vector<int16_t> v;         // [rows][64]
+    int16_t at(int rc, int k) const { return v[rc * 64 + k]; }
+};
+
+template <int KIND, bool IS_A>
+static void stage_piece(const Operand &op, int half, int wtn, Piece &p) {
+    std::vector<int> written(PIECE_BYTES / 16, 0);
+    for (int wave = 0; wave < 8; ++wave)
+        for (int i = 0; i < 2; ++i)
+            for (int lane = 0; lane < 64; ++lane) {
+                const StageSrc s = stage_src<KIND, IS_A>(half, wave, i, lane, wtn);
+                const int dst = stage_dst(wave, i, lane);
+                written[dst / 16]++;
+                for (int j = 0; j < 8; ++j)
+                    p.e[dst / 2 + j] = (KIND == KMAJOR) ? op.at(s.rc, s.k + j) : op.at(s.rc + j, s.k);
+            }
+    for (int c : written)
+        if (c != 1) { g_fail++; std::printf("stage: a 16-byte LDS chunk written %d times\n", c); return; }
+}
+
+// bank conflicts: extra cycles = (max distinct addresses on one bank) - 1 per service group
+static long conflicts(const std::vector<int> &addr, const std::vector<std::vector<int>> &groups, int bytes, int nbanks) {
+    long extra = 0;
+    for (const auto &grp : groups) {
+        std::vector<std::set<int>> per(nbanks);
+        for (int l : grp)
+            for (int b = 0; b < bytes; b += 4) per[((addr[l] + b) / 4) % nbanks].insert((addr[l] + b) / 4);
+        size_t worst = 1;
+        for (auto &s : per) worst = s.size() > worst ? s.size() : worst;
+        extra += (long)worst - 1;
+    }
+    return extra;
+}
+static std::vector<std::vector<int>> groups_b128() {
+    return {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27},
+            {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31},
+            {32, 33, 34, 35, 44, 45, 46, 47, 52, 53, 54, 55, 56, 57, 58, 59},
+            {36, 37, 38, 39, 40, 41, 42, 43, 48, 49, 50, 51, 60, 61, 62, 63}};
+}
+static std::vector<std::vector<int>> groups_2x32() {
+    std::vector<std::vector<int>> g(2);
+    for (int l = 0; l < 64; ++l) g[l / 32].push_back(l);
+    return g;
+}
+
+// fragment values: frag[lane][j] = operand value for (row/col base + (lane & 31), k = 16 s + 8 (lane >> 5) + j)
+template <int KIND, bool IS_A>
+static void read_frag(const Piece &p, int w, int f, int s, int16_t frag[64][8]) {
+    if (KIND == KMAJOR) {
+        std::vector<int> addr(64);
+        for (int lane = 0; lane < 64; ++lane) {
+            addr[lane] = frag_off_kmajor<IS_A>(w, f, s, lane);
+            for (int j = 0; j < 8; ++j) frag[lane][j] = p.e[addr[lane] / 2 + j];
+        }
+        g_conf_b128 += conflicts(addr, groups_b128(), 16, 64);
+    } else {
+        for (int u = 0; u < 2; ++u) {
+            std::vector<int> addr(64);
+            for (int lane = 0; lane < 64; ++lane) addr[lane] = frag_off_kstrided<IS_A>(w, f, s, u, lane);
+            g_conf_tr += conflicts(addr, groups_2x32(), 8, 64);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int g0 = lane & ~15, L = lane & 15;
+                for (int j = 0; j < 4; ++j) frag[lane][4 * u + j] = p.e[addr[g0 + (L / 4) + 4 * j] / 2 + (L % 4)];
+            }
+        }
+    }
+}
+
+template <int AK, int BK>
+static void run(int BN, unsigned seed) {
+    const int wtn = BN / 4, nfj = BN / 128;
+    Operand A{256, std::vector<int16_t>(256 * 64)}, B{BN, std::vector<int16_t>((size_t)BN * 64)};
+    srand(seed);
+    for (auto &x : A.v) x = (int16_t)(rand() % 7 - 3);
+    for (auto &x : B.v) x = (int16_t)(rand() % 5 - 2);
+    std::vector<Piece> pa(2), pb(2);
+    stage_piece<AK, true>(A, 0, wtn, pa[0]);
+    stage_piece<AK, true>(A, 1, wtn, pa[1]);
+    for (int h = 0; h < nfj; ++h) stage_piece<BK, false>(B, h, wtn, pb[h]);
+
+    std::vector<int> C((size_t)256 * BN, 0x7fffffff);
+    for (int wave = 0; wave < 8; ++wave) {
+        const int wr = wave >> 2, wc = wave & 3;
+        // accumulators acc[fi][fj][lane][r]
+        std::vector<int> acc((size_t)4 * nfj * 64 * 16, 0);
+        for (int s = 0; s < 4; ++s)
+            for (int fi = 0; fi < 4; ++fi)
+                for (int fj = 0; fj < nfj; ++fj) {
+                    int16_t af[64][8], bf[64][8];
+                    read_frag<AK, true>(pa[fi >> 1], wr, fi & 1, s, af);
+                    read_frag<BK, false>(pb[fj], wc, 0, s, bf);
+                    // acc = mfma(bf, af, acc): MFMA-A = bf (rows = output columns), MFMA-B = af (columns = output rows)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int r = 0; r < 16; ++r) {
+                            const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
+                            int sum = 0;
+                            for (int k = 0; k < 16; ++k) sum += (int)bf[i + 32 * (k / 8)][k % 8] * (int)af[j + 32 * (k / 8)][k % 8];
+                            acc[(((size_t)fi * nfj + fj) * 64 + lane) * 16 + r] += sum;
+                        }
+                }
+        // (1) the accumulator -> (row, column) map used by the fp32 epilogue
+        // (2) the bf16 epilogue through the wave-private LDS region
+        std::vector<int16_t> region((size_t)128 * wtn, -32768);
+        for (int fi = 0; fi < 4; ++fi)
+            for (int fj = 0; fj < nfj; ++fj)
+                for (int lane = 0; lane < 64; ++lane) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = 128 * wr + 32 * fi + (lane & 31);
+                        const int col = wtn * wc + 32 * fj + acc_col(r, lane);
+                        const int want = [&] { int t = 0; for (int k = 0; k < 64; ++k) t += (int)A.at(row, k) * (int)B.at(col, k); return t; }();
+                        const int got = acc[(((size_t)fi * nfj + fj) * 64 + lane) * 16 + r];
+                        if (got != want && g_fail < 10) { g_fail++; std::printf("acc map: wave %d fi %d fj %d lane %d r %d: got %d want %d\n", wave, fi, fj, lane, r, got, want); }
+                    }
+                    for (int q = 0; q < 4; ++q) {
+                        const int off = epi_write_off(fi, fj, q, lane, wtn);
+                        for (int e = 0; e < 4; ++e) region[off / 2 + e] = (int16_t)acc[(((size_t)fi * nfj + fj) * 64 + lane) * 16 + 4 * q + e];
+                    }
+                }
+        const int passes = 128 / (64 / (wtn / 8));
+        for (int it = 0; it < passes; ++it)
+            for (int lane = 0; lane < 64; ++lane) {
+                int row, c, off;
+                epi_read_map(it, lane, wtn, &row, &c, &off);
+                for (int e = 0; e < 8; ++e) C[(size_t)(128 * wr + row) * BN + wtn * wc + 8 * c + e] = region[off / 2 + e];
+            }
+    }
+    for (int m = 0; m < 256; ++m)
+        for (int n = 0; n < BN; ++n) {
+            int want = 0;
+            for (int k = 0; k < 64; ++k) want += (int)A.at(m, k) * (int)B.at(n, k);
+            if (C[(size_t)m * BN + n] != want && g_fail < 10) { g_fail++; std::printf("C[%d][%d] = %d, want %d (AK %d BK %d BN %d)\n", m, n, C[(size_t)m * BN + n], want, AK, BK, BN); }
+        }
+    std::printf("AK=%d BK=%d BN=%d: %s; bank-conflict cycles: b128 %ld, tr %ld\n", AK, BK, BN, g_fail ? "FAIL" : "ok", g_conf_b128, g_conf_tr);
+}
+
+int main() {
+    for (int BN : {256, 128}) {
+        run<KMAJOR, KMAJOR>(BN, 1);
+        run<KMAJOR, KSTRIDED>(BN, 2);
+        run<KSTRIDED, KSTRIDED>(BN, 3);
+    }
+    // tile order is a bijection for awkward totals
+    for (long total : {1L, 7L, 8L, 9L, 771L, 2313L, 3084L, 252L}) {
+        std::vector<int> seen(total, 0);
+        for (long id = 0; id < total; ++id) {
+            const long p = xcd_order(id, total);
+            if (p < 0 || p >= total) { g_fail++; std::printf("xcd_order out of range\n"); break; }
+            seen[p]++;
+        }
+        for (int c : seen) if (c != 1) { g_fail++; std::printf("xcd_order(total=%ld) is not a bijection\n", total); break; }
+    }
+    std::printf(g_fail ? "FAILED\n" : "ALL OK\n");
+    return g_fail ? 1 : 0;
+}

@@ -1,0 +1,147 @@
+"""xq_gemm_bf16_{nt,nn,tn} (csrc/xq_gemm.hip) against fp32 matrix products of the same bf16 operands, through the C-ABI.
+
+The reference computes nn.Linear under bf16 autocast as a bf16 GEMM with fp32 accumulation and one rounding of the result
+(dino_enc/vision_transformer.py:145-197, :295-339) — which is what an fp32 product of the bf16 operands rounded once to bf16
+is, up to the summation order.  Bound: half a bf16 ulp of the result (2^-9 relative) + the fp32 accumulation-order noise
+(<= 2e-6 * sum |a b| for K <= 3072, cdna_hip_programming.md §3) -> |err| <= 2^-8 |ref| + 4e-6 * sum|ab|.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+SIMPLE, RING = 1, 2
+
+
+def _ops():
+    from imagefolder_amd import ops_dense
+    return ops_dense
+
+
+def _check_bf16(out, ref, absprod):
+    err = (out.float() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + absprod * 4e-6 + 1e-30
+    worst = (err / bound).max().item()
+    assert worst <= 1.0, f"max err/bound {worst:.3f} (max abs err {err.max().item():.3e})"
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda") * scale).to(torch.bfloat16)
+
+
+# (M, N, K): ragged M, BN = 128 tiles (N = 384 / 1152), N below one tile, the ViT-B layer shapes at a small batch
+NT_SHAPES = [(256, 256, 128), (300, 256, 128), (1, 256, 64), (513, 768, 768), (2052, 2304, 768), (2052, 768, 3072),
+             (2056, 3072, 768), (788, 384, 384), (788, 1152, 384), (788, 384, 1536), (1024, 32, 768), (640, 200, 192)]
+
+
+@pytest.mark.parametrize("impl", [SIMPLE, RING])
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_gemm_nt(M, N, K, impl):
+    od = _ops()
+    if impl == RING and (N % 256 or K < 128):
+        pytest.skip("ring schedule: 256-column tiles, K >= 128")
+    x, w = _rand((M, K), 1), _rand((N, K), 2, 0.05)
+    bias = torch.randn(N, device="cuda")
+    od.GEMM_SCHEDULE = impl
+    try:
+        y = od.gemm_nt(x, w, bias)
+        y0 = od.gemm_nt(x, w, None)
+    finally:
+        od.GEMM_SCHEDULE = 0
+    ref = x.float() @ w.float().t()
+    absprod = x.float().abs() @ w.float().abs().t()
+    _check_bf16(y0, ref, absprod)
+    _check_bf16(y, ref + bias, absprod + bias.abs())
+
+
+@pytest.mark.parametrize("impl", [SIMPLE, RING])
+@pytest.mark.parametrize("M,N,K", NT_SHAPES)
+def test_gemm_nn(M, N, K, impl):
+    """g_x[M][N] = g[M][K] @ W[K][N] (W = forward weight [out = K][in = N])"""
+    od = _ops()
+    if impl == RING and (N % 256 or K < 128):
+        pytest.skip("ring schedule: 256-column tiles, K >= 128")
+    g, w = _rand((M, K), 3), _rand((K, N), 4, 0.05)
+    od.GEMM_SCHEDULE = impl
+    try:
+        gx = od.gemm_nn(g, w)
+    finally:
+        od.GEMM_SCHEDULE = 0
+    _check_bf16(gx, g.float() @ w.float(), g.float().abs() @ w.float().abs())
+
+
+# (R, P, Q): R not a multiple of 64, fewer than two K tiles, BN = 128, ViT-B shapes at a small batch
+TN_SHAPES = [(256, 256, 256), (2052, 2304, 768), (2052, 768, 768), (2056, 768, 3072), (1000, 3072, 768), (100, 256, 256),
+             (788, 384, 1536), (788, 1152, 384), (4104, 768, 768), (640, 200, 192), (0, 64, 64)]
+
+
+@pytest.mark.parametrize("impl", [SIMPLE, RING])
+@pytest.mark.parametrize("R,P,Q", TN_SHAPES)
+def test_gemm_tn(R, P, Q, impl):
+    od = _ops()
+    if impl == RING and Q % 256:
+        pytest.skip("ring schedule: 256-column tiles")
+    g, x = _rand((R, P), 5), _rand((R, Q), 6)
+    od.GEMM_SCHEDULE = impl
+    try:
+        gw = od.gemm_tn(g, x)
+    finally:
+        od.GEMM_SCHEDULE = 0
+    ref = g.float().t() @ x.float()
+    absprod = g.float().abs().t() @ x.float().abs()
+    err = (gw - ref).abs()
+    bound = absprod * 4e-6 + 1e-30 if R else torch.full_like(ref, 1e-30)
+    assert (err <= bound).all(), f"max err {err.max().item():.3e}, max err/bound {(err / bound).max().item():.3f}"
+
+
+@pytest.mark.parametrize("op", ["nt", "nn", "tn"])
+def test_gemm_ring_equals_simple_and_is_repeatable(op):
+    """The ring schedule (counted vmcnt, staggered wave rows) must give bit-identical results to the barrier-per-tile
+    schedule (same MFMA order per accumulator) and to itself over repeated launches on a busy chip (race screen)."""
+    od = _ops()
+    M, N, K = 16416, 768, 768           # 64.1 row tiles: ragged last tile, 195 workgroups
+    if op == "tn":
+        a, b = _rand((M, N), 7), _rand((M, 2304), 8)
+        run = lambda: od.gemm_tn(a, b)
+    elif op == "nn":
+        a, b = _rand((M, K), 7), _rand((K, N), 8, 0.05)
+        run = lambda: od.gemm_nn(a, b)
+    else:
+        a, b = _rand((M, K), 7), _rand((N, K), 8, 0.05)
+        bias = torch.randn(N, device="cuda")
+        run = lambda: od.gemm_nt(a, b, bias)
+    od.GEMM_SCHEDULE = SIMPLE
+    try:
+        base = run()
+        od.GEMM_SCHEDULE = RING
+        outs = [run() for _ in range(12)]
+    finally:
+        od.GEMM_SCHEDULE = 0
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o, base)
+
+
+def test_linear_fn_matches_library_autograd():
+    """LinearFn on the hand-written GEMMs vs the same Function on the library GEMMs (values and the three gradients)."""
+    od = _ops()
+    torch.manual_seed(0)
+    x = torch.randn(4, 513, 768, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    w = (torch.randn(2304, 768, device="cuda") * 0.03).requires_grad_(True)
+    b = torch.randn(2304, device="cuda").requires_grad_(True)
+    go = torch.randn(4, 513, 2304, device="cuda").to(torch.bfloat16)
+    res = {}
+    for impl in ("hip", "library"):
+        od.GEMM_IMPL = impl
+        try:
+            for t in (x, w, b):
+                t.grad = None
+            y = od.LinearFn.apply(x, w, b, False)
+            y.backward(go)
+            res[impl] = (y.detach().float(), x.grad.float(), w.grad.float(), b.grad.float())
+        finally:
+            od.GEMM_IMPL = "hip"
+    for a, r, tol in zip(res["hip"], res["library"], (2e-2, 2e-2, 2e-3, 1e-3)):
+        scale = r.abs().max().item()
+        assert (a - r).abs().max().item() <= tol * scale, f"{(a - r).abs().max().item()} vs scale {scale}"

@@ -1,25 +1,81 @@
-"""Dev tool (GPU box): library GEMM rates for the ViT-B train-step shapes, incl. split-K variants of the weight-gradient GEMM."""
-import torch, time, sys
-dev = "cuda"
-M = 128 * 513
-def bench(fn, n=20):
-    for _ in range(3): fn()
-    torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(n): fn()
-    torch.cuda.synchronize(); return (time.perf_counter() - t) / n
-shapes = [("qkv", 2304, 768), ("proj", 768, 768), ("fc1", 3072, 768), ("fc2", 768, 3072)]
-for name, N, K in shapes:
-    x = torch.randn(M, K, device=dev, dtype=torch.bfloat16)
-    W = torch.randn(N, K, device=dev, dtype=torch.bfloat16)
-    b = torch.randn(N, device=dev, dtype=torch.bfloat16)
-    g = torch.randn(M, N, device=dev, dtype=torch.bfloat16)
-    fl = 2.0 * M * N * K
-    t = bench(lambda: torch.addmm(b, x, W.t())); print(f"{name:5s} fwd  addmm          {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
-    t = bench(lambda: torch.mm(g, W)); print(f"{name:5s} gx   mm             {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
-    t = bench(lambda: torch.mm(g.t(), x)); print(f"{name:5s} gW   mm bf16out    {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
-    t = bench(lambda: torch.mm(g.t(), x, out_dtype=torch.float32)); print(f"{name:5s} gW   mm f32out     {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
-    for S in (4, 8, 16, 32):
-        gs, xs = g.view(S, M // S, N), x.view(S, M // S, K)
-        t = bench(lambda: torch.bmm(gs.transpose(1, 2), xs, out_dtype=torch.float32).sum(0)); print(f"{name:5s} gW   bmm S={S:2d} f32    {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
-    # gW as x^T g then transposed view (other operand order)
-    t = bench(lambda: torch.mm(x.t(), g, out_dtype=torch.float32)); print(f"{name:5s} gW^T mm f32out     {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
+"""Times xq_gemm_bf16_{nt,nn,tn} (simple and ring schedules) against the library GEMMs (hipBLASLt through torch) on the ViT-B
+layer shapes of the default bench workload (B = 128, 513 / 514 tokens).  Random operands (cdna_hip_programming.md §5.4 rule 25).
+    python tools/bench_gemm.py [--out gpurun_out/gemm_shapes.txt] [--rows 65664]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagefolder_amd import ops_dense as od  # noqa: E402
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--rows", type=int, nargs="*", default=[65664, 65792])
+    ap.add_argument("--dims", type=int, nargs="*", default=[768])
+    a = ap.parse_args()
+    lines = []
+
+    def emit(s):
+        print(s, flush=True)
+        lines.append(s)
+
+    for D in a.dims:
+        layers = {"qkv": (3 * D, D), "proj": (D, D), "fc1": (4 * D, D), "fc2": (D, 4 * D)}
+        for M in a.rows:
+            for name, (N, K) in layers.items():
+                x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+                w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+                g = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+                bias = torch.randn(N, device="cuda")
+                b16 = bias.to(torch.bfloat16)
+                fl = 2.0 * M * N * K
+                cases = [
+                    ("fwd  library addmm", lambda: torch.addmm(b16, x, w.t())),
+                    ("gx   library mm", lambda: torch.mm(g, w)),
+                    ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
+                ]
+                for sched, tag in ((1, "simple"), (2, "ring")):
+                    def mk(f, sched=sched):
+                        def run():
+                            od.GEMM_SCHEDULE = sched
+                            try:
+                                return f()
+                            finally:
+                                od.GEMM_SCHEDULE = 0
+                        return run
+                    cases += [
+                        (f"fwd  hip nt {tag}", mk(lambda: od.gemm_nt(x, w, bias))),
+                        (f"gx   hip nn {tag}", mk(lambda: od.gemm_nn(g, w))),
+                        (f"gW   hip tn {tag}", mk(lambda: od.gemm_tn(g, x))),
+                    ]
+                for label, fn in cases:
+                    try:
+                        ms = timeit(fn)
+                        emit(f"D{D} M{M} {name:5s} N{N:5d} K{K:5d} {label:28s} {ms:8.3f} ms {fl / ms / 1e9:8.1f} TF/s")
+                    except Exception as e:  # noqa: BLE001
+                        emit(f"D{D} M{M} {name:5s} {label:28s} FAILED: {e}")
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
