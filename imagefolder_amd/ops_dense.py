@@ -166,6 +166,15 @@ def _w16(weight):
     for frozen ones (semantic teacher), an on-the-fly cast otherwise."""
     w16 = getattr(weight, "_xq_w16", None)
     if w16 is not None:
+        if weight._version != getattr(weight, "_xq_w16_version", weight._version):
+            # the master was rewritten by a torch in-place op since the optimizer kernel last wrote the shadow
+            # (load_state_dict, manual init): re-cast this tensor and invalidate what is derived from it
+            with torch.no_grad():
+                w16.copy_(weight.detach())
+            weight._xq_w16_version = weight._version
+            arena = getattr(weight, "_xq_arena", None)
+            if arena is not None:
+                arena.epoch += 1
         return w16
     if not weight.requires_grad:
         cache = getattr(weight, "_xq_w16_frozen", None)
@@ -439,7 +448,11 @@ def _packed_conv_weight(weight, for_data_grad: bool):
     """bf16 K-major pack of a conv3x3 weight, cached on the parameter and refreshed when it changes."""
     key = "_xq_pack_dgrad" if for_data_grad else "_xq_pack_fwd"
     cache = getattr(weight, key, None)
-    if cache is not None and cache[0] == weight._version and cache[1].device == weight.device:
+    # arena-owned parameters are updated by the optimizer kernel through raw pointers, which never bumps `_version`:
+    # the arena's epoch (bumped by every optimizer step / resync) is part of the key
+    arena = getattr(weight, "_xq_arena", None)
+    stamp = (weight._version, -1 if arena is None else arena.epoch)
+    if cache is not None and cache[0] == stamp and cache[1].device == weight.device:
         return cache[1]
     Cout, Cin = weight.shape[0], weight.shape[1]
     w32 = weight.detach().float().contiguous()
@@ -450,7 +463,7 @@ def _packed_conv_weight(weight, for_data_grad: bool):
     with torch.cuda.device(weight.device):
         rc = _lib.lib().xq_conv3x3_pack_weights(ptr(w32), Cout, Cin, int(for_data_grad), ptr(wp), _stream(weight))
     check(rc, "xq_conv3x3_pack_weights")
-    setattr(weight, key, (weight._version, wp))
+    setattr(weight, key, (stamp, wp))
     return wp
 
 

@@ -67,6 +67,28 @@ class FlatArena:
                 for p, o in zip(self.params, self.offsets):
                     p._xq_w16 = self.p16[o:o + p.numel()].view(p.shape)
         self.step_count = 0
+        # `epoch` counts the updates that reach the masters through raw pointers (the optimizer kernel, resync): those never
+        # bump torch's per-tensor version counter, so every cache derived from a parameter (packed conv weights, ...) keys
+        # on (p._version, p._xq_arena.epoch).  `_xq_w16_version` = p._version at the last refresh of the bf16 shadow:
+        # torch in-place updates of a parameter (load_state_dict, manual init) DO bump p._version and are picked up by
+        # ops_dense._w16 on the next use.
+        self.epoch = 0
+        for p in self.params:
+            p._xq_arena = self
+            p._xq_w16_version = p._version
+
+    @torch.no_grad()
+    def resync(self, ema: bool = False):
+        """Call after the masters were overwritten (checkpoint load, weight surgery): refreshes the bf16 shadow, invalidates
+        the derived caches and — `ema=True`, the reference's update_ema(ema, model, decay=0) after loading
+        (xqgan_train.py:384) — re-seeds the EMA copy from the masters."""
+        if self.p16 is not None:
+            self.p16.copy_(self.p)
+        if ema and self.ema is not None:
+            self.ema.copy_(self.p)
+        self.epoch += 1
+        for p in self.params:
+            p._xq_w16_version = p._version
 
     def rebind_grads(self):
         """autograd keeps accumulating into the arena as long as p.grad stays the view; call after anything that
@@ -80,29 +102,111 @@ class FlatArena:
 
 
 class GradAllReducer:
-    """Chunked asynchronous all-reduce (SUM) of a flat gradient arena.  RCCL launches run on its internal stream:
-    `start()` orders them after the backward already queued on the compute stream, `wait()` makes the compute
-    stream wait for them; anything enqueued in between (the discriminator step) overlaps with the transfers."""
+    """Chunked asynchronous all-reduce (SUM) of a flat gradient arena over RCCL (xGMI).
 
-    def __init__(self, flat_grad: torch.Tensor, group=None, chunk_bytes: int = 256 << 20):
+    Chunks are runs of whole parameters (>= chunk_bytes each).  With `params` given, every parameter carries a
+    post-accumulate-grad hook: the moment the backward pass has deposited the last gradient of a chunk, that chunk's
+    all-reduce is enqueued (RCCL's stream waits for the compute stream at that point only), so the transfers of the
+    decoder's gradients run under the encoder's backward — the job DDP's buckets do in the reference
+    (xqgan_train.py:412,455) without its per-bucket copies.  `start()` (after backward) enqueues whatever is left (parameters
+    that received no gradient this step), `wait()` makes the compute stream wait for all of them and records how long it
+    had to (`exposed_ms`, HIP events).  Anything enqueued between start() and wait() — the discriminator step — overlaps.
+    comm_dtype=torch.bfloat16 halves the bytes on the links (cast -> all-reduce -> cast back into the fp32 arena); default
+    is the arena's fp32, which is what DDP reduces.  always=True runs the collectives at world size 1 too (tests)."""
+
+    def __init__(self, flat_grad: torch.Tensor, group=None, chunk_bytes: int = 64 << 20, params=None, offsets=None,
+                 comm_dtype: Optional[torch.dtype] = None, always: bool = False):
         self.g = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.active = self.world > 1 or (always and dist.is_available() and dist.is_initialized())
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, flat_grad.dtype) else None
         per = max(1, chunk_bytes // 4)
-        self.chunks = [(s, min(s + per, flat_grad.numel())) for s in range(0, flat_grad.numel(), per)]
+        n = flat_grad.numel()
+        self.chunks, self._chunk_of_param = [], []
+        if params is not None and offsets is not None and len(params):
+            start, cur = 0, 0
+            for i, (p, o) in enumerate(zip(params, offsets)):
+                end = offsets[i + 1] if i + 1 < len(params) else n
+                self._chunk_of_param.append(cur)
+                if end - start >= per or i + 1 == len(params):
+                    self.chunks.append((start, end))
+                    start, cur = end, cur + 1
+        else:
+            self.chunks = [(s, min(s + per, n)) for s in range(0, n, per)]
+        self._need = [0] * len(self.chunks)
+        for c in self._chunk_of_param:
+            self._need[c] += 1
+        self._left = list(self._need)
+        self._launched = [False] * len(self.chunks)
         self._works = []
+        self._armed = False
+        self.exposed_ms = []          # one entry per wait(): time the compute stream was blocked by the collectives
+        self._ev = None
+        if self.active and params is not None:
+            for i, p in enumerate(params):
+                p.register_post_accumulate_grad_hook(self._make_hook(self._chunk_of_param[i]))
 
-    def start(self):
-        if self.world == 1:
+    def _make_hook(self, ci):
+        def hook(_p):
+            if not self._armed:
+                return
+            self._left[ci] -= 1
+            if self._left[ci] == 0 and not self._launched[ci]:
+                self._launch(ci)
+        return hook
+
+    def _launch(self, ci):
+        s, e = self.chunks[ci]
+        self._launched[ci] = True
+        if self.comm_dtype is not None:
+            buf = self.g[s:e].to(self.comm_dtype)
+            w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append((w, s, e, buf))
+        else:
+            w = dist.all_reduce(self.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._works.append((w, s, e, None))
+
+    def arm(self):
+        """before the backward pass whose gradients are to be reduced"""
+        if not self.active:
             return
         assert not self._works, "previous all-reduce not waited for"
-        for s, e in self.chunks:
-            self._works.append(dist.all_reduce(self.g[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._left = list(self._need)
+        self._launched = [False] * len(self.chunks)
+        self._armed = True
+
+    def start(self):
+        if not self.active:
+            return
+        self._armed = False
+        for ci in range(len(self.chunks)):
+            if not self._launched[ci]:
+                self._launch(ci)
 
     def wait(self):
-        for w in self._works:
+        if not self._works:
+            return
+        timed = self.g.is_cuda
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        for w, s, e, buf in self._works:
             w.wait()
+            if buf is not None:
+                self.g[s:e].copy_(buf)
+        if timed:
+            e1.record()
+            self._ev = (e0, e1)
         self._works = []
+        self._launched = [False] * len(self.chunks)
+
+    def collect_exposed_ms(self):
+        """call after a device synchronisation: duration of the last wait() on the compute stream"""
+        if self._ev is not None:
+            self.exposed_ms.append(self._ev[0].elapsed_time(self._ev[1]))
+            self._ev = None
+        return self.exposed_ms
 
 
 class ArenaOptimizer:
@@ -110,12 +214,54 @@ class ArenaOptimizer:
     (optimizer, ema, DDP reducer) trio for one parameter set."""
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2, eps=1e-8, ema_decay=0.9999, use_ema=True,
-                 group=None, chunk_bytes: int = 256 << 20):
+                 group=None, chunk_bytes: int = 64 << 20, comm_dtype: Optional[torch.dtype] = None, hooks: bool = True,
+                 always_reduce: bool = False):
         self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
         self.ema_decay = ema_decay
         self.arena = FlatArena(params, with_ema=use_ema)
-        self.reducer = GradAllReducer(self.arena.g, group=group, chunk_bytes=chunk_bytes)
+        self.reducer = GradAllReducer(self.arena.g, group=group, chunk_bytes=chunk_bytes,
+                                      params=self.arena.params if hooks else None, offsets=self.arena.offsets if hooks else None,
+                                      comm_dtype=comm_dtype, always=always_reduce)
         self.world = self.reducer.world
+
+    # -- checkpointing: the layout of torch.optim.AdamW.state_dict() (what the reference saves as "optimizer" /
+    #    "optimizer_disc", xqgan_train.py:580-600), one entry per parameter in arena order, plus the EMA copy ------------------
+    def state_dict(self):
+        a = self.arena
+        state = {}
+        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(a.step_count)), "exp_avg": a.m[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": a.v[o:o + n].view(p.shape).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "params": list(range(len(a.params)))}
+        out = {"state": state, "param_groups": [group]}
+        if a.ema is not None:
+            out["ema"] = [a.ema[o:o + p.numel()].view(p.shape).clone() for p, o in zip(a.params, a.offsets)]
+        return out
+
+    @torch.no_grad()
+    def load_state_dict(self, sd):
+        a = self.arena
+        st = sd["state"]
+        assert len(st) in (0, len(a.params)), "optimizer state does not match the parameter list"
+        steps = set()
+        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+            e = st.get(i, st.get(str(i))) if st else None
+            if e is None:
+                continue
+            n = p.numel()
+            a.m[o:o + n].copy_(e["exp_avg"].reshape(-1))
+            a.v[o:o + n].copy_(e["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(e["step"])))
+        assert len(steps) <= 1, "per-parameter step counts differ: not an AdamW state this optimizer can hold"
+        a.step_count = steps.pop() if steps else 0
+        g = sd["param_groups"][0]
+        self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
+        if "ema" in sd and a.ema is not None:
+            for t, p, o in zip(sd["ema"], a.params, a.offsets):
+                a.ema[o:o + p.numel()].copy_(t.reshape(-1))
+        a.resync(ema=False)   # the masters were (re)loaded by the model's own load_state_dict
 
     def zero_grad(self):
         self.arena.g.zero_()
@@ -123,6 +269,7 @@ class ArenaOptimizer:
     def step(self):
         a = self.arena
         a.step_count += 1
+        a.epoch += 1            # masters change through raw pointers below: derived caches must refresh
         if a.p.is_cuda:
             with torch.cuda.device(a.p.device):
                 rc = _lib.lib().xq_adamw_ema_step(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
@@ -161,13 +308,15 @@ class TokenizerTrainStep:
 
     def __init__(self, model: torch.nn.Module, gen_loss_fn: Callable, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2,
                  eps=1e-8, ema_decay=0.9999, use_ema=True, amp_dtype: Optional[torch.dtype] = torch.bfloat16,
-                 disc_step_fn: Optional[Callable] = None, group=None, chunk_bytes: int = 256 << 20):
+                 disc_step_fn: Optional[Callable] = None, group=None, chunk_bytes: int = 64 << 20,
+                 comm_dtype: Optional[torch.dtype] = None, hooks: bool = True, always_reduce: bool = False):
         self.model = model
         self.gen_loss_fn = gen_loss_fn
         self.disc_step_fn = disc_step_fn
         self.amp_dtype = amp_dtype
         self.opt = ArenaOptimizer(model.parameters(), lr=lr, betas=betas, weight_decay=weight_decay, eps=eps,
-                                  ema_decay=ema_decay, use_ema=use_ema, group=group, chunk_bytes=chunk_bytes)
+                                  ema_decay=ema_decay, use_ema=use_ema, group=group, chunk_bytes=chunk_bytes,
+                                  comm_dtype=comm_dtype, hooks=hooks, always_reduce=always_reduce)
         self.arena = self.opt.arena
         self.reducer = self.opt.reducer
         self.world = self.opt.world
@@ -181,9 +330,10 @@ class TokenizerTrainStep:
             out = self.model(imgs, epoch, alpha, beta, delta)
             loss_gen = self.gen_loss_fn(out, imgs)
         _marker(50)
+        self.reducer.arm()                         # chunks leave from the backward hooks as soon as they are complete
         loss_gen.backward()
         _marker(62)
-        self.reducer.start()                       # RCCL over xGMI, overlapped with ...
+        self.reducer.start()                       # the rest; RCCL over xGMI, overlapped with ...
         if self.disc_step_fn is not None:
             self.disc_step_fn(imgs, out[0].detach())   # ... the discriminator step (needs only recons.detach())
         self.reducer.wait()
@@ -198,13 +348,26 @@ class DiscriminatorStep:
     autocast, backward, AdamW on vq_loss.discriminator.parameters() — with the head gradients all-reduced once per
     step (DDP reduces them a second, wasted, time during the generator backward: SURVEY §2.3 C2)."""
 
-    def __init__(self, vq_loss, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2, amp_dtype=torch.bfloat16, group=None):
+    def __init__(self, vq_loss, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2, amp_dtype=torch.bfloat16, group=None,
+                 always_reduce: bool = False):
+        """group: give the discriminator its OWN process group (dist.new_group()) — a separate RCCL communicator and stream.
+        On the generator's group its small all-reduce would queue behind the 689 MB gradient transfer that is in flight
+        while this step runs, and the wait below would stall the compute stream until that transfer is through."""
         self.vq_loss = vq_loss
         self.amp_dtype = amp_dtype
         self.opt = ArenaOptimizer(vq_loss.discriminator.parameters(), lr=lr, betas=betas, weight_decay=weight_decay,
-                                  use_ema=False, group=group)
+                                  use_ema=False, group=group, hooks=False, always_reduce=always_reduce)
         self.global_step = 0
         self.fade_blur_schedule = 0
+
+    def state_dict(self):
+        return {"optimizer_disc": self.opt.state_dict(), "global_step": self.global_step,
+                "fade_blur_schedule": self.fade_blur_schedule}
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd["optimizer_disc"])
+        self.global_step = int(sd["global_step"])
+        self.fade_blur_schedule = sd.get("fade_blur_schedule", 0)
 
     def __call__(self, imgs, recons_detached):
         self.opt.arena.rebind_grads()
