@@ -49,6 +49,11 @@ struct GemmArgs {
     int ktiles;             // 64-deep K tiles per split (split s < kt_rem runs one more)
     int kt_rem;
     int tiles_m, tiles_n, splits;
+    // persistent schedule (gemm_pring_kernel): items [0, main_items) are whole tiles with the bf16 epilogue; the remaining
+    // tail_tiles tiles are cut into tail_splits K ranges each, every range writing an fp32 slab [item][256][256] in `slabs`
+    long main_items;
+    int tail_tiles, tail_splits, kt_full;
+    float *slabs;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -405,6 +410,290 @@ __global__ __launch_bounds__(GT) void gemm_ring_kernel(const GemmArgs g) {
 #undef GR_SLOT
 }
 
+// =====================================================================================================================
+// persistent ring schedule: one workgroup per CU walks a list of work items; the piece ring keeps streaming ACROSS items
+// (the pieces of the next item's first 1.5 K tiles are in flight while this item's epilogue runs), so the per-tile prologue
+// latency and the workgroup relaunch disappear (measured on the non-persistent ring: ~6 us of fixed cost per 256 x 256 x 768
+// tile, a quarter of its time).  Items are whole output tiles or, for the tiles beyond the last full round of CUs and for
+// the weight gradient, K ranges of a tile that leave fp32 slabs for slab_reduce_kernel — so that a launch never ends with
+// a round in which a handful of CUs run a full tile while the rest idle.
+//   staging cursor (item, K tile) : runs 1.5 K tiles ahead of the compute position, retargets the stagers when it enters
+//                                   the next item; ring slot parity = parity of the cursor's global K-tile count
+//   per item                      : [wave row 1: +1 barrier] K tiles [wave row 0: +1 barrier] epilogue — both wave rows run
+//                                   their epilogues side by side; the epilogue stages through 4 KiB per wave OUTSIDE the ring
+//   vmcnt                         : stores of the epilogue may still be outstanding in the next item's first phases; they only
+//                                   make the counted waits stricter (more operations pending than the count assumes)
+// =====================================================================================================================
+struct PItem {
+    long m0, n0, k0;
+    int KT;
+    int slab;            // 0: bf16 epilogue into C; 1: fp32 slab
+    long slab_idx;
+};
+
+__device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it) {
+    long tile, split, nsplit;
+    if (p < g.main_items) { tile = p; split = 0; nsplit = 1; it.slab = 0; it.slab_idx = 0; }
+    else {
+        const long q = p - g.main_items;
+        nsplit = g.tail_splits;
+        tile = g.main_items + q / nsplit;
+        split = q - (q / nsplit) * nsplit;
+        it.slab = 1;
+        it.slab_idx = q;
+    }
+    it.m0 = (tile / g.tiles_n) * gm::BM;
+    it.n0 = (tile % g.tiles_n) * 256;
+    const long base = g.kt_full / nsplit, rem = g.kt_full % nsplit;
+    it.k0 = (split * base + (split < rem ? split : rem)) * gm::BKT;
+    it.KT = (int)(base + (split < rem ? 1 : 0));
+}
+
+template <int AK, int BK>
+__global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
+    constexpr int WTN = 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // 8 ring slots + 8 x 4 KiB epilogue staging
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const long G = gridDim.x;
+    const long items = g.main_items + (long)g.tail_tiles * g.tail_splits;
+    long cp = gm::xcd_order(blockIdx.x, G);          // compute position in the item list (stride G)
+    if (cp >= items) return;
+    PItem cit;
+    decode_item(g, cp, cit);
+
+    // staging cursor
+    Stager<AK, true> sa;
+    Stager<BK, false> sb;
+    sa.init(g.A, g.lda, cit.m0, g.M, cit.k0, wave, lane, WTN, 2);
+    sb.init(g.B, g.ldb, cit.n0, g.N, cit.k0, wave, lane, WTN, 2);
+    long sp = cp;
+    int s_kt = 0, s_KT = cit.KT, s_par = 0, r_par = 0;
+    // past the last item the cursor keeps issuing the SAME number of LDS-DMA instructions per phase (re-reading its last K
+    // tile into this wave's own epilogue staging area), so that the counted vmcnt(8) of the phases stays exact to the end
+    // of the stream and one tile body serves every K tile
+    int s_dummy = 0;
+    char *const region = smem + 8 * gm::PIECE_BYTES + wave * 4096;
+
+    f32x16 acc[4][2];
+#define PR_ZERO()                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                 \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.0f;
+    PR_ZERO()
+
+#define PR_SSLOT(Q) (smem + ((s_par << 2) + (Q)) * gm::PIECE_BYTES)
+#define PR_RSLOT(Q) (smem + ((r_par << 2) + (Q)) * gm::PIECE_BYTES)
+    // (dummy mode: destination = region - wave * 2048, so that issue()'s (2 wave + i) * 1024 lands inside this wave's area)
+#define PR_SDST(Q) (s_dummy ? region - wave * 2048 : PR_SSLOT(Q))
+#define PR_STAGE(Q)                                                   \
+    do {                                                              \
+        if ((Q) == 0) sa.issue(0, s_kt, PR_SDST(0), wave);            \
+        else if ((Q) == 1) sb.issue(0, s_kt, PR_SDST(1), wave);       \
+        else if ((Q) == 2) sb.issue(1, s_kt, PR_SDST(2), wave);       \
+        else sa.issue(1, s_kt, PR_SDST(3), wave);                     \
+    } while (0)
+    // next K tile of the stream; entering the next item retargets the stagers (once per item)
+#define PR_ADVANCE()                                                                   \
+    do {                                                                               \
+        s_par ^= 1;                                                                    \
+        if (!s_dummy && ++s_kt == s_KT) {                                              \
+            sp += G;                                                                   \
+            if (sp < items) {                                                          \
+                PItem nx_;                                                             \
+                decode_item(g, sp, nx_);                                               \
+                sa.init(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN, 2);          \
+                sb.init(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN, 2);          \
+                s_KT = nx_.KT;                                                         \
+                s_kt = 0;                                                              \
+            } else {                                                                   \
+                s_dummy = 1;                                                           \
+                s_kt = s_KT - 1;                                                       \
+            }                                                                          \
+        }                                                                              \
+    } while (0)
+
+    bf16x8 af[2][4], bl[4], br[4];
+#define PR_READ_A(Q)                                                                    \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                  \
+        af[0][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, 0, s_, lane);                  \
+        af[1][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, 1, s_, lane);                  \
+    }
+#define PR_READ_B(DST, Q) \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) DST[s_] = read_frag<BK, false>(PR_RSLOT(Q), wc, 0, s_, lane);
+#define PR_PIN(X) asm volatile("" : "+v"(X))
+#define PR_MFMA(FI0, FJ, BFR)                                                                                          \
+    do {                                                                                                               \
+        PR_PIN(acc[FI0][FJ]);                                                                                          \
+        PR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                             \
+            acc[FI0][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[0][s_], acc[FI0][FJ], 0, 0, 0);         \
+            acc[FI0 + 1][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[1][s_], acc[FI0 + 1][FJ], 0, 0, 0); \
+        }                                                                                                              \
+        PR_PIN(acc[FI0][FJ]);                                                                                          \
+        PR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+    } while (0)
+    // one K tile (phases as in gemm_ring_kernel): always one piece staged per phase, always vmcnt(8)
+#define PR_TILE()                                                             \
+    do {                                                                      \
+        PR_READ_B(bl, 1)                                                      \
+        PR_READ_A(0)                                                          \
+        PR_STAGE(2);                                                          \
+        GR_VMCNT(8);                                                          \
+        GR_BARRIER();                                                         \
+        PR_MFMA(0, 0, bl);                                                    \
+        GR_BARRIER();                                                         \
+        PR_READ_B(br, 2)                                                      \
+        PR_STAGE(3);                                                          \
+        GR_VMCNT(8);                                                          \
+        GR_BARRIER();                                                         \
+        PR_MFMA(0, 1, br);                                                    \
+        GR_BARRIER();                                                         \
+        PR_READ_A(3)                                                          \
+        PR_ADVANCE();                                                         \
+        PR_STAGE(0);                                                          \
+        GR_VMCNT(8);                                                          \
+        GR_BARRIER();                                                         \
+        PR_MFMA(2, 1, br);                                                    \
+        GR_BARRIER();                                                         \
+        PR_STAGE(1);                                                          \
+        GR_VMCNT(8);                                                          \
+        GR_BARRIER();                                                         \
+        PR_MFMA(2, 0, bl);                                                    \
+        GR_BARRIER();                                                         \
+        r_par ^= 1;                                                           \
+    } while (0)
+
+    // prologue: K tile 0 of the first item completely, A-top + B-left of its K tile 1
+    PR_STAGE(0);
+    PR_STAGE(1);
+    PR_STAGE(2);
+    PR_STAGE(3);
+    PR_ADVANCE();
+    PR_STAGE(0);
+    PR_STAGE(1);
+    GR_VMCNT(8);
+    GR_BARRIER();
+
+    const int h = lane >> 5;
+    for (;;) {
+        const bool has_next = cp + G < items;
+        if (wr == 1) GR_BARRIER();
+        for (int kt = 0; kt < cit.KT; ++kt) PR_TILE();
+        if (wr == 0) GR_BARRIER();
+        if (!has_next) GR_VMCNT(0);      // the dummy pieces target `region`
+
+        // ---- epilogue of this item (the next item's first pieces are landing meanwhile) ----
+        if (cit.slab) {
+            float *S = g.slabs + (size_t)cit.slab_idx * 65536;
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+                const int row = 128 * wr + 32 * fi + (lane & 31);
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4 *>(S + row * 256 + 64 * wc + 32 * fj + 8 * q + 4 * h) =
+                            make_float4(acc[fi][fj][4 * q + 0], acc[fi][fj][4 * q + 1], acc[fi][fj][4 * q + 2], acc[fi][fj][4 * q + 3]);
+            }
+        } else {
+            const long ncol0 = cit.n0 + 64 * wc;
+            float4 bv[2][4];
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    long n = ncol0 + 32 * fj + 8 * q + 4 * h;
+                    if (n > g.N - 4) n = g.N - 4;
+                    bv[fj][q] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
+#pragma unroll
+            for (int fi = 0; fi < 4; ++fi) {
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        uint2 pk;
+                        pk.x = pack_bf16(acc[fi][fj][4 * q + 0] + bv[fj][q].x, acc[fi][fj][4 * q + 1] + bv[fj][q].y);
+                        pk.y = pack_bf16(acc[fi][fj][4 * q + 2] + bv[fj][q].z, acc[fi][fj][4 * q + 3] + bv[fj][q].w);
+                        *reinterpret_cast<uint2 *>(region + gm::epi_write_off(0, fj, q, lane, WTN)) = pk;
+                    }
+                // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    int row, c, off;
+                    gm::epi_read_map(it, lane, WTN, &row, &c, &off);
+                    const uint4 v = *reinterpret_cast<const uint4 *>(region + off);
+                    const long gr = cit.m0 + 128 * wr + 32 * fi + row;
+                    const long gc = ncol0 + 8 * c;
+                    if (gr < g.M && gc + 8 <= g.N) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
+                }
+            }
+        }
+        if (!has_next) break;
+        PR_ZERO()
+        cp += G;
+        decode_item(g, cp, cit);
+    }
+#undef PR_TILE
+#undef PR_MFMA
+#undef PR_PIN
+#undef PR_READ_A
+#undef PR_READ_B
+#undef PR_ADVANCE
+#undef PR_STAGE
+#undef PR_SSLOT
+#undef PR_SDST
+#undef PR_RSLOT
+#undef PR_ZERO
+}
+
+// slabs [item = tail tile * nsplit + split][256][256] fp32 -> output: the sum over the splits of every tail tile,
+//   bf16 (+ bias) into C (NT / NN tail tiles), or fp32 into out (TN; + the < 64 remainder rows of the reduction, folded in here)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_n,
+                                                          long M, long N, long ldc, const float *__restrict__ bias,
+                                                          __hip_bfloat16 *__restrict__ out16, float *__restrict__ out32,
+                                                          const __hip_bfloat16 *__restrict__ G, const __hip_bfloat16 *__restrict__ X,
+                                                          long r_begin, long r_end) {
+    const long t = blockIdx.x;
+    const long tile = first_tile + t;
+    const long m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+    const int rl = blockIdx.y * 8 + (threadIdx.x >> 5), cl = (threadIdx.x & 31) * 8;
+    const long gr = m0 + rl, gc = n0 + cl;
+    if (gr >= M || gc + 8 > N) return;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nsplit; ++k) {
+        const float *sp = slabs + ((size_t)(t * nsplit + k) * 256 + rl) * 256 + cl;
+        const float4 a = *reinterpret_cast<const float4 *>(sp), b = *reinterpret_cast<const float4 *>(sp + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (out32) {
+        for (long r = r_begin; r < r_end; ++r) {
+            const float gv = __bfloat162float(G[r * M + gr]);
+            const __hip_bfloat16 *x = X + r * N + gc;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = __builtin_fmaf(gv, __bfloat162float(x[e]), v[e]);
+        }
+        float *o = out32 + gr * ldc + gc;
+        *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        if (bias) {
+            const float4 a = *reinterpret_cast<const float4 *>(bias + gc), b = *reinterpret_cast<const float4 *>(bias + gc + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        uint4 pk;
+        pk.x = pack_bf16(v[0], v[1]); pk.y = pack_bf16(v[2], v[3]); pk.z = pack_bf16(v[4], v[5]); pk.w = pack_bf16(v[6], v[7]);
+        *reinterpret_cast<uint4 *>(out16 + gr * ldc + gc) = pk;
+    }
+}
+
 // sum of the split-K slabs (+ the < 64-row remainder of the reduction, folded in here so the tile kernels only see whole K tiles)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restrict__ slabs, int splits, long P, long Q,
                                                             const __hip_bfloat16 *__restrict__ G, const __hip_bfloat16 *__restrict__ X,
@@ -441,77 +730,144 @@ int set_lds(int bytes) {
     return 0;
 }
 
-template <int AK, int BK, int EPI>
-int launch_tiles(const GemmArgs &g, int BN, int impl, hipStream_t s, const char *fn) {
-    const long total = (long)g.tiles_m * g.tiles_n * g.splits;
-    if (total <= 0) return XQ_OK;
-    if (total > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: too many tiles", fn);
-    const bool ring = (impl == XQ_GEMM_RING) || (impl == XQ_GEMM_AUTO && BN == 256 && g.ktiles >= 2);
-    const double kdepth = ((double)g.ktiles * g.splits + g.kt_rem) * 64.0;
-    const int pslot = prof_begin(XQ_PROF_GEMM, 2.0 * (double)g.M * (double)g.N * kdepth, s);
-    if (ring) {
-        if (BN != 256 || g.ktiles < 2) return xq_set_error(XQ_EINVAL, "%s: the ring schedule needs 256-column tiles and K >= 128", fn);
-        const int lds = 8 * gm::PIECE_BYTES;
-        if (set_lds<gemm_ring_kernel<AK, BK, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-        hipLaunchKernelGGL((gemm_ring_kernel<AK, BK, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
-    } else if (BN == 256) {
-        const int lds = 8 * gm::PIECE_BYTES;
-        if (set_lds<gemm_simple_kernel<AK, BK, 256, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-        hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 256, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+int pick_bn(long N) { return N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : (N >= 1024 ? 256 : 128)); }
+
+// splits of the reduction for the weight gradient: fill the chip once, at least two K tiles per split
+int tn_splits(long kt_all, long tiles) {
+    long s = num_cus() / (tiles > 0 ? tiles : 1);
+    if (s > kt_all / 2) s = kt_all / 2;
+    if (s < 1) s = 1;
+    return (int)s;
+}
+
+// persistent schedule: how many whole tiles, how the tiles beyond the last full round of CUs are cut along K
+struct PPlan {
+    long main_items;
+    int tail_tiles, tail_splits;
+    size_t slab_bytes;
+};
+PPlan plan_persistent(long tiles, int kt_full, bool weight_grad) {
+    PPlan p{tiles, 0, 1, 0};
+    const long G = num_cus();
+    if (weight_grad) {
+        p.main_items = 0;
+        p.tail_tiles = (int)tiles;
+        p.tail_splits = tn_splits(kt_full, tiles);
     } else {
-        const int lds = 6 * gm::PIECE_BYTES;
-        if (set_lds<gemm_simple_kernel<AK, BK, 128, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-        hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 128, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+        const long rem = tiles % G;
+        if (tiles > G && rem > 0 && rem <= G / 4 && kt_full >= 4) {
+            long S = G / rem;
+            if (S > kt_full / 2) S = kt_full / 2;
+            if (S >= 2) { p.main_items = tiles - rem; p.tail_tiles = (int)rem; p.tail_splits = (int)S; }
+        }
+    }
+    p.slab_bytes = (size_t)p.tail_tiles * p.tail_splits * 65536 * sizeof(float);
+    return p;
+}
+
+template <int AK, int BK, int EPI>
+int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStream_t s, const char *fn, double flops) {
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    if (tiles <= 0) return XQ_OK;
+    if (tiles * (g.splits > 0 ? g.splits : 1) > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: too many tiles", fn);
+    const bool ring_ok = BN == 256 && g.kt_full >= 2 && (EPI != EPI_F32_SLAB || g.ktiles >= 2);
+    if (impl == XQ_GEMM_AUTO) impl = ring_ok ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
+    if ((impl == XQ_GEMM_RING || impl == XQ_GEMM_PERSISTENT) && !ring_ok)
+        return xq_set_error(XQ_EINVAL, "%s: the ring schedules need 256-column tiles and >= 2 K tiles per work item", fn);
+    const int pslot = prof_begin(XQ_PROF_GEMM, flops, s);
+    if (impl == XQ_GEMM_PERSISTENT) {
+        PPlan pl = plan_persistent(tiles, g.kt_full, EPI == EPI_F32_SLAB);
+        if (pl.slab_bytes > ws_bytes || (pl.slab_bytes && !ws)) {
+            if (EPI == EPI_F32_SLAB) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
+            pl = PPlan{tiles, 0, 1, 0};      // no workspace: every tile whole
+        }
+        g.main_items = pl.main_items;
+        g.tail_tiles = pl.tail_tiles;
+        g.tail_splits = pl.tail_splits;
+        g.slabs = (float *)ws;
+        const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
+        const long grid = items < num_cus() ? items : num_cus();
+        const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
+        if (set_lds<gemm_pring_kernel<AK, BK>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+        hipLaunchKernelGGL((gemm_pring_kernel<AK, BK>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+        if (EPI == EPI_BF16 && pl.tail_tiles)
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
+                               pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
+                               (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L);
+    } else {
+        const long total = tiles * g.splits;
+        if (impl == XQ_GEMM_RING) {
+            const int lds = 8 * gm::PIECE_BYTES;
+            if (set_lds<gemm_ring_kernel<AK, BK, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            hipLaunchKernelGGL((gemm_ring_kernel<AK, BK, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+        } else if (BN == 256) {
+            const int lds = 8 * gm::PIECE_BYTES;
+            if (set_lds<gemm_simple_kernel<AK, BK, 256, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 256, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+        } else {
+            const int lds = 6 * gm::PIECE_BYTES;
+            if (set_lds<gemm_simple_kernel<AK, BK, 128, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 128, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+        }
     }
     prof_end(pslot, s);
     return xq_check_launch(fn);
 }
 
-int pick_bn(long N) { return N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : (N >= 1024 ? 256 : 128)); }
+int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
+    if (M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
+    if (K < 64 || K % 64 || N % 8 || N < 32)
+        return xq_set_error(XQ_EINVAL, "%s: needs K %% 64 == 0, N %% 8 == 0, N >= 32 (K=%ld N=%ld)", fn, (long)K, (long)N);
+    return XQ_OK;
+}
 
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y, int impl,
-                               xq_stream_t stream) {
+extern "C" size_t xq_gemm_bf16_workspace_bytes(int op, int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N <= 0 || K < 0) return 0;
+    const int BN = pick_bn(N);
+    const long tiles = ((M + 255) / 256) * ((N + BN - 1) / BN);
+    const int kt = (int)(K / 64);
+    if (op == XQ_GEMM_OP_TN) {
+        if (kt < 2) return 0;
+        const size_t compact = (BN == 256) ? plan_persistent(tiles, kt, true).slab_bytes : 0;
+        const size_t flat = (size_t)tn_splits(kt, tiles) * M * N * sizeof(float);
+        return compact > flat ? compact : flat;
+    }
+    return BN == 256 ? plan_persistent(tiles, kt, false).slab_bytes : 0;
+}
+
+extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y,
+                               void *ws, size_t ws_bytes, int impl, xq_stream_t stream) {
     const char *fn = "xq_gemm_bf16_nt";
-    if (M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
+    if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
     if (!x || !w || !y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    if (K < 64 || K % 64 || N % 8 || N < 32) return xq_set_error(XQ_EINVAL, "%s: needs K %% 64 == 0, N %% 8 == 0, N >= 32 (K=%ld N=%ld)", fn, (long)K, (long)N);
     const int BN = pick_bn(N);
-    GemmArgs g{(const char *)x, (const char *)w, bias, (char *)y, M, N, K, K, N, (int)(K / 64), 0,
-               (int)((M + 255) / 256), (int)((N + BN - 1) / BN), 1};
-    return launch_tiles<gm::KMAJOR, gm::KMAJOR, EPI_BF16>(g, BN, impl, (hipStream_t)stream, fn);
+    GemmArgs g{};
+    g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
+    g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
+    g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + BN - 1) / BN);
+    return launch_gemm<gm::KMAJOR, gm::KMAJOR, EPI_BF16>(g, BN, impl, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }
 
-extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_t K, void *g_x, int impl, xq_stream_t stream) {
+extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_t K, void *g_x, void *ws, size_t ws_bytes,
+                               int impl, xq_stream_t stream) {
     const char *fn = "xq_gemm_bf16_nn";
-    if (M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
+    if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
     if (!g_y || !w || !g_x) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    if (K < 64 || K % 64 || N % 8 || N < 32) return xq_set_error(XQ_EINVAL, "%s: needs K %% 64 == 0, N %% 8 == 0, N >= 32 (K=%ld N=%ld)", fn, (long)K, (long)N);
     const int BN = pick_bn(N);
-    GemmArgs g{(const char *)g_y, (const char *)w, nullptr, (char *)g_x, M, N, K, N, N, (int)(K / 64), 0,
-               (int)((M + 255) / 256), (int)((N + BN - 1) / BN), 1};
-    return launch_tiles<gm::KMAJOR, gm::KSTRIDED, EPI_BF16>(g, BN, impl, (hipStream_t)stream, fn);
-}
-
-static int tn_splits(int64_t R, int64_t P, int64_t Q, int BN) {
-    const long tiles = ((P + 255) / 256) * ((Q + BN - 1) / BN);
-    const long kt = R / 64;
-    long s = num_cus() / (tiles > 0 ? tiles : 1);
-    if (s < 1) s = 1;
-    if (s > kt / 2) s = kt / 2;       // >= 2 K tiles per split
-    if (s < 1) s = 1;
-    return (int)s;
-}
-
-extern "C" size_t xq_gemm_bf16_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q) {
-    if (R <= 0 || P <= 0 || Q <= 0) return 0;
-    return (size_t)tn_splits(R, P, Q, pick_bn(Q)) * P * Q * 4;
+    GemmArgs g{};
+    g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
+    g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
+    g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + BN - 1) / BN);
+    return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16>(g, BN, impl, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }
 
 extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_t Q, float *g_w, void *ws, size_t ws_bytes,
@@ -523,19 +879,32 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     if (P % 8 || Q % 8 || P < 32 || Q < 32) return xq_set_error(XQ_EINVAL, "%s: needs P, Q multiples of 8 and >= 32 (P=%ld Q=%ld)", fn, (long)P, (long)Q);
     hipStream_t s = (hipStream_t)stream;
     const int BN = pick_bn(Q);
-    int splits = 0;
     const long kt_all = R / 64;
+    GemmArgs g{};
+    g.A = (const char *)g_y; g.B = (const char *)x; g.C = (char *)ws;
+    g.M = P; g.N = Q; g.lda = P; g.ldb = Q; g.ldc = Q;
+    g.tiles_m = (int)((P + 255) / 256); g.tiles_n = (int)((Q + BN - 1) / BN);
+    const long tiles = (long)g.tiles_m * g.tiles_n;
+    bool compact = false;
+    int splits = 0;
     if (kt_all >= 2) {
-        splits = tn_splits(R, P, Q, BN);
-        if (ws_bytes < (size_t)splits * P * Q * 4 || !ws) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
-        GemmArgs g{(const char *)g_y, (const char *)x, nullptr, (char *)ws, P, Q, P, Q, Q, (int)(kt_all / splits), (int)(kt_all % splits),
-                   (int)((P + 255) / 256), (int)((Q + BN - 1) / BN), splits};
-        const int rc = launch_tiles<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, s, fn);
+        splits = tn_splits(kt_all, tiles);
+        g.splits = splits; g.ktiles = (int)(kt_all / splits); g.kt_rem = (int)(kt_all % splits); g.kt_full = (int)kt_all;
+        if (impl == XQ_GEMM_AUTO) impl = BN == 256 ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
+        compact = impl == XQ_GEMM_PERSISTENT;
+        if (!compact && (ws_bytes < (size_t)splits * P * Q * 4 || !ws)) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
+        const int rc = launch_gemm<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, ws, ws_bytes, s, fn, 2.0 * P * Q * (double)(kt_all * 64));
         if (rc) return rc;
     }
     const long done = splits ? kt_all * 64 : 0;   // rows covered by whole K tiles
-    const long quads = (P * Q) / 4;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float *)ws, splits, (long)P,
-                       (long)Q, (const __hip_bfloat16 *)g_y, (const __hip_bfloat16 *)x, done, (long)R, g_w);
+    if (compact) {
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)tiles, 32), dim3(256), 0, s, (const float *)ws, splits, 0L, g.tiles_n, (long)P,
+                           (long)Q, (long)Q, (const float *)nullptr, (__hip_bfloat16 *)nullptr, g_w, (const __hip_bfloat16 *)g_y,
+                           (const __hip_bfloat16 *)x, done, (long)R);
+    } else {
+        const long quads = (P * Q) / 4;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float *)ws, splits, (long)P,
+                           (long)Q, (const __hip_bfloat16 *)g_y, (const __hip_bfloat16 *)x, done, (long)R, g_w);
+    }
     return xq_check_launch(fn);
 }

@@ -211,11 +211,16 @@ def _weight_grad(g2, x2, wdtype):
 # path of tests/test_model_parity.py) and shapes outside the kernels' contract always take the library call.
 import os as _os
 GEMM_IMPL = _os.environ.get("XQ_GEMM", "hip")
-GEMM_SCHEDULE = int(_os.environ.get("XQ_GEMM_SCHEDULE", "0"))   # 0 auto, 1 simple, 2 ring (include/xq_ops.h XQ_GEMM_*)
+GEMM_SCHEDULE = int(_os.environ.get("XQ_GEMM_SCHEDULE", "0"))   # 0 auto, 1 simple, 2 ring, 3 persistent (include/xq_ops.h XQ_GEMM_*)
 
 
 def _gemm_ok(rows, n_out, k_red):
     return rows > 0 and k_red >= 64 and k_red % 64 == 0 and n_out % 8 == 0 and n_out >= 32
+
+
+def _gemm_ws(op, M, N, K, dev):
+    nbytes = _lib.lib().xq_gemm_bf16_workspace_bytes(op, M, N, K)
+    return (torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None), nbytes
 
 
 def gemm_nt(x2, W, bias32):
@@ -223,8 +228,9 @@ def gemm_nt(x2, W, bias32):
     M, K = x2.shape
     N = W.shape[0]
     y = torch.empty(M, N, dtype=torch.bfloat16, device=x2.device)
+    ws, nbytes = _gemm_ws(0, M, N, K, x2.device)
     with torch.cuda.device(x2.device):
-        rc = _lib.lib().xq_gemm_bf16_nt(ptr(x2), ptr(W), ptr(bias32), M, N, K, ptr(y), GEMM_SCHEDULE, _stream(x2))
+        rc = _lib.lib().xq_gemm_bf16_nt(ptr(x2), ptr(W), ptr(bias32), M, N, K, ptr(y), ptr(ws), nbytes, GEMM_SCHEDULE, _stream(x2))
     check(rc, "xq_gemm_bf16_nt")
     return y
 
@@ -234,8 +240,9 @@ def gemm_nn(g2, W):
     M, Kr = g2.shape
     N = W.shape[1]
     gx = torch.empty(M, N, dtype=torch.bfloat16, device=g2.device)
+    ws, nbytes = _gemm_ws(1, M, N, Kr, g2.device)
     with torch.cuda.device(g2.device):
-        rc = _lib.lib().xq_gemm_bf16_nn(ptr(g2), ptr(W), M, N, Kr, ptr(gx), GEMM_SCHEDULE, _stream(g2))
+        rc = _lib.lib().xq_gemm_bf16_nn(ptr(g2), ptr(W), M, N, Kr, ptr(gx), ptr(ws), nbytes, GEMM_SCHEDULE, _stream(g2))
     check(rc, "xq_gemm_bf16_nn")
     return gx
 
@@ -245,8 +252,7 @@ def gemm_tn(g2, x2):
     R, P = g2.shape
     Q = x2.shape[1]
     gw = torch.empty(P, Q, dtype=torch.float32, device=g2.device)
-    nbytes = _lib.lib().xq_gemm_bf16_tn_workspace_bytes(R, P, Q)
-    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=g2.device)
+    ws, nbytes = _gemm_ws(2, P, Q, R, g2.device)
     with torch.cuda.device(g2.device):
         rc = _lib.lib().xq_gemm_bf16_tn(ptr(g2), ptr(x2), R, P, Q, ptr(gw), ptr(ws), nbytes, GEMM_SCHEDULE, _stream(g2))
     check(rc, "xq_gemm_bf16_tn")

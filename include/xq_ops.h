@@ -273,19 +273,27 @@ int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K, int act_bf
  *      dino_enc/to_pixel.py:70-86).  bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16.
  *      All matrices row-major and contiguous.  impl selects the schedule (tests / benchmarks); use XQ_GEMM_AUTO. ---------- */
 #define XQ_GEMM_AUTO 0
-#define XQ_GEMM_SIMPLE 1 /* two LDS buffers, one barrier per K tile (any shape the op accepts)                      */
-#define XQ_GEMM_RING 2   /* 8-slot LDS-DMA ring, counted vmcnt, staggered wave rows (256-column tiles, K >= 128)   */
-#define XQ_PROF_GEMM 4   /* gemm_*_kernel: 2*M*N*K flops per launch (xq_prof_collect_kind)                          */
+#define XQ_GEMM_SIMPLE 1     /* two LDS buffers, one barrier per K tile (any shape the op accepts)                           */
+#define XQ_GEMM_RING 2       /* 8-slot LDS-DMA ring, counted vmcnt, staggered wave rows; one workgroup per tile              */
+#define XQ_GEMM_PERSISTENT 3 /* the ring kept streaming across a per-CU list of work items; tail tiles / weight gradients
+                                cut along K into fp32 slabs (256-column tiles, >= 2 K tiles per item)                       */
+#define XQ_GEMM_OP_NT 0
+#define XQ_GEMM_OP_NN 1
+#define XQ_GEMM_OP_TN 2
+#define XQ_PROF_GEMM 4       /* gemm_*_kernel: 2*M*N*K flops per launch (xq_prof_collect_kind)                               */
+/* bytes of workspace for op (XQ_GEMM_OP_*) at output rows M, columns N, reduction depth K (TN: M = P, N = Q, K = R);
+ * NT / NN run without one (workspace NULL: no K-split of the tail tiles). */
+size_t xq_gemm_bf16_workspace_bytes(int op, int64_t M, int64_t N, int64_t K);
 /* forward: y[M][N] = x[M][K] . w[N][K]^T (+ bias[N], fp32, nullable).  K % 64 == 0, N % 8 == 0, N >= 32. */
-int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y, int impl,
-                    xq_stream_t stream);
+int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y, void *workspace,
+                    size_t workspace_bytes, int impl, xq_stream_t stream);
 /* data gradient: g_x[M][N] = g_y[M][K] . w[K][N]  (w = the forward's weight [out = K][in = N], read in place with
  * transpose reads: no transposed copy of the weights exists).  K % 64 == 0, N % 8 == 0, N >= 32. */
-int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_t K, void *g_x, int impl, xq_stream_t stream);
+int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_t K, void *g_x, void *workspace,
+                    size_t workspace_bytes, int impl, xq_stream_t stream);
 /* weight gradient: g_w[P][Q] (fp32) = g_y[R][P]^T . x[R][Q], the token axis R split over the chip into fp32 slabs in
- * `workspace` (xq_gemm_bf16_tn_workspace_bytes) that a second kernel sums in a fixed order (deterministic, no atomics).
+ * `workspace` that a second kernel sums in a fixed order (deterministic, no atomics).
  * P, Q multiples of 8 and >= 32; any R >= 0. */
-size_t xq_gemm_bf16_tn_workspace_bytes(int64_t R, int64_t P, int64_t Q);
 int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_t Q, float *g_w, void *workspace,
                     size_t workspace_bytes, int impl, xq_stream_t stream);
 

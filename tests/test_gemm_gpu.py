@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SIMPLE, RING = 1, 2
+SIMPLE, RING, PERSISTENT = 1, 2, 3
 
 
 def _ops():
@@ -32,14 +32,17 @@ def _rand(shape, seed, scale=1.0):
 
 # (M, N, K): ragged M, BN = 128 tiles (N = 384 / 1152), N below one tile, the ViT-B layer shapes at a small batch
 NT_SHAPES = [(256, 256, 128), (300, 256, 128), (1, 256, 64), (513, 768, 768), (2052, 2304, 768), (2052, 768, 3072),
-             (2056, 3072, 768), (788, 384, 384), (788, 1152, 384), (788, 384, 1536), (1024, 32, 768), (640, 200, 192)]
+             (2056, 3072, 768), (788, 384, 384), (788, 1152, 384), (788, 384, 1536), (1024, 32, 768), (640, 200, 192),
+             # more tiles than CUs: 261 = 256 + 5 -> the persistent schedule cuts the last 5 tiles along K (fp32 slabs);
+             # 2 x 256 + 90 tiles: a third, partial round of whole tiles
+             (22300, 768, 768), (22272, 768, 256), (51400, 768, 128)]
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_gemm_nt(M, N, K, impl):
     od = _ops()
-    if impl == RING and (N % 256 or K < 128):
+    if impl != SIMPLE and (N % 256 or K < 128):
         pytest.skip("ring schedule: 256-column tiles, K >= 128")
     x, w = _rand((M, K), 1), _rand((N, K), 2, 0.05)
     bias = torch.randn(N, device="cuda")
@@ -55,12 +58,12 @@ def test_gemm_nt(M, N, K, impl):
     _check_bf16(y, ref + bias, absprod + bias.abs())
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_gemm_nn(M, N, K, impl):
     """g_x[M][N] = g[M][K] @ W[K][N] (W = forward weight [out = K][in = N])"""
     od = _ops()
-    if impl == RING and (N % 256 or K < 128):
+    if impl != SIMPLE and (N % 256 or K < 128):
         pytest.skip("ring schedule: 256-column tiles, K >= 128")
     g, w = _rand((M, K), 3), _rand((K, N), 4, 0.05)
     od.GEMM_SCHEDULE = impl
@@ -76,11 +79,11 @@ TN_SHAPES = [(256, 256, 256), (2052, 2304, 768), (2052, 768, 768), (2056, 768, 3
              (788, 384, 1536), (788, 1152, 384), (4104, 768, 768), (640, 200, 192), (0, 64, 64)]
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
 @pytest.mark.parametrize("R,P,Q", TN_SHAPES)
 def test_gemm_tn(R, P, Q, impl):
     od = _ops()
-    if impl == RING and Q % 256:
+    if impl != SIMPLE and Q % 256:
         pytest.skip("ring schedule: 256-column tiles")
     g, x = _rand((R, P), 5), _rand((R, Q), 6)
     od.GEMM_SCHEDULE = impl
@@ -100,7 +103,7 @@ def test_gemm_ring_equals_simple_and_is_repeatable(op):
     """The ring schedule (counted vmcnt, staggered wave rows) must give bit-identical results to the barrier-per-tile
     schedule (same MFMA order per accumulator) and to itself over repeated launches on a busy chip (race screen)."""
     od = _ops()
-    M, N, K = 16416, 768, 768           # 64.1 row tiles: ragged last tile, 195 workgroups
+    M, N, K = 22300, 768, 768           # 87.1 row tiles (ragged last one) x 3: 264 tiles on 256 CUs
     if op == "tn":
         a, b = _rand((M, N), 7), _rand((M, 2304), 8)
         run = lambda: od.gemm_tn(a, b)
@@ -116,11 +119,19 @@ def test_gemm_ring_equals_simple_and_is_repeatable(op):
         base = run()
         od.GEMM_SCHEDULE = RING
         outs = [run() for _ in range(12)]
+        od.GEMM_SCHEDULE = PERSISTENT
+        outs_p = [run() for _ in range(12)]
     finally:
         od.GEMM_SCHEDULE = 0
     torch.cuda.synchronize()
     for o in outs:
         assert torch.equal(o, base)
+    # the persistent schedule may cut tail tiles (and cuts the weight gradient differently) along K: same values up to the
+    # fp32 summation order, and bit-identical from launch to launch
+    for o in outs_p:
+        assert torch.equal(o, outs_p[0])
+    scale = base.float().abs().max().item()
+    assert (outs_p[0].float() - base.float()).abs().max().item() <= 2.0 ** -7 * scale
 
 
 def test_linear_fn_matches_library_autograd():

@@ -51,7 +51,7 @@ def main():
                     ("gx   library mm", lambda: torch.mm(g, w)),
                     ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
                 ]
-                for sched, tag in ((1, "simple"), (2, "ring")):
+                for sched, tag in ((2, "ring"), (3, "persistent")):
                     def mk(f, sched=sched):
                         def run():
                             od.GEMM_SCHEDULE = sched
