@@ -20,8 +20,14 @@ libxq_ops.so (xq_prof_*): conv3x3_kernel (LPIPS-VGG16 convs: 2*B*H*W*9*Cin*Cout 
 (4*B*H*N^2*64 forward, 10*B*H*N^2*64 backward, bf16 MFMA peak 2500 TFLOP/s) and the quantizer's assign_kernel (fused
 normalise + distance + argmin, 2*N*V*C flops, SURVEY.md §8d, fp32 MFMA peak 157.3 TFLOP/s).  "roofline" is the one with
 the most GPU time in the timed region, "roofline_other_kernels" lists the rest (peaks: MI355X_MICROARCH.md).
-cpu_baseline: the same quantizer stage with the reference's expressions on ATen CPU ops (oracle/torch_restatement.py,
-kind="port": /root/reference does not exist on the GPU box), bounded sample, rank 0, N = 1 only.
+mfu: flops of ONE train step per image, counted by torch.utils.flop_counter.FlopCounterMode over this same step run on the
+library ops (fp32, B = 2: the hand-written kernels are invisible to the counter, the library formulation of the same
+algorithm is not) + the quantizer's 2*N*V*C, times images/sec, over the dense bf16 MFMA peak.
+cpu_baseline: the SAME workload (complete train step of this config: generator fwd + VQLoss + bwd + discriminator step +
+AdamW/EMA) on the host cores, fp32 (the reference's CPU path: torch.cuda.amp.autocast is a no-op there), on a bounded
+sample of B = 2 images, through the host mirrors that are bit-identical to the reference classes on CPU (kind="port":
+/root/reference does not exist on the GPU box); plus the quantizer stage alone, GPU vs CPU, on the same 16-image sample.
+Rank 0, N = 1 only.
 """
 import argparse
 import ctypes
@@ -64,33 +70,99 @@ def parse():
                    help="full = VQLoss (rec + LPIPS + DinoDisc GAN, adaptive weight, LeCAM) + discriminator step; "
                         "recon = rec + codebook + semantic only")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-mfu", action="store_true", help="skip the FlopCounterMode pass (mfu = null)")
+    p.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the links")
     return p.parse_args()
 
 
-def cpu_baseline(B_sample=16, iters=3):
-    """Reference CPU path of the quantizer stage (ATen fp32, all host cores) on a bounded sample of the workload."""
-    from oracle import torch_restatement as tr
+def quantizer_stage(dev, B_sample=16, iters=3):
+    """VectorQuantizer fwd+bwd on B_sample images: ms on `dev` (the HIP op on cuda, the ATen restatement of
+    xqgan_model.py:745-801 on cpu)"""
     torch.manual_seed(0)
     V, C = CFG["V"], CFG["C"]
+    if dev.type == "cuda":
+        from imagefolder_amd.xqgan_model import VectorQuantizer
+        q = VectorQuantizer(V, C, CFG["beta"], True).to(dev).train()
+        z = torch.randn(B_sample, C, 16, 16, device=dev, requires_grad=True)
+
+        def step():
+            zq, usage, vq, commit, _ = q(z)
+            (zq.square().mean() + vq + commit).backward()
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / iters * 1e3
+    from oracle import torch_restatement as tr
     E = torch.nn.functional.normalize(torch.empty(V, C).uniform_(-1.0 / V, 1.0 / V), dim=-1).requires_grad_(True)
     z = torch.randn(B_sample, C, 16, 16, requires_grad=True)
 
     def step():
         zq, idx, vq, commit, hist = tr.vq_forward(z, E, CFG["beta"], True)
         (zq.square().mean() + vq + commit).backward()
-
     step()
     t0 = time.perf_counter()
     for _ in range(iters):
         step()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def cpu_baseline(args, dev, B_sample=2, budget_s=25.0):
+    """The complete train step of this config on the host cores (fp32), bounded sample; + the quantizer stage GPU vs CPU."""
+    cpu = torch.device("cpu")
+    a2 = argparse.Namespace(**vars(args))
+    a2.batch = B_sample
+    torch.manual_seed(0)
+    model, ts = build_train_step(a2, cpu, 1, amp_dtype=None)
+    imgs = torch.rand(B_sample, 3, 256, 256, generator=torch.Generator().manual_seed(1234)) * 2 - 1
+    t0 = time.perf_counter()
+    ts.step(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"])      # warm-up (allocations, oneDNN primitives)
+    warm = time.perf_counter() - t0
+    iters = 2 if warm < budget_s / 3 else 1
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        ts.step(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"])
     dt = (time.perf_counter() - t0) / iters
+    q_gpu, q_cpu = quantizer_stage(dev), quantizer_stage(cpu)
     return dict(value=B_sample / dt, unit="images/sec", cores=torch.get_num_threads(), kind="port",
-                sample=f"quantizer stage only (VectorQuantizer fwd+bwd, the part of the step the CPU restatement covers): "
-                       f"{iters} iters on B={B_sample} images ({B_sample * 256} tokens x V={V} x C={C}), ATen CPU fp32 "
-                       f"restatement of xqgan_model.py:745-801")
+                sample=f"complete train step of {CFG['name']} (same model, VQLoss, discriminator step, AdamW + EMA as the timed GPU "
+                       f"step) in fp32 on the host: {iters} timed step(s) of B={B_sample} images after one warm-up step "
+                       f"({dt:.2f} s/step); host mirrors = the reference classes on CPU (bit-identical, tests/)",
+                quantizer_stage={"sample": f"VectorQuantizer fwd+bwd, B=16 images ({16 * 256} tokens x V={CFG['V']} x C={CFG['C']})",
+                                 "quantizer_stage_gpu_ms": q_gpu, "quantizer_stage_cpu_ms": q_cpu})
 
 
-def build_train_step(args, dev, world):
+def count_flops_per_image(args, dev, B_count=2):
+    """FlopCounterMode over one complete train step on the library formulation (fp32, per-op blocks) / B_count."""
+    from torch.utils.flop_counter import FlopCounterMode
+    from imagefolder_amd import nn_ops, ops_dense
+    a2 = argparse.Namespace(**vars(args))
+    a2.batch = B_count
+    saved = (nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL)
+    nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL = False, "library"
+    impl_saved = dict(nn_ops.IMPL)
+    try:
+        torch.manual_seed(0)
+        model, ts = build_train_step(a2, dev, 1, amp_dtype=None)
+        imgs = torch.rand(B_count, 3, 256, 256, device=dev) * 2 - 1
+        with FlopCounterMode(display=False) as fc:
+            ts.step(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"])
+        torch.cuda.synchronize()
+        total = float(fc.get_total_flops())
+    finally:
+        nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL = saved
+        nn_ops.IMPL.clear()
+        nn_ops.IMPL.update(impl_saved)
+    tokens = CFG["P"] * (sum(p * p for p in CFG["pns"]) if len(CFG["pns"]) > 1 else CFG["L"])
+    quant = 2.0 * tokens * CFG["V"] * CFG["C"]          # the assign kernel (custom op: invisible to the counter)
+    del model, ts
+    torch.cuda.empty_cache()
+    return total / B_count + quant
+
+
+def build_train_step(args, dev, world, amp_dtype=torch.bfloat16, disc_group=None, always_reduce=False, comm_dtype=None):
     from imagefolder_amd.xqgan_model import VQ_models
     from imagefolder_amd.train import TokenizerTrainStep, DiscriminatorStep
     from imagefolder_amd.vq_loss import VQLoss
@@ -110,7 +182,8 @@ def build_train_step(args, dev, world):
                          image_size=256, perceptual_weight=1.0, reconstruction_weight=1.0, reconstruction_loss="l2",
                          codebook_weight=1.0, lecam_loss_weight=0.001, disc_adaptive_weight=True, norm_type="bn",
                          aug_prob=1.0).to(dev).train()
-        disc = DiscriminatorStep(vq_loss, lr=disc_lr, betas=(0.9, 0.95), weight_decay=0.0005, amp_dtype=torch.bfloat16)
+        disc = DiscriminatorStep(vq_loss, lr=disc_lr, betas=(0.9, 0.95), weight_decay=0.0005, amp_dtype=amp_dtype,
+                                 group=disc_group, always_reduce=always_reduce)
         state = {"step": 0}
 
         def gen_loss(out, imgs):
@@ -125,7 +198,7 @@ def build_train_step(args, dev, world):
             return torch.nn.functional.mse_loss(imgs, recons.float()) + vq + commit + entropy + (sem if sem is not None else 0.0)
         disc_fn = None
     ts = TokenizerTrainStep(model, gen_loss, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999, use_ema=True,
-                            amp_dtype=torch.bfloat16, disc_step_fn=disc_fn)
+                            amp_dtype=amp_dtype, disc_step_fn=disc_fn, always_reduce=always_reduce, comm_dtype=comm_dtype)
     return model, ts
 
 
@@ -140,9 +213,18 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # XQ_FORCE_DIST=1: initialise RCCL and run every collective of the step at world size 1 too (tests/test_bench_nccl_gpu.py:
+    # the 8-GPU runs are the driver's, this keeps the "nccl" branch exercised on the 1-GPU box)
+    force_dist = os.environ.get("XQ_FORCE_DIST", "0") == "1"
+    use_dist = world > 1 or force_dist
+    disc_group = None
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # RCCL
+        disc_group = dist.new_group()                    # own communicator + stream for the discriminator heads
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.backends.cuda.matmul.allow_tf32 = True  # xqgan_train.py:6-7 (no-op on gfx950: no TF32 path)
 
@@ -152,7 +234,8 @@ def main():
     g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank synthetic data (xqgan_train.py:189)
 
     if args.workload == "train_step":
-        model, ts = build_train_step(args, dev, world)
+        model, ts = build_train_step(args, dev, world, disc_group=disc_group, always_reduce=force_dist,
+                                     comm_dtype=torch.bfloat16 if args.grad_comm == "bf16" else None)
         imgs = torch.rand(B, 3, 256, 256, device=dev, generator=g) * 2 - 1
 
         def step():
@@ -175,23 +258,27 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     lib.xq_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        if use_dist and args.workload == "train_step":
+            ts.reducer.collect_exposed_ms()   # (elapsed_time of the previous step's events: no extra synchronisation)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    exposed = ts.reducer.collect_exposed_ms() if args.workload == "train_step" else []
     ms_tot, n_launch = ctypes.c_double(0.0), ctypes.c_int(0)
     kinds = {}
     for kind, name in ((1, "conv3x3_kernel (v_mfma_f32_32x32x16_bf16 implicit GEMM, LPIPS-VGG / CNN convs)"),
                        (2, "attn_fwd_kernel (v_mfma_f32_32x32x16_bf16)"),
-                       (3, "attn_delta + attn_bwd_dkdv + attn_bwd_dq kernels (v_mfma_f32_32x32x16_bf16)")):
+                       (3, "attn_delta + attn_bwd_dkdv + attn_bwd_dq kernels (v_mfma_f32_32x32x16_bf16)"),
+                       (4, "gemm_pring / gemm_ring / gemm_simple kernels (v_mfma_f32_32x32x16_bf16; nn.Linear fwd NT, dgrad NN, wgrad TN)")):
         k_ms, k_n, k_work = ctypes.c_double(0.0), ctypes.c_int(0), ctypes.c_double(0.0)
         lib.xq_prof_collect_kind(kind, ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_work))
         if k_n.value:
@@ -200,7 +287,7 @@ def main():
     lib.xq_prof_enable(0)
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
 
@@ -255,25 +342,53 @@ def main():
         # passes, gfx950 read correction applied: tools/pmc_traffic.py); null when that profile does not cover the kernel
         traffic = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_kernel_hbm_traffic.json")) as fh:
+            tf = os.path.join(ROOT, "profiles", "r02_kernel_hbm_traffic.json")
+            if not os.path.exists(tf):
+                tf = os.path.join(ROOT, "profiles", "r01_kernel_hbm_traffic.json")
+            with open(tf) as fh:
                 traffic = json.load(fh).get("kernels", {})
+            traffic_src = os.path.relpath(tf, ROOT)
         except (OSError, ValueError):
             pass
         if full and CFG["name"] == "VQ-8192" and B == 128:   # the profile was taken on this workload
             for e in entries:
                 keys = (["conv3x3"] if e["kernel"].startswith("conv3x3") else ["attn_fwd"] if e["kernel"].startswith("attn_fwd")
-                        else ["attn_bwd_dkdv", "attn_bwd_dq"] if e["kernel"].startswith("attn_delta") else ["assign"])
+                        else ["attn_bwd_dkdv", "attn_bwd_dq"] if e["kernel"].startswith("attn_delta")
+                        else ["gemm"] if e["kernel"].startswith("gemm") else ["assign"])
                 if all(k in traffic for k in keys):
                     e["traffic"] = sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)
-                    e["traffic_source"] = "profiles/r01_kernel_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, bytes per launch)"
+                    e["traffic_source"] = traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, average bytes per launch; per-shape rows in the file)"
         entries.sort(key=lambda e: -e["ms_per_step"])
-        out["roofline"] = dict(entries[0], note="hand-written kernel with the most GPU time in the timed region "
-                                                "(HIP events on its launch stream); algorithmic flops / measured time")
+        out["roofline"] = dict(entries[0], note="kernel family with the most GPU time in the timed region (every MFMA kernel of "
+                                                "the step is hand-written and instrumented: HIP events on its launch stream); "
+                                                "algorithmic flops / measured time")
         out["roofline_other_kernels"] = entries[1:]
+        if full:
+            out["allreduce"] = {"backend": "rccl" if use_dist else "none (single process)", "world": world,
+                                "bytes_per_step": int(ts.arena.numel * (2 if args.grad_comm == "bf16" else 4)),
+                                "comm_dtype": args.grad_comm, "chunks": len(ts.reducer.chunks),
+                                "launch": "per-chunk from backward hooks, generator and discriminator on separate communicators",
+                                "exposed_ms_per_step": (sum(exposed) / len(exposed)) if exposed else None}
+            flops_img = None
+            if not args.no_mfu:
+                try:
+                    flops_img = count_flops_per_image(args, dev)
+                except Exception as e:  # noqa: BLE001 - the bench line must still print
+                    out["mfu_error"] = f"{type(e).__name__}: {e}"
+            out["mfu"] = None if flops_img is None else {
+                "flops_per_image": flops_img, "source": "FlopCounterMode over one complete step on the library formulation (fp32, B=2) + 2*N*V*C of the code search",
+                "achieved_tflops": flops_img * out["value"] / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS * world,
+                "frac": flops_img * out["value"] / 1e12 / (PEAK_BF16_MFMA_TFLOPS * world)}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            if full:
+                out["cpu_baseline"] = cpu_baseline(args, dev)
+            else:
+                q_gpu, q_cpu = quantizer_stage(dev), quantizer_stage(torch.device("cpu"))
+                out["cpu_baseline"] = dict(value=16 / (q_cpu * 1e-3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                                           sample="VectorQuantizer fwd+bwd on B=16 images, ATen CPU fp32 restatement of xqgan_model.py:745-801",
+                                           quantizer_stage={"quantizer_stage_gpu_ms": q_gpu, "quantizer_stage_cpu_ms": q_cpu})
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

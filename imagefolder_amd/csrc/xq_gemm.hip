@@ -730,7 +730,12 @@ int set_lds(int bytes) {
     return 0;
 }
 
-int pick_bn(long N) { return N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : (N >= 1024 ? 256 : 128)); }
+// 256-column tiles (ring / persistent schedules) unless the ragged last tile would waste more than the simple schedule costs;
+// impl bit 8 (XQ_GEMM_WIDE_TILES) forces them (tests, tuning)
+int pick_bn(long N, int impl = 0) {
+    if (impl & XQ_GEMM_WIDE_TILES) return 256;
+    return N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : (N >= 1024 ? 256 : 128));
+}
 
 // splits of the reduction for the weight gradient: fill the chip once, at least two K tiles per split
 int tn_splits(long kt_all, long tiles) {
@@ -828,16 +833,17 @@ int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" size_t xq_gemm_bf16_workspace_bytes(int op, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K < 0) return 0;
-    const int BN = pick_bn(N);
-    const long tiles = ((M + 255) / 256) * ((N + BN - 1) / BN);
+    // enough for either tile width (the XQ_GEMM_WIDE_TILES bit may force 256-column tiles)
+    const long tiles256 = ((M + 255) / 256) * ((N + 255) / 256);
+    const long tilesbn = ((M + 255) / 256) * ((N + pick_bn(N) - 1) / pick_bn(N));
     const int kt = (int)(K / 64);
     if (op == XQ_GEMM_OP_TN) {
         if (kt < 2) return 0;
-        const size_t compact = (BN == 256) ? plan_persistent(tiles, kt, true).slab_bytes : 0;
-        const size_t flat = (size_t)tn_splits(kt, tiles) * M * N * sizeof(float);
+        const size_t compact = plan_persistent(tiles256, kt, true).slab_bytes;
+        const size_t flat = (size_t)tn_splits(kt, tilesbn) * M * N * sizeof(float);
         return compact > flat ? compact : flat;
     }
-    return BN == 256 ? plan_persistent(tiles, kt, false).slab_bytes : 0;
+    return plan_persistent(tiles256, kt, false).slab_bytes;
 }
 
 extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y,
@@ -846,7 +852,8 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
     if (!x || !w || !y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    const int BN = pick_bn(N);
+    const int BN = pick_bn(N, impl);
+    impl &= 0xff;
     GemmArgs g{};
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -861,7 +868,8 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
     if (!g_y || !w || !g_x) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    const int BN = pick_bn(N);
+    const int BN = pick_bn(N, impl);
+    impl &= 0xff;
     GemmArgs g{};
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -878,7 +886,8 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     if (!g_w || (R > 0 && (!g_y || !x))) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     if (P % 8 || Q % 8 || P < 32 || Q < 32) return xq_set_error(XQ_EINVAL, "%s: needs P, Q multiples of 8 and >= 32 (P=%ld Q=%ld)", fn, (long)P, (long)Q);
     hipStream_t s = (hipStream_t)stream;
-    const int BN = pick_bn(Q);
+    const int BN = pick_bn(Q, impl);
+    impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
     g.A = (const char *)g_y; g.B = (const char *)x; g.C = (char *)ws;

@@ -85,6 +85,14 @@ extern "C" int xq_prof_collect(double *assign_ms_total, int *assign_launches) {
     g_prof_n = 0;
     return rc;
 }
+// correction of the algorithmic work of the most recent launch of `kind` (e.g. the conv1_1 data gradient runs with its 3 input
+// channels zero-padded to 64: the padded flops are not algorithmic work)
+extern "C" int xq_prof_add_work(int kind, double delta) {
+    if (!g_prof_on) return XQ_OK;
+    for (int i = g_prof_n - 1; i >= 0; --i)
+        if (g_prof_kind[i] == kind) { g_prof_work[i] += delta; break; }
+    return XQ_OK;
+}
 int xq::prof_begin(int kind, double work, hipStream_t s) {
     if (!g_prof_on || g_prof_n >= PROF_MAX) return -1;
     if (g_prof_n >= g_prof_created) {

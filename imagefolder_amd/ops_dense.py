@@ -568,6 +568,9 @@ class Conv3x3SmallCinFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wp = _packed_conv_weight(weight, True)
             g_x = _conv3x3_call(g, wp, None, wp.shape[0], False)[:, :Cin].to(ctx.in_dtype)
+            # the kernel ran with the Cin input channels zero-padded to wp.shape[0]: only the un-padded flops are algorithmic
+            Bn, _, Hh, Ww = g.shape
+            _lib.lib().xq_prof_add_work(1, -2.0 * Bn * Hh * Ww * 9.0 * weight.shape[0] * (wp.shape[0] - Cin))
         if ctx.needs_input_grad[1]:
             g_w = conv3x3_weight_grad(x_cl, g, weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:

@@ -277,6 +277,7 @@ int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K, int act_bf
 #define XQ_GEMM_RING 2       /* 8-slot LDS-DMA ring, counted vmcnt, staggered wave rows; one workgroup per tile              */
 #define XQ_GEMM_PERSISTENT 3 /* the ring kept streaming across a per-CU list of work items; tail tiles / weight gradients
                                 cut along K into fp32 slabs (256-column tiles, >= 2 K tiles per item)                       */
+#define XQ_GEMM_WIDE_TILES 0x100 /* OR-ed into impl: 256-column tiles even when N is not a multiple of 256 (ragged last tile) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2
@@ -308,6 +309,9 @@ int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_
 int xq_prof_enable(int on);
 int xq_prof_collect_kind(int kind, double *ms_total, int *launches, double *work_total);
 int xq_prof_collect(double *assign_ms_total, int *assign_launches);
+/* adds `delta` (may be negative) to the algorithmic work recorded for the most recent launch of `kind`: for launches that run
+ * zero-padded operands (conv1_1 data gradient: 3 input channels padded to 64), so that only un-padded flops are reported */
+int xq_prof_add_work(int kind, double delta);
 /* launches an empty kernel (xq_marker_kernel) with `id` workgroups of 64 threads: a section boundary that shows up in a
  * rocprofv3 kernel trace (tools/rocpd_sections.py attributes the kernels between two markers to a section) */
 int xq_prof_marker(int id, xq_stream_t stream);

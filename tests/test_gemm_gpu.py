@@ -156,3 +156,25 @@ def test_linear_fn_matches_library_autograd():
     for a, r, tol in zip(res["hip"], res["library"], (2e-2, 2e-2, 2e-3, 1e-3)):
         scale = r.abs().max().item()
         assert (a - r).abs().max().item() <= tol * scale, f"{(a - r).abs().max().item()} vs scale {scale}"
+
+
+@pytest.mark.parametrize("impl", [RING | 0x100, PERSISTENT | 0x100])
+@pytest.mark.parametrize("M,N,K", [(788, 384, 384), (788, 1152, 384), (640, 200, 192), (25216, 384, 1536)])
+def test_gemm_wide_tiles_on_ragged_columns(M, N, K, impl):
+    """XQ_GEMM_WIDE_TILES: the ring schedules on column counts that are not a multiple of 256 (clamped loads, guarded stores)"""
+    od = _ops()
+    x, w = _rand((M, K), 11), _rand((N, K), 12, 0.05)
+    g, wt = _rand((M, K), 13), _rand((K, N), 14, 0.05)
+    bias = torch.randn(N, device="cuda")
+    od.GEMM_SCHEDULE = impl
+    try:
+        y = od.gemm_nt(x, w, bias)
+        gx = od.gemm_nn(g, wt)
+        gw = od.gemm_tn(_rand((M, 256), 15), _rand((M, N), 16))
+    finally:
+        od.GEMM_SCHEDULE = 0
+    _check_bf16(y, x.float() @ w.float().t() + bias, x.float().abs() @ w.float().abs().t() + bias.abs())
+    _check_bf16(gx, g.float() @ wt.float(), g.float().abs() @ wt.float().abs())
+    a, b = _rand((M, 256), 15), _rand((M, N), 16)
+    ref = a.float().t() @ b.float()
+    assert ((gw - ref).abs() <= a.float().abs().t() @ b.float().abs() * 4e-6 + 1e-30).all()

@@ -1,0 +1,75 @@
+"""Arena-owned parameters on the GPU: the caches derived from them (packed conv weights, bf16 shadow) must follow updates that
+reach the masters through raw pointers (optimizer kernel) or through torch in-place ops (load_state_dict) — ADVICE r1."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_packed_conv_weights_follow_the_optimizer():
+    from imagefolder_amd import nn_ops
+    from imagefolder_amd.train import ArenaOptimizer
+    torch.manual_seed(0)
+    conv = torch.nn.Conv2d(64, 64, 3, padding=1).cuda()
+    opt = ArenaOptimizer(conv.parameters(), lr=0.05, weight_decay=0.0, use_ema=False)
+    x = torch.randn(2, 64, 16, 16, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+    def fwd():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return nn_ops.conv2d(x, conv.weight, conv.bias, stride=1, padding=1)
+    y0 = fwd()
+    assert nn_ops.IMPL["conv2d"].startswith("hip")
+    for _ in range(2):                                   # two train steps: the weights move through the optimizer kernel
+        opt.arena.rebind_grads()
+        fwd().float().square().mean().backward()
+        opt.step()
+    y1 = fwd()
+    ref = F.conv2d(x.float(), conv.weight.detach().to(torch.bfloat16).float(), conv.bias.detach().float(), padding=1)
+    scale = ref.abs().max().item()
+    assert (y1.float() - ref).abs().max().item() <= 2e-2 * scale, "conv3x3 forward used stale packed weights"
+    assert (y1.float() - y0.float()).abs().max().item() > 1e-2 * scale, "the step did not move the weights: test is vacuous"
+    # data gradient pack as well
+    xg = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        nn_ops.conv2d(xg, conv.weight, conv.bias, stride=1, padding=1).float().sum().backward()
+    xr = x.float().clone().requires_grad_(True)
+    F.conv2d(xr, conv.weight.detach().to(torch.bfloat16).float(), None, padding=1).sum().backward()
+    assert (xg.grad.float() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item()
+
+
+def test_bf16_shadow_follows_load_state_dict():
+    from imagefolder_amd import ops_dense
+    from imagefolder_amd.train import ArenaOptimizer
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(128, 256).cuda()
+    opt = ArenaOptimizer(lin.parameters(), use_ema=True)
+    new = {"weight": torch.randn(256, 128, device="cuda"), "bias": torch.randn(256, device="cuda")}
+    lin.load_state_dict(new)                             # torch in-place copy into the arena views
+    x = torch.randn(64, 128, device="cuda").to(torch.bfloat16)
+    y = ops_dense.LinearFn.apply(x, lin.weight, lin.bias, False)
+    ref = x.float() @ new["weight"].to(torch.bfloat16).float().t() + new["bias"]
+    assert (y.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item(), "bf16 shadow is stale after load_state_dict"
+    opt.arena.resync(ema=True)                            # the reference's update_ema(decay=0) after loading
+    assert torch.equal(opt.arena.ema, opt.arena.p)
+
+
+def test_bench_runs_its_rccl_branch_at_world_size_1():
+    """XQ_FORCE_DIST=1: bench.py initialises the nccl (RCCL) process groups and runs the chunked gradient all-reduce from the
+    backward hooks, the discriminator's all-reduce on its own communicator and the timing all-reduce — on one GPU."""
+    env = dict(os.environ, XQ_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--no-mfu"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["allreduce"]["backend"] == "rccl"
+    assert res["allreduce"]["exposed_ms_per_step"] is not None
+    assert res["allreduce"]["chunks"] >= 2
+    assert res["value"] > 0

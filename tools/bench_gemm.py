@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--out", default=None)
     ap.add_argument("--rows", type=int, nargs="*", default=[65664, 65792])
     ap.add_argument("--dims", type=int, nargs="*", default=[768])
+    ap.add_argument("--scheds", type=str, nargs="*", default=["3"], help="impl values: 1 simple, 2 ring, 3 persistent, 0x103 = persistent with forced 256-column tiles")
     a = ap.parse_args()
     lines = []
 
@@ -51,7 +52,7 @@ def main():
                     ("gx   library mm", lambda: torch.mm(g, w)),
                     ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
                 ]
-                for sched, tag in ((2, "ring"), (3, "persistent")):
+                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 0x103: "persistent wide", 0x102: "ring wide"}.get(int(x, 0), x)) for x in a.scheds]:
                     def mk(f, sched=sched):
                         def run():
                             od.GEMM_SCHEDULE = sched
