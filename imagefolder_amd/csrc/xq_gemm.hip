@@ -730,11 +730,12 @@ int set_lds(int bytes) {
     return 0;
 }
 
-// 256-column tiles (ring / persistent schedules) unless the ragged last tile would waste more than the simple schedule costs;
+// 256-column tiles (ring / persistent schedules) from N = 256 on;
 // impl bit 8 (XQ_GEMM_WIDE_TILES) forces them (tests, tuning)
 int pick_bn(long N, int impl = 0) {
     if (impl & XQ_GEMM_WIDE_TILES) return 256;
-    return N % 256 == 0 ? 256 : (N % 128 == 0 ? 128 : (N >= 1024 ? 256 : 128));
+    return N >= 256 ? 256 : 128;     // measured (profiles/r02_gemm_shapes_d384.txt): a ragged last 256-column tile on the
+                                     // persistent ring beats 128-column tiles on the simple schedule at N = 384 / 1152
 }
 
 // splits of the reduction for the weight gradient: fill the chip once, at least two K tiles per split

@@ -145,11 +145,13 @@ __global__ __launch_bounds__(256) void phi_update_kernel(const float *__restrict
         const float m = (n_quant == nullptr || (float)si < n_quant[b]) ? 1.0f : 0.0f;
         const float fh = f_hat[o] + h * m;
         f_hat[o] = fh;
-        f_rest[o] = f_rest[o] - h;
+        if (f_rest) f_rest[o] = f_rest[o] - h;
         if (h_out) h_out[o] = h;
         if (fhat_scale_out) fhat_scale_out[o] = fh;
-        const float df = fh - f[o];
-        contrib = m * df * df;
+        if (f) {
+            const float df = fh - f[o];
+            contrib = m * df * df;
+        }
     }
     if (sq_acc) {
         __shared__ float red[4];
@@ -510,4 +512,90 @@ extern "C" int xq_msvq_backward(const float *f, int B, int C, int H, int W, int 
         ioff += (size_t)B * pn * pn;
     }
     return XQ_OK;
+}
+
+
+// ================================================================================================
+// VAR-side helpers of VectorQuantizer2 (quant.py:148-180 embed_to_fhat, :226-258 idxBl_to_var_input /
+// get_next_autoregressive_input; models/quant.py:107-215): the three primitives of the ladder as stand-alone ops —
+// the same kernels (and fma orders) the fused ladder runs, so the results equal oracle/xq_oracle.c bit for bit.
+// ================================================================================================
+__global__ __launch_bounds__(256) void up_tensor_kernel(const float *__restrict__ h, long BC, int pn, int H, int W, Taps ty, Taps tx,
+                                                        float *__restrict__ u) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    if (o >= BC * H * W) return;
+    const int x = (int)(o % W);
+    const int y = (int)((o / W) % H);
+    const float *src = h + (o / ((long)W * H)) * pn * pn;
+    float acc = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        int yy = ty.i0[y] + a;
+        yy = yy < 0 ? 0 : (yy > pn - 1 ? pn - 1 : yy);
+        float r = 0.0f;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            int xx = tx.i0[x] + bb;
+            xx = xx < 0 ? 0 : (xx > pn - 1 ? pn - 1 : xx);
+            r = __builtin_fmaf(tx.w[x][bb], src[yy * pn + xx], r);
+        }
+        acc = __builtin_fmaf(ty.w[y][a], r, acc);
+    }
+    u[o] = acc;
+}
+
+static int ms_check_grid(const char *fn, int B, int C, int H, int W) {
+    if (B < 0 || C < 1 || H < 1 || W < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (H > MS_MAX_HW || W > MS_MAX_HW) return xq_set_error(XQ_EINVAL, "%s: grid %ldx%ld exceeds 16x16", fn, H, W);
+    return XQ_OK;
+}
+
+extern "C" int xq_ms_upsample(const float *h, const float *E, const int64_t *idx, int B, int C, int pn, int H, int W, int bicubic,
+                              float *u, xq_stream_t stream) {
+    const char *fn = "xq_ms_upsample";
+    int rc = ms_check_grid(fn, B, C, H, W);
+    if (rc) return rc;
+    if (B == 0) return XQ_OK;
+    if (pn < 1 || pn > MS_MAX_HW) return xq_set_error(XQ_EINVAL, "%s: bad patch_num %ld", fn, pn);
+    if (!u || (!h && (!E || !idx))) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (!bicubic && (pn != H || pn != W)) return xq_set_error(XQ_EINVAL, "%s: without interpolation the source grid must equal the target", fn);
+    Taps ty, tx;
+    if (bicubic) { make_taps(pn, H, &ty); make_taps(pn, W, &tx); } else { ty = Taps(); tx = Taps(); }
+    const long total = (long)B * C * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    if (h) {
+        if (!bicubic) {
+            if (hipMemcpyAsync(u, h, (size_t)total * 4, hipMemcpyDeviceToDevice, s) != hipSuccess) return xq_set_error(XQ_ELAUNCH, "%s: copy failed", fn);
+            return XQ_OK;
+        }
+        hipLaunchKernelGGL(up_tensor_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, h, (long)B * C, pn, H, W, ty, tx, u);
+    } else {
+        hipLaunchKernelGGL(gather_up_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, E, C, idx, (long)B, pn, H, W, bicubic, ty, tx, u);
+    }
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_ms_phi_accumulate(const float *u, int B, int C, int H, int W, const float *phi_w, const float *phi_b, float ratio,
+                                    float *f_hat, xq_stream_t stream) {
+    const char *fn = "xq_ms_phi_accumulate";
+    int rc = ms_check_grid(fn, B, C, H, W);
+    if (rc) return rc;
+    if (B == 0) return XQ_OK;
+    if (!u || !f_hat || ((phi_w == nullptr) != (phi_b == nullptr))) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(phi_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, (long)B, C, H, W, phi_w,
+                       phi_b, ratio, phi_w ? 1 : 0, (const float *)nullptr, 0, (const float *)nullptr, f_hat, (float *)nullptr,
+                       (float *)nullptr, (float *)nullptr, (double *)nullptr);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_ms_area_pool(const float *in, int B, int C, int H, int W, int pn, float *out, xq_stream_t stream) {
+    const char *fn = "xq_ms_area_pool";
+    int rc = ms_check_grid(fn, B, C, H, W);
+    if (rc) return rc;
+    if (B == 0) return XQ_OK;
+    if (pn < 1 || pn > MS_MAX_HW || !in || !out) return xq_set_error(XQ_EINVAL, "%s: bad argument", fn);
+    const long n = (long)B * C * pn * pn;
+    hipLaunchKernelGGL(area_pool_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, (long)B * C, H, W, pn, pn, out);
+    return xq_check_launch(fn);
 }

@@ -227,6 +227,68 @@ def msvq_forward_raw(f, codebook, patch_nums, phi_sel, phi_w, phi_b, phi_ratio, 
     return out
 
 
+# ---- ladder primitives as stand-alone ops (VAR-side helpers of VectorQuantizer2; no autograd: the reference runs them
+#      under no_grad / on detached index tensors, quant.py:148-180, :226-258) ------------------------------------------------
+def ms_upsample(src, H, W, codebook=None, bicubic=True):
+    """bicubic (or identity) resize to (H, W) of src = a feature map (B,C,pn,pn), or — with `codebook` — of the code vectors
+    selected by the int64 index map src (B, pn*pn): xq_ms_upsample."""
+    _require_gpu(src, "src")
+    dev = src.device
+    if codebook is None:
+        h = src.detach().float().contiguous()
+        B, C, pn, pn2 = h.shape
+        if pn != pn2:
+            raise XqError("square grids only")
+        E = idx = None
+    else:
+        _require_gpu(codebook, "codebook")
+        E = codebook.detach().float().contiguous()
+        idx = src.detach().to(torch.int64).contiguous()
+        B, L = idx.shape
+        pn = int(round(L ** 0.5))
+        if pn * pn != L:
+            raise XqError(f"index map of {L} tokens is not a square grid")
+        C = E.shape[1]
+        h = None
+    u = torch.empty(B, C, H, W, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib().xq_ms_upsample(ptr(h), ptr(E), ptr(idx), B, C, pn, H, W, int(bool(bicubic)), ptr(u), _stream(u))
+    check(rc, "xq_ms_upsample")
+    return u
+
+
+def ms_phi_accumulate(f_hat, u, phi):
+    """f_hat += phi(u) in place (phi: a quant.Phi conv, or nn.Identity): xq_ms_phi_accumulate."""
+    _require_gpu(f_hat, "f_hat"); _require_gpu(u, "u")
+    if f_hat.dtype != torch.float32:
+        raise XqError("f_hat must be an fp32 tensor (it is updated in place, quant.py:155)")
+    target = f_hat if f_hat.is_contiguous() else f_hat.contiguous()   # channel chunk of a product-quantizer map: a strided view
+    B, C, H, W = f_hat.shape
+    uc = u.detach().float().contiguous()
+    w = getattr(phi, "weight", None)
+    pw = None if w is None else w.detach().float().contiguous()
+    pb = None if w is None else phi.bias.detach().float().contiguous()
+    ratio = float(getattr(phi, "resi_ratio", 0.0))
+    with torch.cuda.device(f_hat.device):
+        rc = _lib.lib().xq_ms_phi_accumulate(ptr(uc), B, C, H, W, ptr(pw), ptr(pb), ctypes.c_float(ratio), ptr(target), _stream(f_hat))
+    check(rc, "xq_ms_phi_accumulate")
+    if target is not f_hat:
+        f_hat.copy_(target)
+    return f_hat
+
+
+def ms_area_pool(x, pn):
+    """F.interpolate(x, (pn, pn), mode='area') on (B,C,H,W) fp32: xq_ms_area_pool."""
+    _require_gpu(x, "x")
+    xc = x.detach().float().contiguous()
+    B, C, H, W = xc.shape
+    out = torch.empty(B, C, pn, pn, dtype=torch.float32, device=xc.device)
+    with torch.cuda.device(xc.device):
+        rc = _lib.lib().xq_ms_area_pool(ptr(xc), B, C, H, W, int(pn), ptr(out), _stream(xc))
+    check(rc, "xq_ms_area_pool")
+    return out
+
+
 class MSVQLadder(torch.autograd.Function):
     """VectorQuantizer2.forward ladder (quant.py:64-135) as one differentiable op.
 

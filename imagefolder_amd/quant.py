@@ -224,55 +224,54 @@ class VectorQuantizer2(nn.Module):
             off += n
         return out
 
-    # ===================== VAR-side helpers (SURVEY §8f "next" #3): plain tensor ops for now =====================
+    # ===================== VAR-side helpers on the ladder primitives of libxq_ops.so =====================
+    # Inference-time plumbing between the tokenizer and the VAR generator.  Each is a short sequence of the three kernels the
+    # fused ladder is made of — ops.ms_upsample (code gather + bicubic), ops.ms_phi_accumulate (f_hat += Phi_k(.)) and
+    # ops.ms_area_pool — so they share its arithmetic (bit-identical to oracle/xq_oracle.c); no autograd, as upstream uses them.
+    def _phi_at(self, si: int, SN: int):
+        return self.quant_resi[si / (SN - 1)] if SN > 1 else self.quant_resi[0]
+
     def embed_to_fhat(self, ms_h_BChw: List[torch.Tensor], all_to_max_scale=True, last_one=False):
-        ls_f_hat_BChw = []
-        B = ms_h_BChw[0].shape[0]
-        H = W = self.v_patch_nums[-1]
-        SN = len(self.v_patch_nums)
+        """cumulative reconstructions from per-scale code embeddings (quant.py:148-180, all_to_max_scale branch)"""
         if not all_to_max_scale:
             raise NotImplementedError("experimental upstream branch (quant.py:165-178) is not mirrored")
-        f_hat = ms_h_BChw[0].new_zeros(B, self.Cvae, H, W, dtype=torch.float32)
-        for si, pn in enumerate(self.v_patch_nums):
-            h_BChw = ms_h_BChw[si]
-            if si < len(self.v_patch_nums) - 1:
-                h_BChw = F.interpolate(h_BChw, size=(H, W), mode='bicubic')
-            h_BChw = self.quant_resi[si / (SN - 1)](h_BChw)
-            f_hat.add_(h_BChw)
-            if last_one:
-                ls_f_hat_BChw = f_hat
-            else:
-                ls_f_hat_BChw.append(f_hat.clone())
-        return ls_f_hat_BChw
+        SN = len(self.v_patch_nums)
+        HW = self.v_patch_nums[-1]
+        B = ms_h_BChw[0].shape[0]
+        f_hat = torch.zeros(B, self.Cvae, HW, HW, dtype=torch.float32, device=ms_h_BChw[0].device)
+        outs = []
+        for si in range(SN):
+            u = ops.ms_upsample(ms_h_BChw[si], HW, HW, bicubic=si < SN - 1)
+            ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
+            if not last_one:
+                outs.append(f_hat.clone())
+        return f_hat if last_one else outs
 
     def idxBl_to_var_input(self, gt_ms_idx_Bl: List[torch.Tensor]) -> torch.Tensor:
-        next_scales = []
-        B = gt_ms_idx_Bl[0].shape[0]
-        C = self.Cvae
-        H = W = self.v_patch_nums[-1]
+        """teacher-forcing input of VAR: the area-pooled running reconstruction before every scale but the first
+        (quant.py:226-245) -> (B, sum_{s >= 1} pn_s^2, C)"""
         SN = len(self.v_patch_nums)
-        f_hat = gt_ms_idx_Bl[0].new_zeros(B, C, H, W, dtype=torch.float32)
-        pn_next: int = self.v_patch_nums[0]
+        HW = self.v_patch_nums[-1]
+        B = gt_ms_idx_Bl[0].shape[0]
+        f_hat = torch.zeros(B, self.Cvae, HW, HW, dtype=torch.float32, device=gt_ms_idx_Bl[0].device)
+        nxt = []
         for si in range(SN - 1):
             if self.prog_si == 0 or (0 <= self.prog_si - 1 < si):
                 break
-            h_BChw = F.interpolate(self.embedding(gt_ms_idx_Bl[si]).transpose_(1, 2).view(B, C, pn_next, pn_next),
-                                   size=(H, W), mode='bicubic')
-            f_hat.add_(self.quant_resi[si / (SN - 1)](h_BChw))
-            pn_next = self.v_patch_nums[si + 1]
-            next_scales.append(F.interpolate(f_hat, size=(pn_next, pn_next), mode='area').view(B, C, -1).transpose(1, 2))
-        return torch.cat(next_scales, dim=1) if len(next_scales) else None
+            u = ops.ms_upsample(gt_ms_idx_Bl[si], HW, HW, codebook=self.embedding.weight, bicubic=True)
+            ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
+            pn = self.v_patch_nums[si + 1]
+            nxt.append(ops.ms_area_pool(f_hat, pn).view(B, self.Cvae, pn * pn).transpose(1, 2))
+        return torch.cat(nxt, dim=1) if nxt else None
 
     def get_next_autoregressive_input(self, si: int, SN: int, f_hat: torch.Tensor, h_BChw: torch.Tensor):
+        """one step of VAR sampling (quant.py:248-258): folds scale si into f_hat IN PLACE, returns (f_hat, next input map)"""
         HW = self.v_patch_nums[-1]
+        u = ops.ms_upsample(h_BChw, HW, HW, bicubic=si != SN - 1)
+        ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
         if si != SN - 1:
-            h = self.quant_resi[si / (SN - 1)](F.interpolate(h_BChw, size=(HW, HW), mode='bicubic'))
-            f_hat.add_(h)
-            return f_hat, F.interpolate(f_hat, size=(self.v_patch_nums[si + 1], self.v_patch_nums[si + 1]), mode='area')
-        else:
-            h = self.quant_resi[si / (SN - 1)](h_BChw)
-            f_hat.add_(h)
-            return f_hat, f_hat
+            return f_hat, ops.ms_area_pool(f_hat, self.v_patch_nums[si + 1])
+        return f_hat, f_hat
 
 
 class VectorQuantizer2Var(VectorQuantizer2):

@@ -268,6 +268,20 @@ int xq_unfold1d_circular(const void *h, int B, int L, int C, int K, int act_bf16
 /* the transpose: dh[b][l][c] = sum_tap dcols[b][(l - tap + K/2) mod L][tap][c] */
 int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K, int act_bf16, void *dh, xq_stream_t stream);
 
+/* ---- VAR-side helpers of VectorQuantizer2 (quant.py:148-180 embed_to_fhat, :226-258 idxBl_to_var_input,
+ *      get_next_autoregressive_input): the ladder's three primitives as stand-alone ops (same kernels, same fma orders as
+ *      xq_msvq_forward).  fp32 NCHW, grids up to 16 x 16. ---------------------------------------------------------------- */
+/* u[B][C][H][W] = F.interpolate(src, (H, W), mode='bicubic') (bicubic = 1) or src itself (bicubic = 0, pn == H == W), where
+ * src = h [B][C][pn][pn] when h != NULL, else the gathered code vectors E[idx[b][p]][c] (idx int64 [B][pn*pn], E [V][C]). */
+int xq_ms_upsample(const float *h, const float *E, const int64_t *idx, int B, int C, int pn, int H, int W, int bicubic, float *u,
+                   xq_stream_t stream);
+/* f_hat += Phi(u), Phi(u) = u * (1 - ratio) + (conv3x3(u, phi_w [C][C][3][3]) + phi_b [C]) * ratio (quant.py:261-268);
+ * phi_w = phi_b = NULL: Phi = identity.  In place on f_hat [B][C][H][W]. */
+int xq_ms_phi_accumulate(const float *u, int B, int C, int H, int W, const float *phi_w, const float *phi_b, float ratio,
+                         float *f_hat, xq_stream_t stream);
+/* out[B][C][pn][pn] = F.interpolate(in [B][C][H][W], (pn, pn), mode='area') */
+int xq_ms_area_pool(const float *in, int B, int C, int H, int W, int pn, float *out, xq_stream_t stream);
+
 /* ---- bf16 GEMMs of the transformer blocks (csrc/xq_gemm.hip; replaces the cuBLAS / hipBLASLt calls behind nn.Linear:
  *      dino_enc/vision_transformer.py:145-197 Attention.qkv / proj, :295-339 Block -> Mlp.fc1 / fc2, :684-692 patch embedding,
  *      dino_enc/to_pixel.py:70-86).  bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16.

@@ -120,6 +120,47 @@ def gen_msvq(name, V, C, B, pns, seed, codebook_drop=0.1, start_drop=3, using_zn
     print("wrote", name, "vq", vq.item(), "commit", float(commit), "usages", [round(u, 2) for u in usages][:4])
 
 
+def gen_var_helpers(name, V, C, B, pns, seed, share=4, var_variant=False):
+    """VAR-side helpers of VectorQuantizer2 (tokenizer_image/quant.py:148-180 embed_to_fhat, :226-245 idxBl_to_var_input,
+    :248-258 get_next_autoregressive_input; var_variant: the same methods of models/quant.py) on a ladder of ground-truth
+    indices produced by the reference's own f_to_idxBl_or_fhat."""
+    R = load_reference()
+    torch.manual_seed(seed)
+    H = W = pns[-1]
+    SN = len(pns)
+    if var_variant:
+        q = R["var_quant"].VectorQuantizer2(V, C, True, beta=0.25, v_patch_nums=tuple(pns), share_quant_resi=share).eval()
+    else:
+        q = R["VectorQuantizer2"](V, C, using_znorm=True, v_patch_nums=list(pns), num_latent_tokens=H * W,
+                                  share_quant_resi=share, codebook_drop=0.0).eval()
+    for c in (list(q.quant_resi.qresi_ls) if share > 1 else [q.quant_resi.qresi]):   # non-trivial Phi convs
+        torch.nn.init.normal_(c.weight, std=0.2)
+        torch.nn.init.normal_(c.bias, std=0.1)
+    q.embedding.weight.data.mul_(1.0 + torch.rand(V, 1))      # rows of different norms (lookups are not normalised)
+    f = torch.randn(B, C, H, W) * 0.6
+    with torch.no_grad():
+        idx_list = q.f_to_idxBl_or_fhat(f, to_fhat=False, v_patch_nums=None)
+        ms_h = [q.embedding(idx).transpose(1, 2).reshape(B, C, pn, pn).contiguous() for idx, pn in zip(idx_list, pns)]
+        fhats = q.embed_to_fhat(ms_h, all_to_max_scale=True, last_one=False)
+        fhat_last = q.embed_to_fhat(ms_h, all_to_max_scale=True, last_one=True)
+        var_in = q.idxBl_to_var_input(idx_list)
+        f_hat = torch.zeros(B, C, H, W)
+        nexts = []
+        for si in range(SN):
+            f_hat, nxt = q.get_next_autoregressive_input(si, SN, f_hat, ms_h[si])
+            nexts.append(nxt.clone())
+    convs = list(q.quant_resi.qresi_ls) if share > 1 else [q.quant_resi.qresi]
+    phi_sel = [int(np.argmin(np.abs(q.quant_resi.ticks - si / (SN - 1)))) for si in range(SN)] if share > 1 else [0] * SN
+    np.savez(os.path.join(OUT, name + ".npz"), E=q.embedding.weight.detach().numpy(), pns=np.array(pns, np.int32),
+             share=np.int32(share), var_variant=np.int32(var_variant),
+             phi_w=np.stack([c.weight.detach().numpy() for c in convs]), phi_b=np.stack([c.bias.detach().numpy() for c in convs]),
+             phi_sel=np.array(phi_sel, np.int32), phi_ratio=np.float32(abs(q.quant_resi_ratio)),
+             idx=np.concatenate([i.reshape(-1).numpy() for i in idx_list]),
+             fhat_scales=np.stack([t.numpy() for t in fhats]), fhat_last=fhat_last.numpy(), var_input=var_in.numpy(),
+             next_maps=np.concatenate([t.reshape(-1).numpy() for t in nexts]), f_hat_final=f_hat.numpy(), meta=np.array(str(meta())))
+    print("wrote", name, "var_input", tuple(var_in.shape), "|f_hat|", float(f_hat.abs().mean()))
+
+
 def gen_lfq(name, Cbits, B, pns, seed, codebook_drop=0.1, start_drop=3, using_znorm=True, share=4, entropy_weight=0.1):
     """LFQ.forward/backward (lookup_free_quantize.py:149-250) in train mode with quantizer dropout + f_to_idxBl_or_fhat."""
     R = load_reference()
@@ -205,6 +246,13 @@ def main():
         gen_msvq("msvq_16grid_v512_c16_b4", 512, 16, 4, [1, 2, 3, 4, 5, 6, 8, 10, 13, 16], seed=21, codebook_drop=0.5, start_drop=1)
         gen_msvq("msvq_rawl2_v256_c8_b3", 256, 8, 3, [1, 2, 4, 7], seed=22, using_znorm=False, codebook_drop=0.4, start_drop=2)
         gen_msvq("msvq_var_models_quant_v512_c32_b4", 512, 32, 4, [1, 2, 3, 4, 5, 6, 8, 10], seed=23, var_variant=True)
+        if only:
+            return
+    if only in ("var", ""):
+        # VAR-d16 geometry (1x1 -> 16x16, 10 scales, 4 partially shared Phi) and the MSVR10P2 ladder; models/quant.py twin
+        gen_var_helpers("var_helpers_16grid_v512_c16_b3", 512, 16, 3, [1, 2, 3, 4, 5, 6, 8, 10, 13, 16], seed=50)
+        gen_var_helpers("var_helpers_cfg4_ladder_v1024_c32_b4", 1024, 32, 4, [1, 1, 2, 3, 3, 4, 5, 6, 8, 11], seed=51)
+        gen_var_helpers("var_helpers_models_quant_v256_c8_b2", 256, 8, 2, [1, 2, 3, 4, 6, 8], seed=52, var_variant=True, share=1)
         if only:
             return
     if only == "perturb":

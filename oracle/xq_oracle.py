@@ -192,6 +192,58 @@ def msvq_forward(f_bchw, E, patch_nums, phi_sel, phi_w, phi_b, phi_ratio, using_
 
 
 # ---------------------------------------------------------------------------------------------------
+# VAR-side helpers of VectorQuantizer2 restated on the ladder primitives above
+# (tokenizer/tokenizer_image/quant.py:148-180, :226-245, :248-258; identical methods in models/quant.py:107-215)
+# ---------------------------------------------------------------------------------------------------
+def gather_nchw(E, idx_bl, pn):
+    """embedding(idx).transpose(1, 2).view(B, C, pn, pn)  (quant.py:238)"""
+    E = _f32(E)
+    idx = np.ascontiguousarray(idx_bl, np.int64)
+    return np.ascontiguousarray(E[idx].transpose(0, 2, 1).reshape(idx.shape[0], E.shape[1], pn, pn), np.float32)
+
+
+def _phi_k(u, k, phi_w, phi_b, ratio):
+    return u if phi_w is None else phi(u, phi_w[k], phi_b[k], ratio)
+
+
+def embed_to_fhat(ms_h, patch_nums, phi_sel, phi_w, phi_b, ratio):
+    """quant.py:148-164 (all_to_max_scale): list of cumulative f_hat, one per scale"""
+    SN, HW = len(patch_nums), int(patch_nums[-1])
+    f_hat = np.zeros((ms_h[0].shape[0], ms_h[0].shape[1], HW, HW), np.float32)
+    out = []
+    for si in range(SN):
+        u = bicubic_up(ms_h[si], HW, HW) if si < SN - 1 else _f32(ms_h[si])
+        f_hat = f_hat + _phi_k(u, phi_sel[si], phi_w, phi_b, ratio)
+        out.append(f_hat.copy())
+    return out
+
+
+def idxBl_to_var_input(idx_list, E, patch_nums, phi_sel, phi_w, phi_b, ratio):
+    """quant.py:226-245 -> (B, sum_{s>=1} pn_s^2, C)"""
+    SN, HW = len(patch_nums), int(patch_nums[-1])
+    B, C = idx_list[0].shape[0], E.shape[1]
+    f_hat = np.zeros((B, C, HW, HW), np.float32)
+    nxt = []
+    for si in range(SN - 1):
+        u = bicubic_up(gather_nchw(E, idx_list[si], int(patch_nums[si])), HW, HW)
+        f_hat = f_hat + _phi_k(u, phi_sel[si], phi_w, phi_b, ratio)
+        pn = int(patch_nums[si + 1])
+        nxt.append(area_pool(f_hat, pn, pn).reshape(B, C, pn * pn).transpose(0, 2, 1))
+    return np.concatenate(nxt, axis=1)
+
+
+def next_autoregressive_input(si, f_hat, h, patch_nums, phi_sel, phi_w, phi_b, ratio):
+    """quant.py:248-258 -> (f_hat', next token map)"""
+    SN, HW = len(patch_nums), int(patch_nums[-1])
+    u = bicubic_up(h, HW, HW) if si != SN - 1 else _f32(h)
+    f_hat = _f32(f_hat) + _phi_k(u, phi_sel[si], phi_w, phi_b, ratio)
+    if si != SN - 1:
+        pn = int(patch_nums[si + 1])
+        return f_hat, area_pool(f_hat, pn, pn)
+    return f_hat, f_hat
+
+
+# ---------------------------------------------------------------------------------------------------
 # fp64 margin checker: is a disagreement between two index choices a sub-ulp tie?
 # ---------------------------------------------------------------------------------------------------
 def fp64_scores(z_bchw, E, mode, tokens):
