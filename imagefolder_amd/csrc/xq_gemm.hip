@@ -54,6 +54,7 @@ struct GemmArgs {
     long main_items;
     int tail_tiles, tail_splits, kt_full;
     float *slabs;
+    int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(region + off);
                     const long gr = cit.m0 + 128 * wr + 32 * fi + row;
                     const long gc = ncol0 + 8 * c;
-                    if (gr < g.M && gc + 8 <= g.N) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
+                    if (gr < g.M && gc + 8 <= g.N && !g.debug_no_store) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
                 }
             }
         }
@@ -854,8 +855,9 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     if (M == 0 || N == 0) return XQ_OK;
     if (!x || !w || !y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     const int BN = pick_bn(N, impl);
-    impl &= 0xff;
     GemmArgs g{};
+    g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
+    impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;

@@ -1,0 +1,92 @@
+"""Bulk tokenisation (reference scripts/pretokenization.py:150-259): record layout, the RAR jsonl and
+VAR / LlamaGen npy formats as their readers consume them (data/webdataset_reader.py:253-267, dataset/imagenet.py:8-50),
+and — on the GPU — tokens bit-identical to the reference's code indices on the committed model goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from imagefolder_amd import tokenize as tk
+
+
+class _FakeQuant:
+    vocab_size = 100
+
+
+class _FakeModel(torch.nn.Module):
+    """img_to_idx contract of VQModel: list over product branches of lists over scales"""
+    def __init__(self, P=1, pns=(4,)):
+        super().__init__()
+        self.product_quant = P
+        self.quantize = _FakeQuant()
+        self.quantizes = [_FakeQuant() for _ in range(P)]
+        self.pns = pns
+        self.w = torch.nn.Parameter(torch.zeros(1))
+
+    def img_to_idx(self, x):
+        B = x.shape[0]
+        code = (x.flatten(1).sum(1).abs() * 7).long() % 90           # depends on the image, invariant to a flip
+        left = (x[:, 0, 0, 0] * 1000).long().abs() % 7               # NOT invariant to a flip
+        return [[(code[:, None] + torch.arange(pn * pn)[None] + p + left[:, None]) % 100 for pn in self.pns]
+                for p in range(self.product_quant)]
+
+
+def test_records_flip_jsonl_and_npy_formats(tmp_path):
+    torch.manual_seed(0)
+    model = _FakeModel(P=2, pns=(1, 2, 3))
+    batches = [(torch.randn(3, 3, 8, 8), torch.tensor([5, 6, 7])), (torch.randn(2, 3, 8, 8), torch.tensor([8, 9]))]
+    bt = tk.BulkTokenizer(model, augment="flip").run(batches)
+    cls, tok = bt.records
+    L = 2 * (1 + 4 + 9)
+    assert tok.shape == (10, L) and tok.dtype == np.int64
+    assert cls.tolist() == [5, 6, 7, 5, 6, 7, 8, 9, 8, 9]                       # pretokenization.py:227-228 ordering
+    assert tok[:, :14].max() < 100 and tok[:, 14:].min() >= 100                 # branch p offset by p * V
+    direct = tk.tokens_from_images(model, torch.cat([batches[0][0], torch.flip(batches[0][0], dims=[-1])]))
+    assert np.array_equal(tok[:6], direct.numpy())
+
+    # RAR: per-rank json -> jsonl -> what PretoeknizedDataSetJSONL.__getitem__ returns
+    bt.write_rank_json(str(tmp_path), rank=0)
+    bt.write_rank_json(str(tmp_path), rank=1)                                    # a second rank's shard
+    n = tk.convert_json_to_jsonl(os.path.join(tmp_path, "pretokenized_*.json"), os.path.join(tmp_path, "pretokenized.jsonl"))
+    assert n == 20
+    lines = open(os.path.join(tmp_path, "pretokenized.jsonl")).read().splitlines()
+    assert len(lines) == 20 and set(json.loads(lines[0])) == {"class_id", "tokens"}
+    c, t = tk.read_jsonl_record(os.path.join(tmp_path, "pretokenized.jsonl"), 4)
+    assert c.item() == 6 and t.dtype == torch.int64 and np.array_equal(t.numpy(), tok[4])
+
+    # VAR / LlamaGen: the two views of one image adjacent, (1, n_aug, L) codes + (1,) label per source image
+    c2, t2 = tk.regroup_flip(cls, tok, [3, 2])
+    assert c2.tolist() == [5, 5, 6, 6, 7, 7, 8, 8, 9, 9]
+    bt.class_ids, bt.tokens = [c2], [t2]
+    n_img = bt.write_code_npy(os.path.join(tmp_path, "codes"), os.path.join(tmp_path, "labels"), n_aug=2)
+    assert n_img == 5
+    feats = np.load(os.path.join(tmp_path, "codes", "2.npy"))
+    labels = np.load(os.path.join(tmp_path, "labels", "2.npy"))
+    assert feats.shape == (1, 2, L) and labels.shape == (1,) and labels[0] == 7
+    assert np.array_equal(feats[:, 1], tok[5:6])                                  # CustomDataset: features[:, aug_idx]
+
+
+def test_ten_crop_layout():
+    model = _FakeModel()
+    x = torch.randn(2, 10, 3, 8, 8)
+    bt = tk.BulkTokenizer(model, augment="ten_crop").run([(x, torch.tensor([1, 2]))])
+    cls, tok = bt.records
+    assert cls.tolist() == [1] * 10 + [2] * 10 and tok.shape == (20, 16)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["model_cfg1_cnn_vq4096", "model_cfg2_vitb_vq8192"])
+def test_tokens_equal_reference_indices_on_model_goldens(oracle, name, tmp_path):
+    from test_model_parity import build
+    m, g = build(name)
+    m = m.cuda()
+    x = torch.from_numpy(g["x"]).cuda()
+    out = tk.pretokenize(m, [(x, torch.tensor([3])), (x, torch.tensor([4]))], str(tmp_path), augment="none")
+    c0, t0 = tk.read_jsonl_record(out, 0)
+    c1, t1 = tk.read_jsonl_record(out, 1)
+    assert (c0.item(), c1.item()) == (3, 4) and torch.equal(t0, t1)
+    E = m.quantize.embedding.weight.detach().cpu().numpy()
+    par = oracle.index_parity(g["f"], E, oracle.MODE_L2_NORMED, t0.numpy(), g["idx"], tol=2e-4)
+    assert par["match_rate"] >= 0.98 and par["all_ties"], par                     # same contract as test_model_parity
