@@ -54,7 +54,6 @@ struct GemmArgs {
     long main_items;
     int tail_tiles, tail_splits, kt_full;
     float *slabs;
-    int skew;               // phase-shift three quarters of the CUs (BlockProgram); XQ_GEMM_NO_SKEW turns it off
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
 };
 
@@ -431,50 +430,18 @@ struct PItem {
     int KT;
     int slab;            // 0: bf16 epilogue into C; 1: fp32 slab
     long slab_idx;
-    int qmask;           // which of the four 64 x 32-per-wave quadrant phases this item computes (bit p = phase p); 15 = whole tile
 };
 
-// The item list of one workgroup ("block program").  Whole tiles are dealt round-robin (tile r of block b = position
-// first + r * G of the XCD-aware order).  All CUs of a round would finish their tiles — and burst their 128 KiB of output
-// each — at the same instant: 33 MB hit the memory system at once, HBM takes ~7 us to absorb it and the loads of the next
-// tiles queue behind the stores (measured: the stores cost 14-26 % of the K = 768 layers, profiles/r02_gemm_nostore.txt).
-// So three quarters of the CUs are phase-shifted: class c = 1, 2, 3 starts with only the first c quadrant phases of its
-// first tile (a quarter, half, three quarters of a tile's MFMA work) and finishes that tile's remaining quadrants as
-// its last whole-tile item.  Every quadrant still sees its full K range in one item: results are bit-identical.
-struct BlockProgram {
-    long first, G, R, n_main, n_items;
-    int cls;
-};
-__device__ __forceinline__ BlockProgram make_program(const GemmArgs &g) {
-    BlockProgram bp;
-    bp.G = gridDim.x;
-    const long b = blockIdx.x;
-    bp.first = gm::xcd_order(b, bp.G);
-    bp.R = g.main_items > bp.first ? (g.main_items - bp.first + bp.G - 1) / bp.G : 0;
-    bp.cls = (bp.R >= 1 && g.skew) ? (int)((b >> 3) & 3) : 0;
-    bp.n_main = bp.R + (bp.cls ? 1 : 0);
-    const long tail_items = (long)g.tail_tiles * g.tail_splits;
-    const long tails = tail_items > b ? (tail_items - b + bp.G - 1) / bp.G : 0;
-    bp.n_items = bp.n_main + tails;
-    return bp;
-}
-
-__device__ __forceinline__ void decode_item(const GemmArgs &g, const BlockProgram &bp, long j, PItem &it) {
+__device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it) {
     long tile, split, nsplit;
-    if (j < bp.n_main) {
-        const int low = (1 << bp.cls) - 1;                 // class 1: phase 0; 2: phases 0-1; 3: phases 0-2
-        if (bp.cls && j == 0) { tile = bp.first; it.qmask = low; }
-        else if (bp.cls && j == bp.n_main - 1) { tile = bp.first; it.qmask = 15 ^ low; }
-        else { tile = bp.first + j * bp.G; it.qmask = 15; }
-        split = 0; nsplit = 1; it.slab = 0; it.slab_idx = 0;
-    } else {
-        const long q = (long)blockIdx.x + (j - bp.n_main) * bp.G;
+    if (p < g.main_items) { tile = p; split = 0; nsplit = 1; it.slab = 0; it.slab_idx = 0; }
+    else {
+        const long q = p - g.main_items;
         nsplit = g.tail_splits;
         tile = g.main_items + q / nsplit;
         split = q - (q / nsplit) * nsplit;
         it.slab = 1;
         it.slab_idx = q;
-        it.qmask = 15;
     }
     it.m0 = (tile / g.tiles_n) * gm::BM;
     it.n0 = (tile % g.tiles_n) * 256;
@@ -490,18 +457,19 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
-    const BlockProgram bp = make_program(g);
-    if (bp.n_items == 0) return;
-    long cj = 0;                                      // compute position in this block's item list
+    const long G = gridDim.x;
+    const long items = g.main_items + (long)g.tail_tiles * g.tail_splits;
+    long cp = gm::xcd_order(blockIdx.x, G);          // compute position in the item list (stride G)
+    if (cp >= items) return;
     PItem cit;
-    decode_item(g, bp, cj, cit);
+    decode_item(g, cp, cit);
 
     // staging cursor
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.init(g.A, g.lda, cit.m0, g.M, cit.k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, cit.n0, g.N, cit.k0, wave, lane, WTN, 2);
-    long sj = 0;                                      // the item the staging cursor is in
+    long sp = cp;
     int s_kt = 0, s_KT = cit.KT, s_par = 0, r_par = 0;
     // past the last item the cursor keeps issuing the SAME number of LDS-DMA instructions per phase (re-reading its last K
     // tile into this wave's own epilogue staging area), so that the counted vmcnt(8) of the phases stays exact to the end
@@ -532,10 +500,10 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     do {                                                                               \
         s_par ^= 1;                                                                    \
         if (!s_dummy && ++s_kt == s_KT) {                                              \
-            ++sj;                                                                      \
-            if (sj < bp.n_items) {                                                     \
+            sp += G;                                                                   \
+            if (sp < items) {                                                          \
                 PItem nx_;                                                             \
-                decode_item(g, bp, sj, nx_);                                           \
+                decode_item(g, sp, nx_);                                               \
                 sa.init(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN, 2);          \
                 sb.init(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN, 2);          \
                 s_KT = nx_.KT;                                                         \
@@ -570,34 +538,32 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
     // one K tile (phases as in gemm_ring_kernel): always one piece staged per phase, always vmcnt(8)
-    // FULL: whole-tile item (no tests in the loop); otherwise the reads and MFMAs of the quadrants outside qm are skipped
-    // (staging, waits and barriers stay: the ring and the vmcnt bookkeeping do not depend on the item)
-#define PR_TILE(FULL, qm)                                                     \
+#define PR_TILE()                                                             \
     do {                                                                      \
-        if (FULL || ((qm) & 9)) { PR_READ_B(bl, 1) }                          \
-        if (FULL || ((qm) & 3)) { PR_READ_A(0) }                              \
+        PR_READ_B(bl, 1)                                                      \
+        PR_READ_A(0)                                                          \
         PR_STAGE(2);                                                          \
         GR_VMCNT(8);                                                          \
         GR_BARRIER();                                                         \
-        if (FULL || ((qm) & 1)) PR_MFMA(0, 0, bl);                            \
+        PR_MFMA(0, 0, bl);                                                    \
         GR_BARRIER();                                                         \
-        if (FULL || ((qm) & 6)) { PR_READ_B(br, 2) }                          \
+        PR_READ_B(br, 2)                                                      \
         PR_STAGE(3);                                                          \
         GR_VMCNT(8);                                                          \
         GR_BARRIER();                                                         \
-        if (FULL || ((qm) & 2)) PR_MFMA(0, 1, br);                            \
+        PR_MFMA(0, 1, br);                                                    \
         GR_BARRIER();                                                         \
-        if (FULL || ((qm) & 12)) { PR_READ_A(3) }                             \
+        PR_READ_A(3)                                                          \
         PR_ADVANCE();                                                         \
         PR_STAGE(0);                                                          \
         GR_VMCNT(8);                                                          \
         GR_BARRIER();                                                         \
-        if (FULL || ((qm) & 4)) PR_MFMA(2, 1, br);                            \
+        PR_MFMA(2, 1, br);                                                    \
         GR_BARRIER();                                                         \
         PR_STAGE(1);                                                          \
         GR_VMCNT(8);                                                          \
         GR_BARRIER();                                                         \
-        if (FULL || ((qm) & 8)) PR_MFMA(2, 0, bl);                            \
+        PR_MFMA(2, 0, bl);                                                    \
         GR_BARRIER();                                                         \
         r_par ^= 1;                                                           \
     } while (0)
@@ -615,10 +581,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 
     const int h = lane >> 5;
     for (;;) {
-        const bool has_next = cj + 1 < bp.n_items;
-        const int qm = cit.qmask;
+        const bool has_next = cp + G < items;
         if (wr == 1) GR_BARRIER();
-        for (int kt = 0; kt < cit.KT; ++kt) PR_TILE(false, qm);   // one copy of the tile body: a second one makes hipcc spill
+        for (int kt = 0; kt < cit.KT; ++kt) PR_TILE();
         if (wr == 0) GR_BARRIER();
         if (!has_next) GR_VMCNT(0);      // the dummy pieces target `region`
 
@@ -647,12 +612,8 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                     bv[fj][q] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
-            // quadrant (rows fi in {0,1} | {2,3}) x (columns fj = 0 | 1) <-> phase: (top,left) 0, (top,right) 1, (bottom,right) 2,
-            // (bottom,left) 3
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi) {
-                const int cols = (fi < 2) ? (qm & 3) : (((qm >> 3) & 1) | ((qm >> 1) & 2));   // bit fj: column half present
-                if (cols == 0) continue;
 #pragma unroll
                 for (int fj = 0; fj < 2; ++fj)
 #pragma unroll
@@ -670,15 +631,14 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                     const uint4 v = *reinterpret_cast<const uint4 *>(region + off);
                     const long gr = cit.m0 + 128 * wr + 32 * fi + row;
                     const long gc = ncol0 + 8 * c;
-                    const bool have = (cols >> (c >> 2)) & 1;          // 16-byte chunk c belongs to column half c / 4
-                    if (have && gr < g.M && gc + 8 <= g.N && !g.debug_no_store) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
+                    if (gr < g.M && gc + 8 <= g.N && !g.debug_no_store) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
                 }
             }
         }
         if (!has_next) break;
         PR_ZERO()
-        ++cj;
-        decode_item(g, bp, cj, cit);
+        cp += G;
+        decode_item(g, cp, cit);
     }
 #undef PR_TILE
 #undef PR_MFMA
@@ -897,7 +857,6 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
-    g.skew = (impl & XQ_GEMM_NO_SKEW) ? 0 : 1;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -913,9 +872,8 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     if (M == 0 || N == 0) return XQ_OK;
     if (!g_y || !w || !g_x) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     const int BN = pick_bn(N, impl);
-    GemmArgs g{};
-    g.skew = (impl & XQ_GEMM_NO_SKEW) ? 0 : 1;
     impl &= 0xff;
+    GemmArgs g{};
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;

@@ -293,7 +293,6 @@ int xq_ms_area_pool(const float *in, int B, int C, int H, int W, int pn, float *
                                 cut along K into fp32 slabs (256-column tiles, >= 2 K tiles per item)                       */
 #define XQ_GEMM_WIDE_TILES 0x100 /* OR-ed into impl: 256-column tiles even when N is not a multiple of 256 (ragged last tile) */
 #define XQ_GEMM_DEBUG_NO_STORE 0x200 /* OR-ed into impl (NT, persistent schedule): skip the output stores — timing experiments, result unusable */
-#define XQ_GEMM_NO_SKEW 0x400 /* OR-ed into impl (persistent schedule): all CUs start on whole tiles (no phase shift between CU classes) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2
