@@ -22,6 +22,7 @@
 #include "xq_common.hpp"
 #include "xq_internal.hpp"
 #include "xq_gemm_map.hpp"
+#include "xq_act.hpp"
 #include "../../include/xq_ops.h"
 
 #include <hip/hip_bf16.h>
@@ -39,6 +40,8 @@ typedef __attribute__((address_space(1))) void gbl_void;
 
 constexpr int GT = 512;               // threads per block
 enum { EPI_BF16 = 0, EPI_F32_SLAB = 1 };
+// epilogue activation of the persistent kernel's bf16 outputs (template parameter ACT)
+enum { ACT_NONE = 0, ACT_GELU_FWD = 1, ACT_GELU_BWD = 2 };
 
 struct GemmArgs {
     const char *A, *B;      // bf16
@@ -54,6 +57,14 @@ struct GemmArgs {
     long main_items;
     int tail_tiles, tail_splits, kt_full;
     float *slabs;
+    // fused GELU (persistent schedule).  ACT_GELU_FWD: C = h (pre-activation, + bias), C2 = gelu(h).  ACT_GELU_BWD: C = acc * gelu'(H),
+    // colpart[2 * row_tile + wave_row][N] = column sums of C over the 128 rows of that wave row (fc1 bias gradient)
+    char *C2;
+    const char *H;
+    float *colpart;
+    int gelu_tanh;
+    int nt_store;           // non-temporal bf16 output stores (default; XQ_GEMM_PLAIN_STORE turns them off): the 128 KiB a CU
+                            // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
 };
 
@@ -450,7 +461,10 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
     it.KT = (int)(base + (split < rem ? 1 : 0));
 }
 
-template <int AK, int BK>
+__device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+template <int AK, int BK, int ACT>
 __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int WTN = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 8 ring slots + 8 x 4 KiB epilogue staging
@@ -612,8 +626,22 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                     bv[fj][q] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ACT_GELU_BWD: this lane's 8 columns over its 16 rows
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi) {
+                u32x4 hv[4];
+                if (ACT == ACT_GELU_BWD) {      // the pre-activations of the 4 store passes, fetched ahead of the LDS round trip
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        int row, c, off;
+                        gm::epi_read_map(it, lane, WTN, &row, &c, &off);
+                        long gr = cit.m0 + 128 * wr + 32 * fi + row, gc = ncol0 + 8 * c;
+                        if (gr > g.M - 1) gr = g.M - 1;
+                        if (gc > g.N - 8) gc = g.N - 8;
+                        hv[it] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __hip_bfloat16 *>(g.H) + gr * g.ldc + gc);
+                    }
+                }
 #pragma unroll
                 for (int fj = 0; fj < 2; ++fj)
 #pragma unroll
@@ -628,10 +656,53 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                 for (int it = 0; it < 4; ++it) {
                     int row, c, off;
                     gm::epi_read_map(it, lane, WTN, &row, &c, &off);
-                    const uint4 v = *reinterpret_cast<const uint4 *>(region + off);
+                    const u32x4 v = *reinterpret_cast<const u32x4 *>(region + off);
                     const long gr = cit.m0 + 128 * wr + 32 * fi + row;
                     const long gc = ncol0 + 8 * c;
-                    if (gr < g.M && gc + 8 <= g.N && !g.debug_no_store) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
+                    const bool ok = gr < g.M && gc + 8 <= g.N && !g.debug_no_store;
+                    u32x4 o = v;
+                    if (ACT == ACT_GELU_FWD) {
+                        // the activation acts on the bf16-ROUNDED pre-activation, as the unfused pair (Linear -> GELU) does
+                        u32x4 a2;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float x0 = bf16_lo(v[e]), x1 = bf16_hi(v[e]);
+                            a2[e] = g.gelu_tanh ? pack_bf16(gelu_val<true>(x0), gelu_val<true>(x1)) : pack_bf16(gelu_val<false>(x0), gelu_val<false>(x1));
+                        }
+                        if (ok) {
+                            u32x4 *p2 = reinterpret_cast<u32x4 *>(reinterpret_cast<__hip_bfloat16 *>(g.C2) + gr * g.ldc + gc);
+                            if (g.nt_store) __builtin_nontemporal_store(a2, p2); else *p2 = a2;
+                        }
+                    } else if (ACT == ACT_GELU_BWD) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float d0 = g.gelu_tanh ? gelu_grad<true>(bf16_lo(hv[it][e])) : gelu_grad<false>(bf16_lo(hv[it][e]));
+                            const float d1 = g.gelu_tanh ? gelu_grad<true>(bf16_hi(hv[it][e])) : gelu_grad<false>(bf16_hi(hv[it][e]));
+                            o[e] = pack_bf16(bf16_lo(v[e]) * d0, bf16_hi(v[e]) * d1);
+                            if (gr < g.M) { csum[2 * e] += bf16_lo(o[e]); csum[2 * e + 1] += bf16_hi(o[e]); }
+                        }
+                    }
+                    if (ok) {
+                        u32x4 *p1 = reinterpret_cast<u32x4 *>(C + gr * g.ldc + gc);
+                        if (g.nt_store) __builtin_nontemporal_store(o, p1); else *p1 = o;
+                    }
+                }
+            }
+            if (ACT == ACT_GELU_BWD && g.colpart) {
+                // lanes l, l + 8, ..., l + 56 hold the same 8 columns (c = l & 7) for different rows
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = csum[e];
+                    t += __shfl_xor(t, 8);
+                    t += __shfl_xor(t, 16);
+                    t += __shfl_xor(t, 32);
+                    csum[e] = t;
+                }
+                const long gc = ncol0 + 8 * (lane & 7);
+                if (lane < 8 && gc + 8 <= g.N) {
+                    float *cp = g.colpart + ((cit.m0 / 128) + wr) * g.N + gc;
+                    *reinterpret_cast<float4 *>(cp) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+                    *reinterpret_cast<float4 *>(cp + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
                 }
             }
         }
@@ -772,7 +843,7 @@ PPlan plan_persistent(long tiles, int kt_full, bool weight_grad) {
     return p;
 }
 
-template <int AK, int BK, int EPI>
+template <int AK, int BK, int EPI, int ACT = ACT_NONE>
 int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStream_t s, const char *fn, double flops) {
     const long tiles = (long)g.tiles_m * g.tiles_n;
     if (tiles <= 0) return XQ_OK;
@@ -784,6 +855,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
     const int pslot = prof_begin(XQ_PROF_GEMM, flops, s);
     if (impl == XQ_GEMM_PERSISTENT) {
         PPlan pl = plan_persistent(tiles, g.kt_full, EPI == EPI_F32_SLAB);
+        if (ACT != ACT_NONE) pl = PPlan{tiles, 0, 1, 0};   // the fused activation lives in the whole-tile epilogue
         if (pl.slab_bytes > ws_bytes || (pl.slab_bytes && !ws)) {
             if (EPI == EPI_F32_SLAB) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
             pl = PPlan{tiles, 0, 1, 0};      // no workspace: every tile whole
@@ -795,13 +867,14 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
         const long grid = items < num_cus() ? items : num_cus();
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
-        if (set_lds<gemm_pring_kernel<AK, BK>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-        hipLaunchKernelGGL((gemm_pring_kernel<AK, BK>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+        if (set_lds<gemm_pring_kernel<AK, BK, ACT>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+        hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT>), dim3((unsigned)grid), dim3(GT), lds, s, g);
         if (EPI == EPI_BF16 && pl.tail_tiles)
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
                                pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
                                (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L);
     } else {
+        if (ACT != ACT_NONE) return xq_set_error(XQ_EINVAL, "%s: the fused activation needs the persistent schedule", fn);
         const long total = tiles * g.splits;
         if (impl == XQ_GEMM_RING) {
             const int lds = 8 * gm::PIECE_BYTES;
@@ -857,6 +930,7 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
+    g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -872,8 +946,9 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     if (M == 0 || N == 0) return XQ_OK;
     if (!g_y || !w || !g_x) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     const int BN = pick_bn(N, impl);
-    impl &= 0xff;
     GemmArgs g{};
+    g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
+    impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
@@ -919,4 +994,39 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
                            (long)Q, (const __hip_bfloat16 *)g_y, (const __hip_bfloat16 *)x, done, (long)R, g_w);
     }
     return xq_check_launch(fn);
+}
+
+// ---- fused MLP GEMMs (persistent schedule only: N >= 256, K >= 128) -----------------------------------------------------
+extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *h, void *h_act,
+                                    int approximate_tanh, xq_stream_t stream) {
+    const char *fn = "xq_gemm_bf16_nt_gelu";
+    if (int rc = check_mnk(fn, M, N, K)) return rc;
+    if (M == 0 || N == 0) return XQ_OK;
+    if (!x || !w || !h || !h_act) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (N < 256 || K < 128) return xq_set_error(XQ_EINVAL, "%s: needs N >= 256 and K >= 128 (N=%ld K=%ld)", fn, (long)N, (long)K);
+    GemmArgs g{};
+    g.nt_store = 1;
+    g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)h; g.C2 = (char *)h_act; g.gelu_tanh = approximate_tanh;
+    g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
+    g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
+    return launch_gemm<gm::KMAJOR, gm::KMAJOR, EPI_BF16, ACT_GELU_FWD>(g, 256, XQ_GEMM_PERSISTENT, nullptr, 0, (hipStream_t)stream, fn, 2.0 * M * N * K);
+}
+
+extern "C" size_t xq_gemm_colpart_rows(int64_t M) { return M > 0 ? (size_t)(2 * ((M + 255) / 256)) : 0; }
+
+extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h,
+                                        float *colpart, int approximate_tanh, xq_stream_t stream) {
+    const char *fn = "xq_gemm_bf16_nn_gelu_bwd";
+    if (int rc = check_mnk(fn, M, N, K)) return rc;
+    if (M == 0 || N == 0) return XQ_OK;
+    if (!g_y || !w || !h || !g_h) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (N < 256 || K < 128) return xq_set_error(XQ_EINVAL, "%s: needs N >= 256 and K >= 128 (N=%ld K=%ld)", fn, (long)N, (long)K);
+    GemmArgs g{};
+    g.nt_store = 1;
+    g.A = (const char *)g_y; g.B = (const char *)w; g.C = (char *)g_h; g.H = (const char *)h; g.colpart = colpart; g.gelu_tanh = approximate_tanh;
+    g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
+    g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
+    return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16, ACT_GELU_BWD>(g, 256, XQ_GEMM_PERSISTENT, nullptr, 0, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }

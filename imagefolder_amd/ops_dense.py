@@ -211,7 +211,7 @@ def _weight_grad(g2, x2, wdtype):
 # path of tests/test_model_parity.py) and shapes outside the kernels' contract always take the library call.
 import os as _os
 GEMM_IMPL = _os.environ.get("XQ_GEMM", "hip")
-GEMM_SCHEDULE = int(_os.environ.get("XQ_GEMM_SCHEDULE", "0"))   # 0 auto, 1 simple, 2 ring, 3 persistent (include/xq_ops.h XQ_GEMM_*)
+GEMM_SCHEDULE = int(_os.environ.get("XQ_GEMM_SCHEDULE", "0"), 0)   # 0 auto, 1 simple, 2 ring, 3 persistent (include/xq_ops.h XQ_GEMM_*)
 
 
 def _gemm_ok(rows, n_out, k_red):
@@ -326,6 +326,66 @@ class LinearFn(torch.autograd.Function):
         return g_x, g_w, g_b, None
 
 
+FUSED_MLP = _os.environ.get("XQ_FUSED_MLP", "1") == "1"
+
+
+def mlp_fused_supported(a, mlp):
+    """fc1 -> GELU -> fc2 on the GEMMs with the activation in their epilogues: bf16 activations, hidden and model widths that
+    the persistent GEMM schedule takes (>= 256 columns, reduction depths multiples of 64 and >= 128)."""
+    w1, w2 = mlp.fc1.weight, mlp.fc2.weight
+    Hd, D = w1.shape
+    return (FUSED_MLP and GEMM_IMPL == "hip" and a.is_cuda and a.dtype == torch.bfloat16 and Hd >= 256 and D >= 256 and Hd % 64 == 0
+            and D % 64 == 0 and D >= 128 and Hd % 8 == 0 and mlp.fc1.bias is not None and tuple(w2.shape) == (D, Hd))
+
+
+class MlpFn(torch.autograd.Function):
+    """f = fc2(GELU(fc1(a))) (timm Mlp, vision_transformer.py:295-339) as four GEMM launches per direction instead of GEMMs +
+    two elementwise passes: forward  h, GELU(h) from ONE launch (xq_gemm_bf16_nt_gelu), f = xq_gemm_bf16_nt;
+    backward g_h = (g_f W2) * GELU'(h) from ONE launch, which also leaves the column sums for the fc1 bias gradient
+    (xq_gemm_bf16_nn_gelu_bwd); weight gradients split-K TN; g_a = g_h W1.  The fc2 bias gradient is delivered by the fused
+    residual + LayerNorm backward that produces g_f (same arrangement as LinearFn(bias_grad_external=True))."""
+
+    @staticmethod
+    def forward(ctx, a, w1, b1, w2, b2, tanh):
+        shp = a.shape
+        a2 = a.detach().reshape(-1, shp[-1])
+        if not a2.is_contiguous():
+            a2 = a2.contiguous()
+        W1, W2 = _w16(w1), _w16(w2)
+        M, D = a2.shape
+        Hd = W1.shape[0]
+        h = torch.empty(M, Hd, dtype=torch.bfloat16, device=a2.device)
+        hg = torch.empty_like(h)
+        with torch.cuda.device(a2.device):
+            rc = _lib.lib().xq_gemm_bf16_nt_gelu(ptr(a2), ptr(W1), ptr(b1.detach().float().contiguous()), M, Hd, D, ptr(h), ptr(hg), int(bool(tanh)),
+                                                 _stream(a2))
+        check(rc, "xq_gemm_bf16_nt_gelu")
+        f = gemm_nt(hg, W2, None if b2 is None else b2.detach().float().contiguous())
+        ctx.save_for_backward(a2, W1, W2, h, hg)
+        ctx.meta = (shp, bool(tanh), w1.dtype)
+        return f.view(*shp[:-1], W2.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        a2, W1, W2, h, hg = ctx.saved_tensors
+        shp, tanh, wdtype = ctx.meta
+        g2 = g.reshape(-1, g.shape[-1]).to(torch.bfloat16)
+        if not g2.is_contiguous():
+            g2 = g2.contiguous()
+        M, Hd = h.shape
+        g_h = torch.empty_like(h)
+        rows = _lib.lib().xq_gemm_colpart_rows(M)
+        colpart = torch.empty(rows, Hd, dtype=torch.float32, device=h.device)
+        with torch.cuda.device(h.device):
+            rc = _lib.lib().xq_gemm_bf16_nn_gelu_bwd(ptr(g2), ptr(W2), ptr(h), M, Hd, W2.shape[0], ptr(g_h), ptr(colpart), int(tanh), _stream(h))
+        check(rc, "xq_gemm_bf16_nn_gelu_bwd")
+        g_w2 = gemm_tn(g2, hg).to(wdtype) if ctx.needs_input_grad[3] else None
+        g_b1 = colpart.sum(0) if ctx.needs_input_grad[2] else None
+        g_w1 = gemm_tn(g_h, a2).to(wdtype) if ctx.needs_input_grad[1] else None
+        g_a = gemm_nn(g_h, W1).view(shp) if ctx.needs_input_grad[0] else None
+        return g_a, g_w1, g_b1, g_w2, None, None
+
+
 class AttentionFn(torch.autograd.Function):
     """softmax(q k^T / sqrt(hd)) v on the packed (B, N, 3*H*64) bf16 projection: xq_attn_forward / xq_attn_backward
     (csrc/xq_attn.hip).  Mirrors dino_enc/vision_transformer.py:175-195 (fused_attn branch, attn_drop = 0)."""
@@ -406,9 +466,13 @@ def run_blocks(blocks, x, final_norm, act_dtype, taps=None):
         g1 = ls1.gamma if isinstance(ls1, LayerScale) else None
         m1 = dp1.keep_mask(p) if isinstance(dp1, DropPath) else None
         x, a = ResLNFn.apply(x, p, g1, m1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, at.proj.bias)
-        h = LinearFn.apply(a, blk.mlp.fc1.weight, blk.mlp.fc1.bias, True)
-        hg = GeluFn.apply(h, blk.mlp.fc1.bias, bool(getattr(blk.mlp, "gelu_tanh", False)))
-        f = LinearFn.apply(hg, blk.mlp.fc2.weight, blk.mlp.fc2.bias, True)
+        if mlp_fused_supported(a, blk.mlp):
+            f = MlpFn.apply(a, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias,
+                            bool(getattr(blk.mlp, "gelu_tanh", False)))
+        else:
+            h = LinearFn.apply(a, blk.mlp.fc1.weight, blk.mlp.fc1.bias, True)
+            hg = GeluFn.apply(h, blk.mlp.fc1.bias, bool(getattr(blk.mlp, "gelu_tanh", False)))
+            f = LinearFn.apply(hg, blk.mlp.fc2.weight, blk.mlp.fc2.bias, True)
         g2 = ls2.gamma if isinstance(ls2, LayerScale) else None
         m2 = dp2.keep_mask(f) if isinstance(dp2, DropPath) else None
         nxt = blocks[i + 1].norm1 if i + 1 < n else final_norm

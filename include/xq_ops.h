@@ -293,6 +293,7 @@ int xq_ms_area_pool(const float *in, int B, int C, int H, int W, int pn, float *
                                 cut along K into fp32 slabs (256-column tiles, >= 2 K tiles per item)                       */
 #define XQ_GEMM_WIDE_TILES 0x100 /* OR-ed into impl: 256-column tiles even when N is not a multiple of 256 (ragged last tile) */
 #define XQ_GEMM_DEBUG_NO_STORE 0x200 /* OR-ed into impl (NT, persistent schedule): skip the output stores — timing experiments, result unusable */
+#define XQ_GEMM_PLAIN_STORE 0x800 /* OR-ed into impl (persistent schedule): plain instead of non-temporal output stores (A/B timing) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2
@@ -307,6 +308,17 @@ int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, 
  * transpose reads: no transposed copy of the weights exists).  K % 64 == 0, N % 8 == 0, N >= 32. */
 int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_t K, void *g_x, void *workspace,
                     size_t workspace_bytes, int impl, xq_stream_t stream);
+/* fc1 of the transformer MLP with its GELU in the epilogue (timm Mlp.fc1 -> act, vision_transformer.py:295-339):
+ * h[M][N] = x . w^T + bias (bf16, kept for the backward), h_act[M][N] = GELU(h) evaluated on the bf16-rounded h exactly as the
+ * unfused Linear -> GELU pair does; approximate_tanh selects F.gelu(approximate='tanh').  N >= 256, K >= 128, K % 64 == 0. */
+int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *h, void *h_act,
+                         int approximate_tanh, xq_stream_t stream);
+/* data gradient of fc2 with the GELU derivative in the epilogue: g_h[M][N] = (g_y[M][K] . w[K][N]) * GELU'(h[M][N]) (the product
+ * rounded to bf16 before the multiplication, as the unfused pair does); colpart (nullable) fp32 [xq_gemm_colpart_rows(M)][N]
+ * receives the column sums of g_h per 128-row block: their sum over the rows is the fc1 bias gradient. */
+size_t xq_gemm_colpart_rows(int64_t M);
+int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h, float *colpart,
+                             int approximate_tanh, xq_stream_t stream);
 /* weight gradient: g_w[P][Q] (fp32) = g_y[R][P]^T . x[R][Q], the token axis R split over the chip into fp32 slabs in
  * `workspace` that a second kernel sums in a fixed order (deterministic, no atomics).
  * P, Q multiples of 8 and >= 32; any R >= 0. */

@@ -178,3 +178,37 @@ def test_gemm_wide_tiles_on_ragged_columns(M, N, K, impl):
     a, b = _rand((M, 256), 15), _rand((M, N), 16)
     ref = a.float().t() @ b.float()
     assert ((gw - ref).abs() <= a.float().abs().t() @ b.float().abs() * 4e-6 + 1e-30).all()
+
+
+@pytest.mark.parametrize("tanh", [False, True])
+@pytest.mark.parametrize("B,N,D,Hd", [(2, 513, 768, 3072), (3, 197, 384, 1536), (1, 300, 256, 512)])
+def test_fused_mlp_equals_the_unfused_functions(B, N, D, Hd, tanh):
+    """MlpFn (GELU in the GEMM epilogues) vs LinearFn -> GeluFn -> LinearFn on the same GEMM kernels: the activation is
+    evaluated on the same bf16-rounded values by the same device function, so outputs and gradients must agree to the
+    summation order of the split weight gradients / bias column sums."""
+    od = _ops()
+    torch.manual_seed(1)
+    a = torch.randn(B, N, D, device="cuda").to(torch.bfloat16).requires_grad_(True)
+    w1 = (torch.randn(Hd, D, device="cuda") * 0.05).requires_grad_(True)
+    b1 = (torch.randn(Hd, device="cuda") * 0.1).requires_grad_(True)
+    w2 = (torch.randn(D, Hd, device="cuda") * 0.03).requires_grad_(True)
+    b2 = (torch.randn(D, device="cuda") * 0.1).requires_grad_(True)
+    go = torch.randn(B, N, D, device="cuda").to(torch.bfloat16)
+
+    def run(fused):
+        for t in (a, w1, b1, w2, b2):
+            t.grad = None
+        if fused:
+            f = od.MlpFn.apply(a, w1, b1, w2, b2, tanh)
+        else:
+            h = od.LinearFn.apply(a, w1, b1, True)
+            hg = od.GeluFn.apply(h, b1, tanh)
+            f = od.LinearFn.apply(hg, w2, b2, True)
+        f.backward(go)
+        return [f.detach().float(), a.grad.float(), w1.grad.float(), b1.grad.float(), w2.grad.float()]
+    fu, un = run(True), run(False)
+    assert torch.equal(fu[0], un[0]), "forward differs"
+    assert torch.equal(fu[1], un[1]), "g_a differs"
+    for x, y, name in zip(fu[2:], un[2:], ("g_w1", "g_b1", "g_w2")):
+        scale = y.abs().max().item()
+        assert (x - y).abs().max().item() <= 2e-5 * scale, f"{name}: {(x - y).abs().max().item()} vs scale {scale}"
