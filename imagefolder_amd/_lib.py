@@ -76,6 +76,12 @@ SIGNATURES = {
     "xq_ms_upsample": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_ms_phi_accumulate": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float, vp, vp]),
     "xq_ms_area_pool": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv2d_f32_pack_weights": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv2d_f32_nhwc": (ctypes.c_int, [vp, vp, vp] + [ctypes.c_int] * 13 + [vp, vp]),
+    "xq_attention_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                        ctypes.c_float, vp, vp]),
+    "xq_groupnorm_silu_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,
+                                             vp, vp]),
     "xq_gemm_bf16_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64]),
     "xq_gemm_bf16_nt": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_size_t, ctypes.c_int, vp]),
     "xq_gemm_bf16_nn": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_size_t, ctypes.c_int, vp]),

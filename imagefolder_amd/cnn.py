@@ -65,11 +65,7 @@ class AttnBlock(nn.Module):
     def forward(self, x):
         h = _norm_act(self.norm, x, silu=False)
         b, c, hh, ww = h.shape
-        q = _conv(self.q, h).reshape(b, c, hh * ww).permute(0, 2, 1)     # b, hw, c
-        k = _conv(self.k, h).reshape(b, c, hh * ww)                      # b, c, hw
-        v = _conv(self.v, h).reshape(b, c, hh * ww)
-        w_ = F.softmax(torch.bmm(q, k) * (int(c) ** (-0.5)), dim=2)      # b, hw(q), hw(k)
-        h = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+        h = nn_ops.spatial_attention(_conv(self.q, h), _conv(self.k, h), _conv(self.v, h))
         return x + _conv(self.proj_out, h)
 
 
@@ -81,8 +77,9 @@ class Upsample(nn.Module):
             self.conv = nn.Conv2d(in_channels, in_channels, 3, 1, 1)
 
     def forward(self, x):
-        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-        return _conv(self.conv, x) if self.with_conv else x
+        if self.with_conv:
+            return nn_ops.conv2d_upsample(x, self.conv.weight, self.conv.bias)
+        return F.interpolate(x, scale_factor=2.0, mode="nearest")
 
 
 class Downsample(nn.Module):
@@ -94,7 +91,7 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         if self.with_conv:
-            return _conv(self.conv, F.pad(x, (0, 1, 0, 1), mode="constant", value=0))
+            return nn_ops.conv2d_downsample(x, self.conv.weight, self.conv.bias)
         return F.avg_pool2d(x, kernel_size=2, stride=2)
 
 

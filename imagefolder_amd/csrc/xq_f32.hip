@@ -1,0 +1,228 @@
+// xq_f32.hip — fp32 forward kernels of the encoder / decoder layers: the REFERENCE-PARITY path (inference, no autograd).
+//
+// BASELINE.json asks for reconstructions within 1e-4 (fp32) of the reference CPU path.  The training kernels compute in bf16
+// (as the reference does under autocast) and cannot sit on that path; these do: every matrix product is an exact fp32 fma
+// chain on v_mfma_f32_32x32x2_f32 (1/16 of the bf16 MFMA rate — irrelevant at the batch sizes parity is checked at), norms
+// and softmax use IEEE expf / sqrtf / division.  With them tests/test_model_parity.py runs the whole tokenizer on hand-written
+// kernels end to end.
+//   conv2d_f32_kernel    : implicit-GEMM convolution, NHWC, kernel 1x1 / 3x3, stride 1 / 2, explicit top/left padding (bottom /
+//                          right implied by the output size: the (0,1,0,1) pad of Downsample, xqgan_model.py:697-704), optional
+//                          nearest-2x upsampling of the input folded into the gather (Upsample, :682-686), any channel counts
+//                          (conv_in 3 -> 128, conv_out 128 -> 3); with H = W = 1 it is nn.Linear (ViT blocks, patch embedding).
+//   attention_f32_kernel : softmax(q k^T * scale) v for one (batch, head, query) per wave — the ViT's SDPA
+//                          (vision_transformer.py:175-195) and the CNN AttnBlock (xqgan_model.py:635-659, one head of C dims).
+//   groupnorm_silu_f32   : GroupNorm(32, eps 1e-6) [+ x * sigmoid(x)] (xqgan_model.py:662-672), two-pass statistics in double.
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "../../include/xq_ops.h"
+
+using namespace xq;
+
+namespace {
+
+struct ConvF32 {
+    const float *X, *Wp, *bias;
+    float *Y;
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad_t, pad_l, up;   // up = 1: the conv sees the 2x nearest-upsampled input
+    long M;        // B * Ho * Wo
+    int K;         // KH * KW * Cin
+};
+
+// 64 output pixels x 64 output channels per block, 4 waves of 32 x 32, K step 16
+__global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32 p) {
+    __shared__ float As[64][17], Bs[64][17];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const long m0 = (long)blockIdx.x * 64;
+    const int n0 = blockIdx.y * 64;
+    const int Hl = p.up ? 2 * p.Hi : p.Hi, Wl = p.up ? 2 * p.Wi : p.Wi;     // logical input size
+
+    // staging: thread -> row r = tid / 4, k offsets (tid % 4) * 4 .. + 3
+    const int r = tid >> 2, kq = (tid & 3) * 4;
+    const long m = m0 + r;
+    const bool mok = m < p.M;
+    const long mm = mok ? m : 0;
+    const int ox = (int)(mm % p.Wo), oy = (int)((mm / p.Wo) % p.Ho);
+    const long b = mm / ((long)p.Wo * p.Ho);
+    const int n = n0 + r;
+    const bool nok = n < p.Cout;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+
+    for (int k0 = 0; k0 < p.K; k0 += 16) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + kq + j;
+            float a = 0.0f, w = 0.0f;
+            if (k < p.K) {
+                const int tap = k / p.Cin, c = k - tap * p.Cin;
+                const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                const int yy = oy * p.stride + ky - p.pad_t, xx = ox * p.stride + kx - p.pad_l;
+                if (mok && yy >= 0 && yy < Hl && xx >= 0 && xx < Wl)
+                    a = p.X[((b * p.Hi + (p.up ? yy >> 1 : yy)) * p.Wi + (p.up ? xx >> 1 : xx)) * p.Cin + c];
+                if (nok) w = p.Wp[(long)n * p.K + k];
+            }
+            As[r][kq + j] = a;
+            Bs[r][kq + j] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float a = As[wm * 32 + (lane & 31)][kk + (lane >> 5)];
+            const float w = Bs[wn * 32 + (lane & 31)][kk + (lane >> 5)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[i = pixel][j = channel]: j = lane & 31, i = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int co = n0 + wn * 32 + (lane & 31);
+    if (co < p.Cout) {
+        const float bv = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const long mo = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            if (mo < p.M) p.Y[mo * p.Cout + co] = acc[q] + bv;
+        }
+    }
+}
+
+// one wave per (batch b, head h, query i): scores over all keys, softmax, weighted sum of the values.
+// q / k / v: element offset of (b, token, head) = b * batch_stride + token * tok_stride + h * hd; out row = (b * N + i) * (H * hd) + h * hd
+__global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                            int B, int N, int H, int hd, long batch_stride, long tok_stride, float scale,
+                                                            float *__restrict__ out) {
+    extern __shared__ float sm[];          // [4 waves][hd + N]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long item = (long)blockIdx.x * 4 + wave;            // (b, h, i) flattened, i fastest
+    if (item >= (long)B * H * N) return;                       // whole wave exits together (no block barrier below)
+    float *qs = sm + (size_t)wave * (hd + N), *ps = qs + hd;
+    const int i = (int)(item % N), h = (int)((item / N) % H);
+    const long b = item / ((long)N * H);
+    const float *qp = q + b * batch_stride + (long)i * tok_stride + (long)h * hd;
+    for (int d = lane; d < hd; d += 64) qs[d] = qp[d];
+    __builtin_amdgcn_wave_barrier();
+    // scores
+    float mx = -__builtin_inff();
+    for (int j = lane; j < N; j += 64) {
+        const float *kp = k + b * batch_stride + (long)j * tok_stride + (long)h * hd;
+        float s = 0.0f;
+        for (int d = 0; d < hd; ++d) s = __builtin_fmaf(qs[d], kp[d], s);
+        s *= scale;
+        ps[j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+    for (int j = lane; j < N; j += 64) {
+        const float e = expf(ps[j] - mx);
+        ps[j] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    __builtin_amdgcn_wave_barrier();
+    const float inv = 1.0f / sum;
+    float *op = out + ((b * N + i) * (long)H + h) * hd;
+    for (int d = lane; d < hd; d += 64) {
+        float o = 0.0f;
+        const float *vp = v + b * batch_stride + (long)h * hd + d;
+        for (int j = 0; j < N; ++j) o = __builtin_fmaf(ps[j] * inv, vp[(long)j * tok_stride], o);
+        op[d] = o;
+    }
+}
+
+// one block per (sample, group): x [B][HW][C] -> y, statistics in double
+__global__ __launch_bounds__(256) void groupnorm_silu_f32_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
+                                                                 int HW, int C, int G, float eps, int silu, float *__restrict__ y) {
+    __shared__ double red[256];
+    const int b = blockIdx.y, g = blockIdx.x, cg = C / G;
+    const float *xb = x + (long)b * HW * C + g * cg;
+    float *yb = y + (long)b * HW * C + g * cg;
+    const long n = (long)HW * cg;
+    double s = 0.0;
+    for (long e = threadIdx.x; e < n; e += 256) s += (double)xb[(e / cg) * C + (e % cg)];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const double mean = red[0] / (double)n;
+    __syncthreads();
+    s = 0.0;
+    for (long e = threadIdx.x; e < n; e += 256) { const double d = (double)xb[(e / cg) * C + (e % cg)] - mean; s += d * d; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+    const float rstd = (float)(1.0 / sqrt(red[0] / (double)n + (double)eps));
+    const float mu = (float)mean;
+    for (long e = threadIdx.x; e < n; e += 256) {
+        const int c = (int)(e % cg);
+        const long o = (e / cg) * C + c;
+        float pre = (xb[o] - mu) * rstd;
+        pre = pre * (w ? w[g * cg + c] : 1.0f) + (bias ? bias[g * cg + c] : 0.0f);
+        yb[o] = silu ? pre / (1.0f + expf(-pre)) : pre;
+    }
+}
+
+__global__ __launch_bounds__(256) void pack_conv_weights_f32_kernel(const float *__restrict__ W, int Cout, int Cin, int KH, int KW,
+                                                                    float *__restrict__ Wp) {
+    const long o = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)Cout * Cin * KH * KW;
+    if (o >= total) return;
+    // Wp[n][(ky * KW + kx) * Cin + c] = W[n][c][ky][kx]
+    const int c = (int)(o % Cin);
+    const int tap = (int)((o / Cin) % (KH * KW));
+    const long n = o / ((long)Cin * KH * KW);
+    Wp[o] = W[((n * Cin + c) * KH + tap / KW) * KW + tap % KW];
+}
+
+}  // namespace
+
+extern "C" int xq_conv2d_f32_pack_weights(const float *w_oihw, int Cout, int Cin, int KH, int KW, float *w_packed, xq_stream_t stream) {
+    const char *fn = "xq_conv2d_f32_pack_weights";
+    if (Cout < 1 || Cin < 1 || KH < 1 || KW < 1 || !w_oihw || !w_packed) return xq_set_error(XQ_EINVAL, "%s: bad argument", fn);
+    const long total = (long)Cout * Cin * KH * KW;
+    hipLaunchKernelGGL(pack_conv_weights_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w_oihw, Cout, Cin, KH,
+                       KW, w_packed);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_conv2d_f32_nhwc(const float *x, const float *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int KH,
+                                  int KW, int stride, int pad_top, int pad_left, int Ho, int Wo, int upsample2x, float *y, xq_stream_t stream) {
+    const char *fn = "xq_conv2d_f32_nhwc";
+    if (B < 0 || Hi < 1 || Wi < 1 || Cin < 1 || Cout < 1 || Ho < 1 || Wo < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (!((KH == 1 && KW == 1) || (KH == 3 && KW == 3)) || (stride != 1 && stride != 2) || pad_top < 0 || pad_left < 0)
+        return xq_set_error(XQ_EINVAL, "%s: kernel 1x1 / 3x3, stride 1 / 2 only", fn);
+    if (B == 0) return XQ_OK;
+    if (!x || !w_packed || !y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    ConvF32 p{x, w_packed, bias, y, B, Hi, Wi, Cin, Ho, Wo, Cout, KH, KW, stride, pad_top, pad_left, upsample2x ? 1 : 0, (long)B * Ho * Wo,
+              KH * KW * Cin};
+    const long gx = (p.M + 63) / 64;
+    if (gx > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: too many pixels", fn);
+    hipLaunchKernelGGL(conv2d_f32_kernel, dim3((unsigned)gx, (unsigned)((Cout + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_attention_f32(const float *q, const float *k, const float *v, int B, int N, int H, int hd, int64_t batch_stride,
+                                int64_t token_stride, float scale, float *out, xq_stream_t stream) {
+    const char *fn = "xq_attention_f32";
+    if (B < 0 || N < 1 || H < 1 || hd < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (B == 0) return XQ_OK;
+    if (!q || !k || !v || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const size_t lds = (size_t)4 * (hd + N) * sizeof(float);
+    if (lds > 64 * 1024) return xq_set_error(XQ_EINVAL, "%s: hd + N = %ld exceeds the 4096-float LDS row", fn, (long)(hd + N));
+    const long items = (long)B * H * N;
+    hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, q, k, v, B, N, H, hd,
+                       (long)batch_stride, (long)token_stride, scale, out);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int B, int HW, int C, int G, float eps, int silu, float *y,
+                                     xq_stream_t stream) {
+    const char *fn = "xq_groupnorm_silu_f32";
+    if (B < 0 || HW < 1 || C < 1 || G < 1 || C % G) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (B == 0) return XQ_OK;
+    if (!x || !y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(groupnorm_silu_f32_kernel, dim3(G, B), dim3(256), 0, (hipStream_t)stream, x, w, bias, HW, C, G, eps, silu, y);
+    return xq_check_launch(fn);
+}

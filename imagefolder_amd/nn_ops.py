@@ -50,6 +50,10 @@ def layer_norm(x, weight, bias, eps):
 
 
 def linear(x, weight, bias=None):
+    from . import ops_f32
+    if ops_f32.eligible(x, weight, bias) and x.numel():
+        IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"
+        return ops_f32.linear(x, weight, bias)
     return F.linear(x, weight, bias)
 
 
@@ -60,10 +64,13 @@ def linear_gelu(x, weight, bias=None):
 def attention_qkvpacked(qkv, num_heads):
     """qkv: (B, N, 3*C) packed as [3][heads][head_dim] -> (B, N, C); softmax(q k^T / sqrt(d)) v, no mask, no dropout."""
     if qkv.is_cuda:
-        from . import ops_dense
+        from . import ops_dense, ops_f32
         if ops_dense.attention_supported(qkv, num_heads):
             IMPL["attention"] = "hip"
             return ops_dense.AttentionFn.apply(qkv, num_heads)
+        if ops_f32.eligible(qkv):
+            IMPL["attention_fp32_inference"] = "hip (xq_attention_f32)"
+            return ops_f32.attention_qkvpacked(qkv, num_heads)
     B, N, C3 = qkv.shape
     C = C3 // 3
     q, k, v = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)
@@ -100,10 +107,13 @@ def conv1x1(x, weight, bias=None):
 def group_norm_silu(x, groups, weight, bias, eps, silu=True):
     """GroupNorm [+ x * sigmoid(x)]: hand-written NHWC bf16 kernels (csrc/xq_gn.hip) under bf16 autocast on the GPU."""
     if x.is_cuda:
-        from . import ops_dense
+        from . import ops_dense, ops_f32
         if ops_dense.groupnorm_supported(x, groups):
             IMPL["group_norm_silu"] = "hip"
             return ops_dense.GroupNormSiluFn.apply(x, groups, weight, bias, eps, silu)
+        if x.dim() == 4 and ops_f32.eligible(x, weight, bias):
+            IMPL["group_norm_silu_fp32_inference"] = "hip (xq_groupnorm_silu_f32)"
+            return ops_f32.group_norm_silu(x, groups, weight, bias, eps, silu)
     y = F.group_norm(x, groups, weight, bias, eps)
     return y * torch.sigmoid(y) if silu else y
 
@@ -115,7 +125,14 @@ CHANNELS_LAST = True
 
 def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
     """conv2d [+ ReLU].  3x3 / stride 1 / pad 1 convs with 64-multiple channel counts run on the hand-written
-    implicit-GEMM kernel (csrc/xq_conv.hip) when activations are bf16 (autocast); everything else is the library conv."""
+    implicit-GEMM kernel (csrc/xq_conv.hip) when activations are bf16 (autocast); fp32 inference runs on the fp32-MFMA
+    kernel (csrc/xq_f32.hip); everything else is the library conv."""
+    if x.is_cuda and tuple(weight.shape[2:]) in ((1, 1), (3, 3)) and stride in (1, 2):
+        from . import ops_f32
+        if ops_f32.eligible(x, weight, bias):
+            IMPL["conv2d_fp32_inference"] = "hip (xq_conv2d_f32_nhwc: fp32 MFMA implicit GEMM)"
+            y = ops_f32.conv2d(x, weight, bias, stride=stride, padding=padding)
+            return torch.relu(y) if relu else y
     if x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled("cuda")):
         from . import ops_dense
         if ops_dense.conv3x3_supported(x, weight, stride, padding):
@@ -141,3 +158,33 @@ def _conv2d_library(x, weight, bias, stride=1, padding=0):
     if CHANNELS_LAST and x.is_cuda and x.dim() == 4 and weight.shape[-1] > 1:
         x = x.contiguous(memory_format=torch.channels_last)
     return F.conv2d(x, weight, bias, stride=stride, padding=padding)
+
+
+def conv2d_downsample(x, weight, bias):
+    """Downsample.conv (xqgan_model.py:697-704): zero-pad one row / column after the last (F.pad(x, (0, 1, 0, 1))), 3x3 conv, stride 2."""
+    from . import ops_f32
+    if x.is_cuda and ops_f32.eligible(x, weight, bias):
+        IMPL["conv2d_fp32_inference"] = "hip (xq_conv2d_f32_nhwc: fp32 MFMA implicit GEMM)"
+        return ops_f32.conv2d(x, weight, bias, stride=2, padding=0, pad_br=1)
+    return conv2d(F.pad(x, (0, 1, 0, 1), mode="constant", value=0), weight, bias, stride=2, padding=0)
+
+
+def conv2d_upsample(x, weight, bias):
+    """Upsample (xqgan_model.py:682-686): nearest 2x, then 3x3 conv, pad 1 — the upsampled map is never written on the fp32 path."""
+    from . import ops_f32
+    if x.is_cuda and ops_f32.eligible(x, weight, bias):
+        IMPL["conv2d_fp32_inference"] = "hip (xq_conv2d_f32_nhwc: fp32 MFMA implicit GEMM)"
+        return ops_f32.conv2d(x, weight, bias, stride=1, padding=1, upsample=True)
+    return conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), weight, bias, stride=1, padding=1)
+
+
+def spatial_attention(q, k, v):
+    """single-head attention over the H*W positions of a feature map (AttnBlock, xqgan_model.py:646-656)"""
+    from . import ops_f32
+    if q.is_cuda and ops_f32.eligible(q, k, v):
+        IMPL["spatial_attention_fp32_inference"] = "hip (xq_attention_f32)"
+        return ops_f32.spatial_attention(q, k, v)
+    b, c, hh, ww = q.shape
+    qq = q.reshape(b, c, hh * ww).permute(0, 2, 1)
+    w_ = F.softmax(torch.bmm(qq, k.reshape(b, c, hh * ww)) * (int(c) ** (-0.5)), dim=2)
+    return torch.bmm(v.reshape(b, c, hh * ww), w_.permute(0, 2, 1)).reshape(b, c, hh, ww)

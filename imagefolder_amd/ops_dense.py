@@ -286,6 +286,11 @@ class LinearFn(torch.autograd.Function):
         else:
             W = weight.detach()
             b = None if bias is None else bias.detach()
+            from . import ops_f32
+            if x2.is_cuda and x2.dtype == torch.float32 and not any(ctx.needs_input_grad) and not torch.is_autocast_enabled("cuda") and x2.numel():
+                # fp32 inference (the reference-parity path): exact fp32 MFMA product, no library call
+                nn_ops.IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"
+                return ops_f32.linear(x2, W, b).view(*shp[:-1], W.shape[0])
         if not hip:
             y = torch.addmm(b, x2, W.t()) if b is not None else torch.mm(x2, W.t())
         ctx.save_for_backward(x2, W)

@@ -1,0 +1,128 @@
+"""fp32 forward ops of the encoder / decoder on the hand-written kernels of csrc/xq_f32.hip: the reference-parity path.
+
+BASELINE.json: reconstructions within 1e-4 (fp32) of the reference CPU path.  nn_ops routes here when the activations are
+fp32 CUDA tensors outside autocast and nothing needs a gradient (inference: img_to_reconstructed_img, img_to_idx, the
+model-level parity tests); training runs the bf16 kernels.  No autograd, no CPU fallback."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def eligible(*tensors):
+    """fp32 CUDA tensors, autocast off, no gradient wanted"""
+    if torch.is_autocast_enabled("cuda"):
+        return False
+    for t in tensors:
+        if t is None:
+            continue
+        if not (t.is_cuda and t.dtype == torch.float32):
+            return False
+        if torch.is_grad_enabled() and t.requires_grad:
+            return False
+    return True
+
+
+def _nhwc(x):
+    """(B, C, H, W) logical tensor -> contiguous [B][H][W][C] buffer (free for channels_last inputs)"""
+    return x.detach().permute(0, 2, 3, 1).contiguous()
+
+
+def _packed(weight):
+    """[Cout][KH*KW*Cin] fp32 pack of a conv weight, cached on the parameter (refreshed when it changes)"""
+    arena = getattr(weight, "_xq_arena", None)
+    stamp = (weight._version, -1 if arena is None else arena.epoch)
+    cache = getattr(weight, "_xq_pack_f32", None)
+    if cache is not None and cache[0] == stamp and cache[1].device == weight.device:
+        return cache[1]
+    Cout, Cin, KH, KW = weight.shape
+    w = weight.detach().float().contiguous()
+    if KH == 1 and KW == 1:
+        wp = w.reshape(Cout, Cin)
+    else:
+        wp = torch.empty(Cout, KH * KW * Cin, dtype=torch.float32, device=w.device)
+        with torch.cuda.device(w.device):
+            rc = _lib.lib().xq_conv2d_f32_pack_weights(ptr(w), Cout, Cin, KH, KW, ptr(wp), _stream(w))
+        check(rc, "xq_conv2d_f32_pack_weights")
+    weight._xq_pack_f32 = (stamp, wp)
+    return wp
+
+
+def conv2d(x, weight, bias, stride=1, padding=0, pad_br=None, upsample=False):
+    """Conv2d(kernel 1 / 3, stride 1 / 2) on an NCHW-logical fp32 tensor; returns an NCHW-logical (channels_last strided) tensor.
+    pad_br: zeros after the last row / column (default = padding); upsample: conv over the nearest-2x upsampled input."""
+    B, Cin, Hi, Wi = x.shape
+    Cout, _, KH, KW = weight.shape
+    pad_br = padding if pad_br is None else pad_br
+    Hl, Wl = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
+    Ho = (Hl + padding + pad_br - KH) // stride + 1
+    Wo = (Wl + padding + pad_br - KW) // stride + 1
+    xh = _nhwc(x)
+    y = torch.empty(B, Ho, Wo, Cout, dtype=torch.float32, device=x.device)
+    b = None if bias is None else bias.detach().float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().xq_conv2d_f32_nhwc(ptr(xh), ptr(_packed(weight)), ptr(b), B, Hi, Wi, Cin, Cout, KH, KW, stride, padding, padding, Ho, Wo,
+                                           int(bool(upsample)), ptr(y), _stream(x))
+    check(rc, "xq_conv2d_f32_nhwc")
+    return y.permute(0, 3, 1, 2)
+
+
+def linear(x, weight, bias=None):
+    """x (..., K) @ weight[N][K]^T + bias on the same kernel (a 1 x 1 convolution over `rows` pixels)"""
+    shp = x.shape
+    x2 = x.detach().reshape(-1, shp[-1]).contiguous()
+    M, K = x2.shape
+    N = weight.shape[0]
+    w = weight.detach().float().reshape(N, K).contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    if M:
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().xq_conv2d_f32_nhwc(ptr(x2), ptr(w), ptr(b), 1, M, 1, K, N, 1, 1, 1, 0, 0, M, 1, 0, ptr(y), _stream(x))
+        check(rc, "xq_conv2d_f32_nhwc")
+    return y.view(*shp[:-1], N)
+
+
+def attention_qkvpacked(qkv, num_heads):
+    """(B, N, 3*C) packed [3][heads][hd] -> (B, N, C)"""
+    B, N, C3 = qkv.shape
+    C = C3 // 3
+    hd = C // num_heads
+    q = qkv.detach().contiguous()
+    out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+    base = q.data_ptr()
+    with torch.cuda.device(q.device):
+        rc = _lib.lib().xq_attention_f32(ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * C), ctypes.c_void_p(base + 8 * C), B, N, num_heads, hd,
+                                         N * C3, C3, ctypes.c_float(float(hd) ** -0.5), ptr(out), _stream(q))
+    check(rc, "xq_attention_f32")
+    return out
+
+
+def spatial_attention(q, k, v):
+    """single-head attention over the H*W positions (CNN AttnBlock, xqgan_model.py:646-656): q, k, v (B, C, H, W) -> (B, C, H, W)"""
+    B, C, H, W = q.shape
+    qh, kh, vh = _nhwc(q), _nhwc(k), _nhwc(v)
+    out = torch.empty(B, H, W, C, dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        rc = _lib.lib().xq_attention_f32(ptr(qh), ptr(kh), ptr(vh), B, H * W, 1, C, H * W * C, C, ctypes.c_float(int(C) ** (-0.5)), ptr(out),
+                                         _stream(q))
+    check(rc, "xq_attention_f32")
+    return out.permute(0, 3, 1, 2)
+
+
+def group_norm_silu(x, groups, weight, bias, eps, silu=True):
+    B, C, H, W = x.shape
+    xh = _nhwc(x)
+    y = torch.empty_like(xh)
+    w = None if weight is None else weight.detach().float().contiguous()
+    b = None if bias is None else bias.detach().float().contiguous()
+    with torch.cuda.device(x.device):
+        rc = _lib.lib().xq_groupnorm_silu_f32(ptr(xh), ptr(w), ptr(b), B, H * W, C, groups, ctypes.c_float(eps), int(bool(silu)), ptr(y), _stream(x))
+    check(rc, "xq_groupnorm_silu_f32")
+    return y.permute(0, 3, 1, 2)

@@ -282,6 +282,25 @@ int xq_ms_phi_accumulate(const float *u, int B, int C, int H, int W, const float
 /* out[B][C][pn][pn] = F.interpolate(in [B][C][H][W], (pn, pn), mode='area') */
 int xq_ms_area_pool(const float *in, int B, int C, int H, int W, int pn, float *out, xq_stream_t stream);
 
+/* ---- fp32 forward kernels of the encoder / decoder layers: the reference-parity path (csrc/xq_f32.hip).  Exact fp32 fma chains
+ *      on v_mfma_f32_32x32x2_f32, IEEE expf / sqrt / division; inference only (no backward).  Activations NHWC fp32. ---------- */
+/* w_packed[n][(ky * KW + kx) * Cin + c] = w_oihw[n][c][ky][kx] */
+int xq_conv2d_f32_pack_weights(const float *w_oihw, int Cout, int Cin, int KH, int KW, float *w_packed, xq_stream_t stream);
+/* y[B][Ho][Wo][Cout] = conv(x[B][Hi][Wi][Cin]) (+ bias): kernel 1x1 or 3x3, stride 1 or 2, pad_top / pad_left zeros before the
+ * first row / column, as many zero rows / columns after the last as (Ho, Wo) imply (Conv2d padding p: pad_top = pad_left = p;
+ * Downsample, xqgan_model.py:697-704: pads 0 and Ho = Hi / 2); upsample2x = 1: the conv sees the nearest-neighbour 2x upsampling
+ * of x (Upsample, :682-686) without it being materialised.  Hi = Wi = Ho = Wo = 1, B = rows: y = x . w^T + b (nn.Linear). */
+int xq_conv2d_f32_nhwc(const float *x, const float *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
+                       int stride, int pad_top, int pad_left, int Ho, int Wo, int upsample2x, float *y, xq_stream_t stream);
+/* out[b][i][h][:] = sum_j softmax_j(q_i . k_j * scale) v_j per (batch, head); element (b, token t, head h, d) of q / k / v lives at
+ * b * batch_stride + t * token_stride + h * hd + d (ViT packed qkv: three pointers into one [B][N][3][H][hd] buffer;
+ * CNN AttnBlock, xqgan_model.py:635-659: H = 1, hd = C); out is [B][N][H][hd] contiguous. */
+int xq_attention_f32(const float *q, const float *k, const float *v, int B, int N, int H, int hd, int64_t batch_stride,
+                     int64_t token_stride, float scale, float *out, xq_stream_t stream);
+/* y = [silu](GroupNorm(x)) on x [B][HW][C] fp32, G groups, statistics accumulated in double (xqgan_model.py:662-672) */
+int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int B, int HW, int C, int G, float eps, int silu, float *y,
+                          xq_stream_t stream);
+
 /* ---- bf16 GEMMs of the transformer blocks (csrc/xq_gemm.hip; replaces the cuBLAS / hipBLASLt calls behind nn.Linear:
  *      dino_enc/vision_transformer.py:145-197 Attention.qkv / proj, :295-339 Block -> Mlp.fc1 / fc2, :684-692 patch embedding,
  *      dino_enc/to_pixel.py:70-86).  bf16 operands, fp32 accumulation on v_mfma_f32_32x32x16_bf16, one rounding to bf16.
