@@ -84,6 +84,10 @@ class Mlp(nn.Module):
 class DropPath(nn.Module):
     """Stochastic depth per sample (timm DropPath, scale_by_keep=True)."""
 
+    # parity tests (SURVEY §7 "pass RNG draws as tensors"): when REPLAY is a list, keep_mask pops the recorded (already scaled)
+    # masks of a reference run instead of drawing from the device generator
+    REPLAY = None
+
     def __init__(self, drop_prob: float = 0.):
         super().__init__()
         self.drop_prob = drop_prob
@@ -93,6 +97,8 @@ class DropPath(nn.Module):
             return None
         keep_prob = 1 - self.drop_prob
         shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+        if DropPath.REPLAY is not None:
+            return DropPath.REPLAY.pop(0).to(device=x.device, dtype=torch.float32).reshape(shape)
         # fp32 like upstream, where the masked tensor is the fp32 LayerScale output under autocast
         m = torch.empty(shape, dtype=torch.float32, device=x.device).bernoulli_(keep_prob)
         if keep_prob > 0.0:

@@ -432,10 +432,13 @@ def attention_supported(qkv, num_heads):
 def attention_qkvpacked(qkv, num_heads):
     """(B, N, 3*C) -> (B, N, C).  bf16 with head_dim 64: the hand-written kernels on the packed projection; anything else
     (the fp32 parity path): library SDPA on strided q/k/v views."""
-    from . import nn_ops
+    from . import nn_ops, ops_f32
     if attention_supported(qkv, num_heads):
         nn_ops.IMPL["attention"] = "hip"
         return AttentionFn.apply(qkv, num_heads)
+    if qkv.is_cuda and ops_f32.eligible(qkv):
+        nn_ops.IMPL["attention_fp32_inference"] = "hip (xq_attention_f32)"
+        return ops_f32.attention_qkvpacked(qkv, num_heads)
     nn_ops.IMPL["attention"] = "library (SDPA)"
     B, N, C3 = qkv.shape
     C = C3 // 3

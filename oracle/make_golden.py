@@ -216,6 +216,96 @@ def gen_model(name, kw, seed):
     print("wrote", name, "rec range", float(rec.min()), float(rec.max()), "distinct codes", len(set(idx.tolist())))
 
 
+TRAIN_COMMON = dict(enc_type="dinov2", dec_type="dinov2", semantic_guide="dinov2", detail_guide="none", abs_pos_embed=True,
+                    encoder_model="vit_base_patch14_dinov2.lvd142m", decoder_model="vit_base_patch14_dinov2.lvd142m",
+                    share_quant_resi=4, start_drop=3, sem_loss_weight=0.1, guide_type_1="class")
+# the four ViT-B configs of BASELINE.json (configs[1..4]) as xqgan_train.py:285-313 builds them from the yamls
+TRAIN_CASES = {
+    "train_fwd_cfg2_vq8192": (dict(codebook_size=8192, codebook_embed_dim=32, v_patch_nums=[16], num_latent_tokens=256, product_quant=1,
+                                   codebook_drop=0.0, half_sem=False), 4, 0.0, 0.0, 100),
+    "train_fwd_cfg3_vp2_16384": (dict(codebook_size=16384, codebook_embed_dim=32, v_patch_nums=[16], num_latent_tokens=256, product_quant=2,
+                                      codebook_drop=0.1, half_sem=True), 10, 0.0, 0.0, 100),
+    "train_fwd_cfg4_msvr10p2_4096": (dict(codebook_size=4096, codebook_embed_dim=32, v_patch_nums=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11],
+                                          num_latent_tokens=121, product_quant=2, codebook_drop=0.1, half_sem=True), 10, 0.0, 0.0, 100),
+    "train_fwd_cfg5_robusttok": (dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], num_latent_tokens=256, product_quant=1,
+                                      codebook_drop=0.0, half_sem=False), 10, 0.5, 0.1, 100),
+}
+
+
+def gen_train_forward(name, kw, B, alpha, beta, delta, seed):
+    """VQModel.forward in train() mode (xqgan_model.py:268-365): decoder output, codebook losses, usages, semantic loss, with
+    every random draw of the pass recorded — DropPath masks (vision_transformer.py:713 rates, timm DropPath), the quantizer
+    dropout depths (:274), the two draws of add_perturbation (latent_perturbation.py:21-22) — so that the mirror can replay them."""
+    from oracle.det_init import det_state_dict
+    from oracle import timm_shim
+    import contextlib, io
+    R = load_reference()
+    torch.manual_seed(seed)
+    m = R["VQ_models"]["VQ-16"](**dict(TRAIN_COMMON, **kw)).train()
+    m.load_state_dict(det_state_dict(m.state_dict(), seed))
+    x = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(4321 + seed)) * 2 - 1
+    draws = {"rand": [], "randint": []}
+    real_rand, real_randint = torch.rand, torch.randint
+
+    def rec_rand(*a, **k):
+        t = real_rand(*a, **k)
+        draws["rand"].append(t.detach().cpu().clone())
+        return t
+
+    def rec_randint(*a, **k):
+        t = real_randint(*a, **k)
+        draws["randint"].append((tuple(int(v) for v in a[:2] if isinstance(v, int)), t.detach().cpu().clone()))
+        return t
+    timm_shim.DropPath.RECORD = []
+    torch.manual_seed(seed + 17)
+    torch.rand, torch.randint = rec_rand, rec_randint
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):          # the forward prints (alpha, beta, delta) every call (:296)
+            dec, (vq, commit, ent, usages), sem, detail, dep = m(x, 0, alpha, beta, delta)
+    finally:
+        torch.rand, torch.randint = real_rand, real_randint
+        masks = timm_shim.DropPath.RECORD
+        timm_shim.DropPath.RECORD = None
+    P, SN = kw["product_quant"], len(kw["v_patch_nums"])
+    N = B * kw["num_latent_tokens"]
+    dropout_rand = [t for (_, t) in draws["randint"] if tuple(t.shape) == (B,)]
+    lp_prob = [t for t in draws["rand"] if tuple(t.shape) == (N,)]
+    lp_idx = [t for (_, t) in draws["randint"] if tuple(t.shape) == (N,)]
+    assert len(dropout_rand) == (1 if SN > 1 else 0), (len(dropout_rand), SN)
+    assert len(lp_prob) == len(lp_idx) == (1 if P == 1 else 0)
+    dec = dec.detach()
+    np.savez(os.path.join(OUT, name + ".npz"), seed=np.int32(seed), B=np.int32(B), alpha=np.float32(alpha), beta=np.float32(beta),
+             delta=np.int32(delta), droppath=torch.stack(masks).numpy() if masks else np.zeros((0, B), np.float32),
+             dropout_rand=dropout_rand[0].numpy().astype(np.int64) if dropout_rand else np.zeros(0, np.int64),
+             lp_prob=lp_prob[0].numpy() if lp_prob else np.zeros(0, np.float32),
+             lp_idx=lp_idx[0].numpy().astype(np.int64) if lp_idx else np.zeros(0, np.int64),
+             dec_sub=dec[:, :, ::4, ::4].contiguous().numpy(), dec_mean=np.float64(dec.double().mean()), dec_l2=np.float64(dec.double().square().mean().sqrt()),
+             dec_absmax=np.float32(dec.abs().max()), vq=np.float32(float(vq)), commit=np.float32(float(commit)), entropy=np.float32(float(ent)),
+             usages=np.array(usages, np.float32), sem=np.float32(float(sem)), dep=np.float32(float(dep)), meta=np.array(str(meta())))
+    print("wrote", name, "masks", len(masks), "vq", float(vq), "commit", float(commit), "sem", float(sem), "dep", float(dep), "usages", [round(float(u), 2) for u in usages][:3])
+
+
+def gen_model_bf16(name, kw, seed):
+    """the same image through the reference under torch.autocast('cpu', bfloat16): what the reference's own reduced-precision
+    path does to reconstructions and indices — the yardstick for the MI355X bf16 kernels (tests/test_model_parity.py)."""
+    from oracle.det_init import det_state_dict
+    R = load_reference()
+    torch.manual_seed(seed)
+    m = R["VQ_models"]["VQ-16"](**kw).eval()
+    m.load_state_dict(det_state_dict(m.state_dict(), seed))
+    x = torch.rand(1, 3, 256, 256, generator=torch.Generator().manual_seed(1234 + seed)) * 2 - 1
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        rec = m.img_to_reconstructed_img(x).float()
+        h = m.encoder(x)
+        if kw["enc_type"] == "dinov2":
+            b, l, c = h.shape
+            h = h.view(b, int(l ** 0.5), int(l ** 0.5), c).permute(0, 3, 1, 2)
+        f = m.quant_conv(h).float()
+        idx = m.quantize.f_to_idxBl_or_fhat(f, to_fhat=False, v_patch_nums=None)[0]
+    np.savez(os.path.join(OUT, name + "_bf16.npz"), rec_bf16=rec.numpy(), idx_bf16=idx.numpy(), f_bf16=f.numpy(), meta=np.array(str(meta())))
+    print("wrote", name + "_bf16", "rec range", float(rec.min()), float(rec.max()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
@@ -248,6 +338,20 @@ def main():
         gen_msvq("msvq_var_models_quant_v512_c32_b4", 512, 32, 4, [1, 2, 3, 4, 5, 6, 8, 10], seed=23, var_variant=True)
         if only:
             return
+    if only == "train":
+        for i, (nm, (kw, B, al, be, de)) in enumerate(TRAIN_CASES.items()):
+            gen_train_forward(nm, kw, B, al, be, de, seed=60 + i)
+        return
+    if only == "bf16":
+        gen_model_bf16("model_cfg1_cnn_vq4096", dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], enc_type="cnn",
+                                                     dec_type="cnn", semantic_guide="none", detail_guide="none",
+                                                     num_latent_tokens=256, product_quant=1), seed=31)
+        gen_model_bf16("model_cfg2_vitb_vq8192", dict(codebook_size=8192, codebook_embed_dim=32, v_patch_nums=[16], enc_type="dinov2",
+                                                      dec_type="dinov2", semantic_guide="none", detail_guide="none",
+                                                      num_latent_tokens=256, product_quant=1, abs_pos_embed=True,
+                                                      encoder_model="vit_base_patch14_dinov2.lvd142m",
+                                                      decoder_model="vit_base_patch14_dinov2.lvd142m"), seed=32)
+        return
     if only in ("var", ""):
         # VAR-d16 geometry (1x1 -> 16x16, 10 scales, 4 partially shared Phi) and the MSVR10P2 ladder; models/quant.py twin
         gen_var_helpers("var_helpers_16grid_v512_c16_b3", 512, 16, 3, [1, 2, 3, 4, 5, 6, 8, 10, 13, 16], seed=50)

@@ -58,6 +58,9 @@ class Mlp(nn.Module):
 
 
 class DropPath(nn.Module):
+    # golden generation: when RECORD is a list, every mask drawn (after the 1/keep scaling) is appended to it, in call order
+    RECORD = None
+
     def __init__(self, drop_prob: float = 0., scale_by_keep: bool = True):
         super().__init__()
         self.drop_prob = drop_prob
@@ -71,6 +74,8 @@ class DropPath(nn.Module):
         random_tensor = x.new_empty(shape).bernoulli_(keep_prob)
         if keep_prob > 0.0 and self.scale_by_keep:
             random_tensor.div_(keep_prob)
+        if DropPath.RECORD is not None:
+            DropPath.RECORD.append(random_tensor.detach().reshape(-1).clone())
         return x * random_tensor
 
 

@@ -1,0 +1,81 @@
+"""M1: VQModel.forward in train() mode against the reference (xqgan_model.py:268-365), BASELINE configs 2-5 at model level:
+P = 1 and P = 2, single-scale and the 10-scale ladder, quantizer dropout, the semantic branch, latent perturbation.
+
+Goldens (oracle/make_golden.py gen_train_forward): the unmodified reference model with deterministic weights on CPU in fp32,
+with EVERY random draw of the pass recorded — the DropPath masks of the 24 transformer blocks, the per-sample quantizer
+dropout depths, the two draws of add_perturbation.  The mirror replays them ("pass RNG draws as tensors") and runs
+its fp32 path on the GPU: HIP quantizers / perturbation + fused row kernels + the fp32-MFMA kernels of csrc/xq_f32.hip.
+Bounds: pixels 1e-4 on at least 97 % of the (4x-subsampled) decoder output — a token that sits on an fp32 near-tie may flip
+and legitimately change its 16 x 16 patch; codebook / commitment / semantic losses 2e-3 relative."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle.det_init import det_state_dict
+
+pytestmark = pytest.mark.gpu
+
+COMMON = dict(enc_type="dinov2", dec_type="dinov2", semantic_guide="dinov2", detail_guide="none", abs_pos_embed=True,
+              encoder_model="vit_base_patch14_dinov2.lvd142m", decoder_model="vit_base_patch14_dinov2.lvd142m",
+              share_quant_resi=4, start_drop=3, sem_loss_weight=0.1, guide_type_1="class")
+CASES = {
+    "train_fwd_cfg2_vq8192": dict(codebook_size=8192, codebook_embed_dim=32, v_patch_nums=[16], num_latent_tokens=256, product_quant=1,
+                                  codebook_drop=0.0, half_sem=False),
+    "train_fwd_cfg3_vp2_16384": dict(codebook_size=16384, codebook_embed_dim=32, v_patch_nums=[16], num_latent_tokens=256, product_quant=2,
+                                     codebook_drop=0.1, half_sem=True),
+    "train_fwd_cfg4_msvr10p2_4096": dict(codebook_size=4096, codebook_embed_dim=32, v_patch_nums=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11],
+                                         num_latent_tokens=121, product_quant=2, codebook_drop=0.1, half_sem=True),
+    "train_fwd_cfg5_robusttok": dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], num_latent_tokens=256, product_quant=1,
+                                     codebook_drop=0.0, half_sem=False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_train_mode_forward_matches_reference(name, monkeypatch):
+    from imagefolder_amd import latent_perturbation, xqgan_model
+    from imagefolder_amd.dino_enc.vision_transformer import DropPath
+    g = load_golden(name)
+    seed, B = int(g["seed"]), int(g["B"])
+    torch.manual_seed(seed)
+    m = xqgan_model.VQ_models["VQ-16"](**dict(COMMON, **CASES[name])).train()
+    m.load_state_dict(det_state_dict(m.state_dict(), seed))
+    m = m.cuda()
+    x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(4321 + seed)) * 2 - 1).cuda()
+
+    # ---- replay the reference's random draws ----
+    DropPath.REPLAY = [torch.from_numpy(r) for r in g["droppath"]]
+    real_randint = torch.randint
+
+    def randint(*a, **k):
+        if len(g["dropout_rand"]) and len(a) >= 3 and tuple(a[2]) == (B,):
+            return torch.from_numpy(g["dropout_rand"]).clone()
+        return real_randint(*a, **k)
+    monkeypatch.setattr(torch, "randint", randint)
+    if len(g["lp_prob"]):
+        alpha = float(g["alpha"])
+        prob, ridx = torch.from_numpy(g["lp_prob"]), torch.from_numpy(g["lp_idx"])
+        rank = torch.where(prob > alpha, torch.zeros_like(ridx), ridx)               # latent_perturbation.py:23
+
+        def draw(n_tokens, a_, delta_, device):
+            assert n_tokens == rank.numel()
+            return rank.to(device)
+        monkeypatch.setattr(latent_perturbation, "draw_ranks", draw)
+    try:
+        with torch.no_grad():
+            dec, (vq, commit, ent, usages), sem, detail, dep = m(x, 0, float(g["alpha"]), float(g["beta"]), int(g["delta"]))
+        assert DropPath.REPLAY == [], f"{len(DropPath.REPLAY)} recorded DropPath masks were not consumed"
+    finally:
+        DropPath.REPLAY = None
+    dec = dec.float().cpu()
+    diff = (dec[:, :, ::4, ::4].numpy() - g["dec_sub"])
+    frac = float(np.mean(np.abs(diff) <= 1e-4))
+    print(f"{name}: pixels within 1e-4: {100 * frac:.2f} %, max |diff| {np.abs(diff).max():.2e}; vq {float(vq):.6f} / {float(g['vq']):.6f}; "
+          f"sem {float(sem):.6f} / {float(g['sem']):.6f}; usages {usages[:3]} / {g['usages'][:3]}")
+    assert frac >= 0.97, f"only {100 * frac:.1f} % of the pixels within 1e-4 (max {np.abs(diff).max():.3e})"
+    np.testing.assert_allclose(float(vq), float(g["vq"]), rtol=2e-3)
+    np.testing.assert_allclose(float(commit), float(g["commit"]), rtol=2e-3)
+    np.testing.assert_allclose(float(sem), float(g["sem"]), rtol=2e-3, atol=1e-5)
+    np.testing.assert_allclose(float(dep), float(g["dep"]), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(np.asarray(usages, np.float32), g["usages"], atol=0.05)
+    assert detail is None
