@@ -93,3 +93,37 @@ def test_gpu_fp32_indices_and_pixels_match_reference_cpu(oracle, name):
         assert np.abs(rec - g["rec"]).max() <= 1e-4
     else:  # a flipped token changes its neighbourhood legitimately; the rest must still agree
         assert np.mean(np.abs(rec - g["rec"]) <= 1e-4) >= 0.9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_gpu_bf16_kernels_are_as_close_to_fp32_as_the_reference_bf16_path(name):
+    """The TRAINING kernels (bf16 MFMA convolution / GEMM / attention, bf16 GroupNorm) on the reference-parity path.
+    bf16 results cannot meet the 1e-4 fp32 bound; the bound is DERIVED: tests/golden/*_bf16.npz holds what the unmodified reference
+    produces for the same image under torch.autocast(bfloat16) on CPU (oracle/make_golden.py gen_model_bf16), and its distance to
+    the reference's own fp32 result is the yardstick — the MI355X bf16 path must be at most 1.5x as far from the fp32 golden
+    (rms over the latent and over the pixels) and may flip at most twice as many code indices (+2)."""
+    from imagefolder_amd import nn_ops
+    m, g = build(name)
+    gb = load_golden(name + "_bf16")
+    m = m.cuda()
+    x = torch.from_numpy(g["x"]).cuda()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        f = m.encode(x).float().cpu().numpy()
+        idx = m.img_to_idx(x)[0][0].cpu().numpy()
+        rec = m.img_to_reconstructed_img(x).float().cpu().numpy()
+    if CASES[name]["enc_type"] == "cnn":
+        assert nn_ops.IMPL["conv2d"].startswith("hip") and nn_ops.IMPL["group_norm_silu"] == "hip"
+    else:
+        assert nn_ops.IMPL["attention"] == "hip" and nn_ops.IMPL["linear"].startswith("hip")
+
+    def rms(a):
+        return float(np.sqrt(np.mean(np.square(a, dtype=np.float64))))
+    ref_f, ref_rec = rms(gb["f_bf16"] - g["f"]), rms(gb["rec_bf16"] - g["rec"])
+    ref_flips = int((gb["idx_bf16"] != g["idx"]).sum())
+    our_f, our_rec, our_flips = rms(f - g["f"]), rms(rec - g["rec"]), int((idx != g["idx"]).sum())
+    print(f"{name}: latent rms {our_f:.4e} (reference bf16 {ref_f:.4e}); pixel rms {our_rec:.4e} (reference bf16 {ref_rec:.4e}); "
+          f"code flips {our_flips} (reference bf16 {ref_flips}) of {idx.size}")
+    assert our_f <= 1.5 * ref_f
+    assert our_rec <= 1.5 * ref_rec
+    assert our_flips <= 2 * ref_flips + 2
