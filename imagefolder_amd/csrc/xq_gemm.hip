@@ -57,6 +57,11 @@ struct GemmArgs {
     long main_items;
     int tail_tiles, tail_splits, kt_full;
     float *slabs;
+    // implicit-GEMM convolution (A operand = NHWC image gathered tap by tap; Stager<KMAJOR_CONV>): output pixel m = (b, oy, ox),
+    // k = tap * Cin + c, tap = ky * 3 + kx.  forward: input pixel (oy * stride + ky - pad, ox * stride + kx - pad), divided by 2
+    // when `up` (the conv sees the nearest-2x upsampled image); transposed (data gradient of a strided conv): input pixel
+    // ((oy + ky - (2 - pad)) / stride, ...) where divisible.  Pixels outside the image read the zero page.
+    int cv_Hi, cv_Wi, cv_Cin, cv_Ho, cv_Wo, cv_stride, cv_pad, cv_up, cv_transposed, relu;
     // fused GELU (persistent schedule).  ACT_GELU_FWD: C = h (pre-activation, + bias), C2 = gelu(h).  ACT_GELU_BWD: C = acc * gelu'(H),
     // colpart[2 * row_tile + wave_row][N] = column sums of C over the 128 rows of that wave row (fc1 bias gradient)
     char *C2;
@@ -87,6 +92,7 @@ struct Stager {
     unsigned off[2][2];     // [half][i]
     const char *base;       // tile base at K tile 0 (wave-uniform)
     long adv;               // bytes per K tile
+    __device__ __forceinline__ void bind(const GemmArgs &) {}
     // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
     __device__ __forceinline__ void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn,
                                          int halves) {
@@ -124,10 +130,76 @@ struct Stager {
     }
 };
 
+__device__ __attribute__((aligned(64))) char xq_zero_page[64];      // zero-initialised: the source of out-of-image taps
+
+// A operand of the implicit-GEMM convolution: same LDS image and lane map as Stager<KMAJOR, true>, the source address of every
+// 16-byte chunk (8 channels of one input pixel) is computed per K tile from the tap the tile lies in (Cin % 64 == 0: a K tile
+// never straddles two taps)
+template <>
+struct Stager<gm::KMAJOR_CONV, true> {
+    const char *X;
+    int Hi, Wi, Cin, stride, pad, up, transposed, Hl, Wl;
+    long kt0;                     // first K tile of this work item
+    int pix0[2][2];               // [half][i]: pixel index of (b, 0, 0)  (B * Hi * Wi < 2^31, checked by the launcher)
+    int oyx[2][2];                // (oy << 16) | ox; -1: row beyond M
+    unsigned kbyte[2];            // [i]: byte offset of the lane's chunk inside the 64-wide K slice (independent of the half)
+    __device__ __forceinline__ void bind(const GemmArgs &g) {
+        X = g.A; Hi = g.cv_Hi; Wi = g.cv_Wi; Cin = g.cv_Cin; stride = g.cv_stride; pad = g.cv_pad; up = g.cv_up; transposed = g.cv_transposed;
+        Hl = up ? 2 * Hi : Hi; Wl = up ? 2 * Wi : Wi;
+        ho_ = g.cv_Ho; wo_ = g.cv_Wo;
+    }
+    int ho_, wo_;
+    __device__ __forceinline__ void init(const char *, long, long rc0, long rc_count, long k0, int wave, int lane, int wtn, int) {
+        kt0 = k0 / gm::BKT;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const gm::StageSrc s = gm::stage_src<gm::KMAJOR, true>(h, wave, i, lane, wtn);
+                const long m = rc0 + s.rc;
+                kbyte[i] = (unsigned)(s.k * 2);
+                if (m < rc_count) {
+                    const int b = (int)(m / ((long)ho_ * wo_));
+                    const int rem = (int)(m - (long)b * ho_ * wo_);
+                    const int y = rem / wo_;
+                    oyx[h][i] = (y << 16) | (rem - y * wo_);
+                    pix0[h][i] = b * Hi * Wi;
+                } else {
+                    oyx[h][i] = -1; pix0[h][i] = 0;
+                }
+            }
+    }
+    __device__ __forceinline__ void issue(int half, long kt, char *dst, int wave) const {
+        const long kg = (kt0 + kt) * gm::BKT;
+        const int tap = (int)(kg / Cin), c0 = (int)(kg - (long)tap * Cin);
+        const int ky = tap / 3, kx = tap - 3 * ky;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int iy, ix;
+            bool ok = oyx[half][i] >= 0;
+            const int oy_ = oyx[half][i] >> 16, ox_ = oyx[half][i] & 0xffff;
+            if (!transposed) {
+                iy = oy_ * stride + ky - pad;
+                ix = ox_ * stride + kx - pad;
+                ok = ok && iy >= 0 && iy < Hl && ix >= 0 && ix < Wl;
+                if (up) { iy >>= 1; ix >>= 1; }
+            } else {
+                iy = oy_ + ky - (2 - pad);
+                ix = ox_ + kx - (2 - pad);
+                ok = ok && iy >= 0 && ix >= 0 && (iy % stride) == 0 && (ix % stride) == 0;
+                iy /= stride; ix /= stride;
+                ok = ok && iy < Hi && ix < Wi;
+            }
+            const char *src = ok ? X + ((long)(pix0[half][i] + iy * Wi + ix) * Cin + c0) * 2 + kbyte[i] : xq_zero_page;
+            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+        }
+    }
+};
+
 // fragment of 8 reduction indices for row / column (lane & 31) out of a piece
 template <int KIND, bool IS_A>
 __device__ __forceinline__ bf16x8 read_frag(const char *piece, int w, int f, int s, int lane) {
-    if (KIND == gm::KMAJOR) {
+    if (KIND != gm::KSTRIDED) {
         return *reinterpret_cast<const bf16x8 *>(piece + gm::frag_off_kmajor<IS_A>(w, f, s, lane));
     } else {
         const bf16x4 lo = tr4(piece + gm::frag_off_kstrided<IS_A>(w, f, s, 0, lane));
@@ -159,8 +231,11 @@ __device__ __forceinline__ void epilogue_bf16(const f32x16 (&acc)[4][NFJ], const
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 uint2 pk;
-                pk.x = pack_bf16(acc[fi][fj][4 * q + 0] + bv[q].x, acc[fi][fj][4 * q + 1] + bv[q].y);
-                pk.y = pack_bf16(acc[fi][fj][4 * q + 2] + bv[q].z, acc[fi][fj][4 * q + 3] + bv[q].w);
+                float e0 = acc[fi][fj][4 * q + 0] + bv[q].x, e1 = acc[fi][fj][4 * q + 1] + bv[q].y;
+                float e2 = acc[fi][fj][4 * q + 2] + bv[q].z, e3 = acc[fi][fj][4 * q + 3] + bv[q].w;
+                if (g.relu) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                pk.x = pack_bf16(e0, e1);
+                pk.y = pack_bf16(e2, e3);
                 *reinterpret_cast<uint2 *>(region + gm::epi_write_off(fi, fj, q, lane, WTN)) = pk;
             }
     }
@@ -232,6 +307,7 @@ __global__ __launch_bounds__(GT) void gemm_simple_kernel(const GemmArgs g) {
 
     Stager<AK, true> sa;
     Stager<BK, false> sb;
+    sa.bind(g);
     sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, NFJ);
 
@@ -311,6 +387,7 @@ __global__ __launch_bounds__(GT) void gemm_ring_kernel(const GemmArgs g) {
 
     Stager<AK, true> sa;
     Stager<BK, false> sb;
+    sa.bind(g);
     sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, 2);
 
@@ -481,6 +558,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     // staging cursor
     Stager<AK, true> sa;
     Stager<BK, false> sb;
+    sa.bind(g);
     sa.init(g.A, g.lda, cit.m0, g.M, cit.k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, cit.n0, g.N, cit.k0, wave, lane, WTN, 2);
     long sp = cp;
@@ -647,8 +725,11 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         uint2 pk;
-                        pk.x = pack_bf16(acc[fi][fj][4 * q + 0] + bv[fj][q].x, acc[fi][fj][4 * q + 1] + bv[fj][q].y);
-                        pk.y = pack_bf16(acc[fi][fj][4 * q + 2] + bv[fj][q].z, acc[fi][fj][4 * q + 3] + bv[fj][q].w);
+                        float e0 = acc[fi][fj][4 * q + 0] + bv[fj][q].x, e1 = acc[fi][fj][4 * q + 1] + bv[fj][q].y;
+                        float e2 = acc[fi][fj][4 * q + 2] + bv[fj][q].z, e3 = acc[fi][fj][4 * q + 3] + bv[fj][q].w;
+                        if (g.relu) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                        pk.x = pack_bf16(e0, e1);
+                        pk.y = pack_bf16(e2, e3);
                         *reinterpret_cast<uint2 *>(region + gm::epi_write_off(0, fj, q, lane, WTN)) = pk;
                     }
                 // same wave wrote and reads: LDS operations of one wave complete in order
@@ -844,7 +925,7 @@ PPlan plan_persistent(long tiles, int kt_full, bool weight_grad) {
 }
 
 template <int AK, int BK, int EPI, int ACT = ACT_NONE>
-int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStream_t s, const char *fn, double flops) {
+int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStream_t s, const char *fn, double flops, int prof_kind = XQ_PROF_GEMM) {
     const long tiles = (long)g.tiles_m * g.tiles_n;
     if (tiles <= 0) return XQ_OK;
     if (tiles * (g.splits > 0 ? g.splits : 1) > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: too many tiles", fn);
@@ -852,7 +933,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
     if (impl == XQ_GEMM_AUTO) impl = ring_ok ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
     if ((impl == XQ_GEMM_RING || impl == XQ_GEMM_PERSISTENT) && !ring_ok)
         return xq_set_error(XQ_EINVAL, "%s: the ring schedules need 256-column tiles and >= 2 K tiles per work item", fn);
-    const int pslot = prof_begin(XQ_PROF_GEMM, flops, s);
+    const int pslot = prof_begin(prof_kind, flops, s);
     if (impl == XQ_GEMM_PERSISTENT) {
         PPlan pl = plan_persistent(tiles, g.kt_full, EPI == EPI_F32_SLAB);
         if (ACT != ACT_NONE) pl = PPlan{tiles, 0, 1, 0};   // the fused activation lives in the whole-tile epilogue
@@ -1029,4 +1110,31 @@ extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const vo
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
     g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
     return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16, ACT_GELU_BWD>(g, 256, XQ_GEMM_PERSISTENT, nullptr, 0, (hipStream_t)stream, fn, 2.0 * M * N * K);
+}
+
+// ---- 3x3 convolution as an implicit GEMM on the tile engine (NHWC bf16; Cin % 64 == 0, Cout % 8 == 0, Cout >= 64) -------------
+extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int Ho,
+                                    int Wo, int stride, int pad, int upsample2x, int transposed, int relu, void *y, int impl,
+                                    xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_gemm_bf16";
+    if (B < 0 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (Cin % 64 || Cout % 8 || Cout < 64) return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 64 == 0, Cout %% 8 == 0, Cout >= 64 (Cin=%ld Cout=%ld)", fn, (long)Cin, (long)Cout);
+    if ((stride != 1 && stride != 2) || pad < 0 || pad > 2 || (upsample2x && (stride != 1 || transposed)))
+        return xq_set_error(XQ_EINVAL, "%s: stride 1 / 2, pad 0..2, upsampling only with stride 1 forward", fn);
+    if (B == 0) return XQ_OK;
+    if (!x || !w_packed || !y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if ((long)B * Hi * Wi >= 0x7fffffffL || Ho > 32767 || Wo > 32767) return xq_set_error(XQ_EINVAL, "%s: image too large for 32-bit pixel indices", fn);
+    const long M = (long)B * Ho * Wo, K = 9L * Cin;
+    const int BN = pick_bn(Cout, impl);
+    impl &= 0xff;
+    GemmArgs g{};
+    g.nt_store = 1;
+    g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;
+    g.M = M; g.N = Cout; g.lda = K; g.ldb = K; g.ldc = Cout;
+    g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((Cout + BN - 1) / BN);
+    g.cv_Hi = Hi; g.cv_Wi = Wi; g.cv_Cin = Cin; g.cv_Ho = Ho; g.cv_Wo = Wo; g.cv_stride = stride; g.cv_pad = pad; g.cv_up = upsample2x ? 1 : 0;
+    g.cv_transposed = transposed ? 1 : 0;
+    return launch_gemm<gm::KMAJOR_CONV, gm::KMAJOR, EPI_BF16>(g, BN, impl, nullptr, 0, (hipStream_t)stream, fn, 2.0 * (double)M * (double)K * Cout,
+                                                              XQ_PROF_CONV3X3);
 }

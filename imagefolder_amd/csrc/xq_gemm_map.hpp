@@ -26,7 +26,7 @@
 
 namespace gm {
 
-enum { KMAJOR = 0, KSTRIDED = 1 };
+enum { KMAJOR = 0, KSTRIDED = 1, KMAJOR_CONV = 2 };   // KMAJOR_CONV: K-major A operand gathered from an NHWC image (implicit GEMM)
 constexpr int PIECE_BYTES = 16384;
 constexpr int BM = 256, BKT = 64;   // block rows, reduction depth of one K tile
 

@@ -560,6 +560,27 @@ def _conv3x3_call(x_cl, wp, bias, Cout, relu):
     return y
 
 
+CONV_ENGINE = _os.environ.get("XQ_CONV", "gemm")     # "gemm": implicit GEMM on the tile engine of csrc/xq_gemm.hip; "r1": csrc/xq_conv.hip
+CONV_SCHEDULE = int(_os.environ.get("XQ_CONV_SCHEDULE", "0"), 0)
+
+
+def conv3x3_gemm(x_cl, wp, bias, Cout, relu=False, stride=1, pad=1, upsample=False, transposed=False, out_hw=None):
+    """3x3 convolution (or, transposed, its data gradient) on the GEMM tile engine: xq_conv3x3_gemm_bf16.
+    x_cl: (B, Cin, Hi, Wi) bf16 channels_last; wp: packed weights [Cout][9 * Cin]; returns (B, Cout, Ho, Wo) channels_last."""
+    B, Cin, Hi, Wi = x_cl.shape
+    if out_hw is None:
+        Hl, Wl = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
+        out_hw = ((Hl + 2 * pad - 3) // stride + 1, (Wl + 2 * pad - 3) // stride + 1)
+    Ho, Wo = out_hw
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.bfloat16, device=x_cl.device, memory_format=torch.channels_last)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    with torch.cuda.device(x_cl.device):
+        rc = _lib.lib().xq_conv3x3_gemm_bf16(ptr(x_cl), ptr(wp), ptr(b32), B, Hi, Wi, Cin, Cout, Ho, Wo, stride, pad, int(bool(upsample)),
+                                             int(bool(transposed)), int(bool(relu)), ptr(y), CONV_SCHEDULE, _stream(x_cl))
+    check(rc, "xq_conv3x3_gemm_bf16")
+    return y
+
+
 def conv3x3_weight_grad(x_cl, g, weight):
     """dW of the 3x3 / stride 1 / pad 1 conv from channels-last bf16 x and dY: the hand-written transpose-read MFMA kernel
     (fp32 accumulation, csrc/xq_conv.hip) when both channel counts are multiples of 128, else the library wgrad."""

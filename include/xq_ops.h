@@ -338,6 +338,16 @@ int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_
 size_t xq_gemm_colpart_rows(int64_t M);
 int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h, float *colpart,
                              int approximate_tanh, xq_stream_t stream);
+/* 3x3 convolution on the GEMM tile engine (implicit GEMM: the A operand is gathered from the NHWC image tap by tap by the
+ * LDS-DMA, out-of-image taps read a zero page; csrc/xq_gemm.hip Stager<KMAJOR_CONV>).  x [B][Hi][Wi][Cin] bf16, w_packed
+ * [Cout][9 * Cin] bf16 as xq_conv3x3_pack_weights writes it, y [B][Ho][Wo][Cout] bf16 (+ bias, optional ReLU).
+ *   forward:     input pixel (oy * stride + ky - pad, ox * stride + kx - pad); upsample2x: of the nearest-2x upsampled image
+ *                (Upsample, xqgan_model.py:682-686); stride 2 / pad 0 with Ho = Hi / 2 is Downsample (:697-704);
+ *   transposed:  the data gradient of a forward conv of that stride / pad: x = dY [B][Hi][Wi][Cin = forward Cout], w_packed = the
+ *                for_data_grad pack, y = dX [B][Ho][Wo] (Ho x Wo = the forward input size).
+ * Cin % 64 == 0, Cout % 8 == 0, Cout >= 64. */
+int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int Ho, int Wo,
+                         int stride, int pad, int upsample2x, int transposed, int relu, void *y, int impl, xq_stream_t stream);
 /* weight gradient: g_w[P][Q] (fp32) = g_y[R][P]^T . x[R][Q], the token axis R split over the chip into fp32 slabs in
  * `workspace` that a second kernel sums in a fixed order (deterministic, no atomics).
  * P, Q multiples of 8 and >= 32; any R >= 0. */

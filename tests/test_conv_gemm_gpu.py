@@ -1,0 +1,74 @@
+"""3x3 convolutions on the GEMM tile engine (xq_conv3x3_gemm_bf16: implicit GEMM, the image gathered tap by tap by the LDS-DMA)
+against F.conv2d in fp32 on the same bf16 operands: forward (stride 1 / 2, the (0,1,0,1)-padded Downsample, the nearest-2x
+Upsample folded into the gather, ReLU) and the data gradients (transposed gather) of the stride-1 and stride-2 convs.
+Bound as for the GEMMs: half a bf16 ulp of the result + fp32 accumulation-order noise."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(out, ref, absprod):
+    err = (out.float() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + absprod * 4e-6 + 1e-30
+    worst = (err / bound).max().item()
+    assert worst <= 1.0, f"max err/bound {worst:.3f} (max abs err {err.max().item():.3e})"
+
+
+def _mk(B, Cin, H, W, Cout, seed=0):
+    torch.manual_seed(seed)
+    x = torch.randn(B, Cin, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(Cout, Cin, 3, 3, device="cuda") * 0.05)
+    b = torch.randn(Cout, device="cuda")
+    return x, w, b
+
+
+@pytest.mark.parametrize("impl", [1, 2, 3])
+@pytest.mark.parametrize("B,Cin,H,W,Cout", [(2, 64, 20, 24, 64), (3, 128, 16, 16, 256), (1, 256, 33, 17, 512), (2, 64, 8, 8, 72)])
+def test_conv3x3_forward(B, Cin, H, W, Cout, impl):
+    from imagefolder_amd import ops_dense as od
+    if impl != 1 and Cout < 256:
+        pytest.skip("ring schedules: 256-column tiles")
+    x, w, b = _mk(B, Cin, H, W, Cout)
+    w16 = w.to(torch.bfloat16).float()
+    wp = od._packed_conv_weight(torch.nn.Parameter(w), False)
+    od.CONV_SCHEDULE = impl
+    try:
+        y = od.conv3x3_gemm(x, wp, b, Cout)
+        yr = od.conv3x3_gemm(x, wp, b, Cout, relu=True)
+    finally:
+        od.CONV_SCHEDULE = 0
+    ref = F.conv2d(x.float(), w16, b, padding=1)
+    absprod = F.conv2d(x.float().abs(), w16.abs(), b.abs(), padding=1)
+    _check(y, ref, absprod)
+    _check(yr, ref.clamp_min(0), absprod)
+
+
+def test_downsample_and_upsample_forward():
+    from imagefolder_amd import ops_dense as od
+    x, w, b = _mk(2, 128, 32, 32, 128, seed=1)
+    w16 = w.to(torch.bfloat16).float()
+    wp = od._packed_conv_weight(torch.nn.Parameter(w), False)
+    yd = od.conv3x3_gemm(x, wp, b, 128, stride=2, pad=0, out_hw=(16, 16))                      # Downsample: pad (0,1,0,1), stride 2
+    ref = F.conv2d(F.pad(x.float(), (0, 1, 0, 1)), w16, b, stride=2)
+    _check(yd, ref, F.conv2d(F.pad(x.float().abs(), (0, 1, 0, 1)), w16.abs(), b.abs(), stride=2))
+    yu = od.conv3x3_gemm(x, wp, b, 128, upsample=True)                                        # Upsample: nearest 2x + conv
+    xu = F.interpolate(x.float(), scale_factor=2.0, mode="nearest")
+    _check(yu, F.conv2d(xu, w16, b, padding=1), F.conv2d(xu.abs(), w16.abs(), b.abs(), padding=1))
+
+
+@pytest.mark.parametrize("stride,pad,pad_br", [(1, 1, 1), (2, 0, 1)])
+def test_data_gradient_transposed_gather(stride, pad, pad_br):
+    from imagefolder_amd import ops_dense as od
+    B, Cin, H, W, Cout = 2, 128, 16, 16, 256
+    x, w, _ = _mk(B, Cin, H, W, Cout, seed=2)
+    w16 = w.to(torch.bfloat16).float()
+    xr = x.float().clone().requires_grad_(True)
+    y = F.conv2d(F.pad(xr, (pad, pad_br, pad, pad_br)), w16, None, stride=stride)
+    g = torch.randn_like(y).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    y.backward(g.float())
+    wpd = od._packed_conv_weight(torch.nn.Parameter(w), True)                                 # [Cin][9 * Cout], taps rotated
+    gx = od.conv3x3_gemm(g, wpd, None, Cin, stride=stride, pad=pad, transposed=True, out_hw=(H, W))
+    absprod = torch.autograd.grad(F.conv2d(F.pad(xr, (pad, pad_br, pad, pad_br)), w16.abs(), None, stride=stride), xr, g.float().abs())[0]
+    _check(gx, xr.grad, absprod)
