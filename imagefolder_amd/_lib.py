@@ -57,6 +57,8 @@ SIGNATURES = {
     "xq_conv3x3_nhwc_bf16": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, vp, vp]),
     "xq_conv3x3_wgrad_nhwc_bf16": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv3x3_wgrad_nhwc_bf16_ex": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp]),
+    "xq_sumpool2x2_nhwc_bf16": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_maxpool2x2_nhwc_bf16_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_maxpool2x2_nhwc_bf16_backward": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_attn_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp]),

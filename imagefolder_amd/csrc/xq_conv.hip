@@ -19,6 +19,7 @@
 #include "../../include/xq_ops.h"
 
 #include <hip/hip_bf16.h>
+#include "xq_vec.hpp"
 
 using namespace xq;
 
@@ -248,9 +249,11 @@ __device__ __forceinline__ wg_s4 wg_tr4(const short *p) {
 static constexpr int WG_PITCH = 136;   // 128 channels + 8: LDS row pitch in bf16 elements (272 bytes)
 #define WG_TFRAG(TRP, ROW0, COL0) __builtin_shufflevector(wg_tr4((TRP) + (ROW0) * WG_PITCH + (COL0)), wg_tr4((TRP) + ((ROW0) + 8) * WG_PITCH + (COL0)), 0, 1, 2, 3, 4, 5, 6, 7)
 
+// Geometry: dY pixel (b, y, x) of an H x Wd map pairs with X pixel ((y * stride + ky - pad) >> up, (x * stride + kx - pad) >> up) of an
+// Hi x Wi map (stride 2 / pad 0: Downsample; up = 1: the conv ran on the nearest-2x upsampled X; default stride 1 / pad 1 / Hi = H).
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16 *__restrict__ X, const __hip_bfloat16 *__restrict__ dY, long M,
                                                             int H, int Wd, int Cin, int Cout, int tiles_per_split, int nsplit,
-                                                            float *__restrict__ dWp) {
+                                                            float *__restrict__ dWp, int Hi, int Wi, int stride, int pad, int up) {
     __shared__ __attribute__((aligned(16))) short lds[2][2 * 64 * WG_PITCH];   // [buffer][dY tile | X tile], 64 pixels each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
@@ -265,7 +268,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
     const int tap = rest / (gn * gc);
     rest -= tap * gn * gc;
     const int n0 = (rest / gc) * 128, c0 = (rest % gc) * 128;
-    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const int dy = tap / 3 - pad, dx = tap - (tap / 3) * 3 - pad;
+    const int Hl = up ? 2 * Hi : Hi, Wl = up ? 2 * Wi : Wi;
+    const long HWin = (long)Hi * Wi;
     const long ntiles = (M + 63) / 64;
     const long t_begin = (long)split * tiles_per_split;
     long t_end = t_begin + tiles_per_split;
@@ -287,9 +292,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
         const int b_ = (int)mm / HWi;             /* M < 2^31 (checked by the launcher): 32-bit divisions */          \
         const int rem_ = (int)mm - b_ * HWi;                                                                           \
         const int y_ = rem_ / Wd, x_ = rem_ - y_ * Wd;                                                                 \
-        const int yy = y_ + dy, xx = x_ + dx;                                                                          \
-        const bool ok = okm && yy >= 0 && yy < H && xx >= 0 && xx < Wd;                                                \
-        RX = *reinterpret_cast<const uint4 *>(X + (((long)b_ * HWi + (ok ? yy * Wd + xx : 0)) * Cin + c0 + spart));    \
+        const int yy = y_ * stride + dy, xx = x_ * stride + dx;                                                        \
+        const bool ok = okm && yy >= 0 && yy < Hl && xx >= 0 && xx < Wl;                                               \
+        RX = *reinterpret_cast<const uint4 *>(X + (((long)b_ * HWin + (ok ? (yy >> up) * Wi + (xx >> up) : 0)) * Cin + c0 + spart)); \
         if (!ok) RX = zero4;                                                                                           \
     }
 #define WG_LOAD(TILE) { WG_LOAD_ROW(ry0, rx0, 0, TILE) WG_LOAD_ROW(ry1, rx1, 1, TILE) WG_LOAD_ROW(ry2, rx2, 2, TILE) WG_LOAD_ROW(ry3, rx3, 3, TILE) }
@@ -372,7 +377,70 @@ extern "C" int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, 
     nsplit = (ntiles + tps - 1) / tps;
     const long T = nsplit * base;
     hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(((T + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, H, W, Cin, Cout, (int)tps, (int)nsplit, dWp);
+                       (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, H, W, Cin, Cout, (int)tps, (int)nsplit, dWp, H, W, 1, 1, 0);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_conv3x3_wgrad_nhwc_bf16_ex(const void *X, const void *dY, int B, int Hi, int Wi, int Ho, int Wo, int Cin, int Cout, int stride,
+                                             int pad, int upsample2x, float *dWp, xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_wgrad_nhwc_bf16_ex";
+    if (B == 0) return XQ_OK;
+    if (!X || !dY || !dWp) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (Cin % 128 != 0 || Cout % 128 != 0)
+        return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 128 == 0 and Cout %% 128 == 0 (got %ld, %ld)", fn, Cin, Cout);
+    if ((stride != 1 && stride != 2) || pad < 0 || pad > 1) return xq_set_error(XQ_EINVAL, "%s: stride 1 / 2, pad 0 / 1", fn);
+    const long M = (long)B * Ho * Wo;
+    if (M >= (1L << 31) || (long)B * Hi * Wi >= (1L << 31)) return xq_set_error(XQ_EINVAL, "%s: pixel counts must be below 2^31", fn);
+    const long ntiles = (M + 63) / 64;
+    const long base = 9L * (Cout / 128) * (Cin / 128);
+    long nsplit = (4L * num_cus() + base - 1) / base;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    const long tps = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + tps - 1) / tps;
+    const long T = nsplit * base;
+    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(((T + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, Ho, Wo, Cin, Cout, (int)tps, (int)nsplit, dWp, Hi, Wi, stride, pad,
+                       upsample2x ? 1 : 0);
+    return xq_check_launch(fn);
+}
+
+// out[b][y][x][c] = sum of the 2 x 2 block of in at (2y, 2x): the backward of nearest-2x upsampling (Upsample, xqgan_model.py:682-686)
+__global__ __launch_bounds__(256) void sumpool2x2_kernel(const __hip_bfloat16 *__restrict__ in, int B, int Ho, int Wo, int C,
+                                                         __hip_bfloat16 *__restrict__ out) {
+    const int cv = C / 8;
+    const long total = (long)B * Ho * Wo * cv;
+    const long Wi = 2L * Wo;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv);
+        long t = i / cv;
+        const int xo = (int)(t % Wo);
+        t /= Wo;
+        const int yo = (int)(t % Ho);
+        const long b = t / Ho;
+        const __hip_bfloat16 *p = in + (((b * 2 * Ho + 2 * yo) * Wi + 2 * xo) * C + c * 8);
+        float a[8], q[8], r[8], d[8], o[8];
+        load_vec<__hip_bfloat16, 8>(p, a);
+        load_vec<__hip_bfloat16, 8>(p + C, q);
+        load_vec<__hip_bfloat16, 8>(p + Wi * C, r);
+        load_vec<__hip_bfloat16, 8>(p + Wi * C + C, d);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (a[j] + q[j]) + (r[j] + d[j]);
+        store_vec<__hip_bfloat16, 8>(out + i * 8, o);
+    }
+}
+
+extern "C" int xq_sumpool2x2_nhwc_bf16(const void *in, int B, int Ho, int Wo, int C, void *out, xq_stream_t stream) {
+    const char *fn = "xq_sumpool2x2_nhwc_bf16";
+    if (B < 0 || Ho < 1 || Wo < 1 || C < 8 || C % 8) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (B == 0) return XQ_OK;
+    if (!in || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * Ho * Wo * (C / 8);
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sumpool2x2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)in, B, Ho, Wo, C,
+                       (__hip_bfloat16 *)out);
     return xq_check_launch(fn);
 }
 

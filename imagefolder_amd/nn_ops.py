@@ -100,7 +100,15 @@ def patch_embed(x, weight, bias, patch):
 def conv1x1(x, weight, bias=None):
     """1x1 Conv2d on NCHW as a GEMM over the channel axis (quant_conv / post_quant_conv, xqgan_model.py:89-146).
     The input is usually a permuted view of a channels-last token tensor, so the permute below is free."""
-    y = linear(x.permute(0, 2, 3, 1), weight.reshape(weight.shape[0], -1), bias)
+    xt = x.permute(0, 2, 3, 1)
+    w2 = weight.reshape(weight.shape[0], -1)
+    if x.is_cuda and torch.is_autocast_enabled("cuda") and xt.dtype == torch.float32 and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        xt = xt.to(torch.bfloat16)         # what autocast does to the input of the conv
+    if x.is_cuda and xt.dtype == torch.bfloat16:
+        from . import ops_dense
+        y = ops_dense.LinearFn.apply(xt, w2, bias, False)          # the hand-written GEMMs in all three passes
+    else:
+        y = linear(xt, w2, bias)
     return y.permute(0, 3, 1, 2)
 
 
@@ -140,6 +148,12 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
             return ops_dense.Conv3x3Fn.apply(x, weight, bias, relu)
         if ops_dense.conv3x3_small_cin_supported(x, weight, stride, padding):
             return ops_dense.Conv3x3SmallCinFn.apply(x, weight, bias, relu)
+        if tuple(weight.shape[2:]) == (1, 1) and stride == 1 and padding == 0 and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 \
+                and weight.shape[0] >= 32:
+            # 1x1 conv = a GEMM over the channel axis of the channels-last map (nin_shortcut, AttnBlock q / k / v / proj_out)
+            IMPL["conv1x1"] = "hip (xq_gemm_bf16_*)"
+            y = conv1x1(x.to(torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype), weight, bias)
+            return torch.relu(y) if relu else y
     y = _conv2d_library(x, weight, bias, stride, padding)
     return torch.relu(y) if relu else y
 
@@ -160,12 +174,22 @@ def _conv2d_library(x, weight, bias, stride=1, padding=0):
     return F.conv2d(x, weight, bias, stride=stride, padding=padding)
 
 
+def _conv3x3_modes_supported(x, weight):
+    """bf16 training path of the strided / upsampling 3x3 convs: channel counts the weight-gradient kernel takes, even sizes"""
+    return (x.is_cuda and x.dim() == 4 and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled("cuda")) and tuple(weight.shape[2:]) == (3, 3)
+            and weight.shape[0] % 128 == 0 and weight.shape[1] % 128 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+
+
 def conv2d_downsample(x, weight, bias):
     """Downsample.conv (xqgan_model.py:697-704): zero-pad one row / column after the last (F.pad(x, (0, 1, 0, 1))), 3x3 conv, stride 2."""
     from . import ops_f32
     if x.is_cuda and ops_f32.eligible(x, weight, bias):
         IMPL["conv2d_fp32_inference"] = "hip (xq_conv2d_f32_nhwc: fp32 MFMA implicit GEMM)"
         return ops_f32.conv2d(x, weight, bias, stride=2, padding=0, pad_br=1)
+    if _conv3x3_modes_supported(x, weight):
+        from . import ops_dense
+        IMPL["conv2d_downsample"] = "hip (implicit GEMM, stride 2 with the (0,1,0,1) zero pad in the gather; transposed-gather data grad)"
+        return ops_dense.Conv3x3Fn.apply(x, weight, bias, False, "down")
     return conv2d(F.pad(x, (0, 1, 0, 1), mode="constant", value=0), weight, bias, stride=2, padding=0)
 
 
@@ -175,6 +199,10 @@ def conv2d_upsample(x, weight, bias):
     if x.is_cuda and ops_f32.eligible(x, weight, bias):
         IMPL["conv2d_fp32_inference"] = "hip (xq_conv2d_f32_nhwc: fp32 MFMA implicit GEMM)"
         return ops_f32.conv2d(x, weight, bias, stride=1, padding=1, upsample=True)
+    if _conv3x3_modes_supported(x, weight):
+        from . import ops_dense
+        IMPL["conv2d_upsample"] = "hip (implicit GEMM over the nearest-2x upsampled map, never materialised; 2x2 sum-pool in the backward)"
+        return ops_dense.Conv3x3Fn.apply(x, weight, bias, False, "up")
     return conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), weight, bias, stride=1, padding=1)
 
 

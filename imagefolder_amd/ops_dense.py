@@ -581,31 +581,76 @@ def conv3x3_gemm(x_cl, wp, bias, Cout, relu=False, stride=1, pad=1, upsample=Fal
     return y
 
 
-def conv3x3_weight_grad(x_cl, g, weight):
-    """dW of the 3x3 / stride 1 / pad 1 conv from channels-last bf16 x and dY: the hand-written transpose-read MFMA kernel
-    (fp32 accumulation, csrc/xq_conv.hip) when both channel counts are multiples of 128, else the library wgrad."""
+def _use_gemm_engine(n_pixels, Cout):
+    """the tile engine wins once its 256-row tiles fill the chip and the output is at least 128 channels wide
+    (profiles/r02_conv_gemm_v1.txt); narrow / small layers stay on the round-1 kernel (64- and 128-channel tiles, 128-pixel tiles)"""
+    if CONV_ENGINE != "gemm" or Cout < 128:
+        return False
+    bn = 256 if Cout >= 256 else 128
+    return (n_pixels + 255) // 256 * ((Cout + bn - 1) // bn) >= 192
+
+
+def conv3x3_weight_grad(x_cl, g, weight, mode="s1"):
+    """dW of a 3x3 conv from channels-last bf16 x and dY: the hand-written transpose-read MFMA kernel (fp32 accumulation,
+    csrc/xq_conv.hip) when both channel counts are multiples of 128, else (stride 1 only) the library wgrad.
+    mode: "s1" stride 1 / pad 1, "down" stride 2 with the (0,1,0,1) zero padding, "up" conv over the nearest-2x upsampled x."""
     Cout, Cin = weight.shape[0], weight.shape[1]
     if Cin % 128 == 0 and Cout % 128 == 0:
-        B, _, H, W = x_cl.shape
+        B, _, Hi, Wi = x_cl.shape
+        Ho, Wo = g.shape[2], g.shape[3]
         dwp = torch.zeros(Cout, 9 * Cin, dtype=torch.float32, device=x_cl.device)
+        stride, pad, up = {"s1": (1, 1, 0), "down": (2, 0, 0), "up": (1, 1, 1)}[mode]
         with torch.cuda.device(x_cl.device):
-            rc = _lib.lib().xq_conv3x3_wgrad_nhwc_bf16(ptr(x_cl), ptr(g), B, H, W, Cin, Cout, ptr(dwp), _stream(x_cl))
-        check(rc, "xq_conv3x3_wgrad_nhwc_bf16")
+            rc = _lib.lib().xq_conv3x3_wgrad_nhwc_bf16_ex(ptr(x_cl), ptr(g), B, Hi, Wi, Ho, Wo, Cin, Cout, stride, pad, up, ptr(dwp), _stream(x_cl))
+        check(rc, "xq_conv3x3_wgrad_nhwc_bf16_ex")
         return dwp.view(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3).to(weight.dtype)
+    if mode != "s1":
+        raise XqError(f"conv3x3 weight gradient ({mode}) needs channel counts that are multiples of 128, got {Cin} -> {Cout}")
     _, g_w, _ = torch.ops.aten.convolution_backward(g, x_cl, weight.detach().to(torch.bfloat16), None, [1, 1], [1, 1], [1, 1],
                                                     False, [0, 0], 1, [False, True, False])
     return g_w.to(weight.dtype)
 
 
+def _channel_sum(g_cl):
+    """bias gradient: sum over batch and pixels of a channels-last bf16 map, on the column-sum kernel"""
+    B, C, H, W = g_cl.shape
+    rows = B * H * W
+    if C % 8:
+        return g_cl.float().sum((0, 2, 3))
+    g2 = g_cl.permute(0, 2, 3, 1).reshape(rows, C)
+    out = torch.empty(C, dtype=torch.float32, device=g_cl.device)
+    nb = _lib.lib().xq_row_partials_blocks(rows * 4)
+    part = torch.empty(nb * C, dtype=torch.float32, device=g_cl.device)
+    with torch.cuda.device(g_cl.device):
+        rc = _lib.lib().xq_colsum(ptr(g2), rows, C, 1, ptr(out), 0, ptr(part), _stream(g_cl))
+    check(rc, "xq_colsum")
+    return out
+
+
 class Conv3x3Fn(torch.autograd.Function):
-    """y = [relu](conv3x3(x, W) + b), stride 1, pad 1, bf16 NHWC, hand-written implicit-GEMM kernel both ways for the
-    activations; the weight gradient (only needed for the trainable CNN encoder/decoder) uses the library wgrad."""
+    """y = [relu](conv3x3(x, W) + b) on bf16 NHWC activations, hand-written in all three passes.
+    mode "s1": stride 1 / pad 1; "down": Downsample.conv — stride 2 over the (0,1,0,1)-padded map (xqgan_model.py:697-704);
+    "up": Upsample — the conv over the nearest-2x upsampled map, which is never materialised (:682-686).
+    Forward and data gradient: implicit GEMM on the tile engine (csrc/xq_gemm.hip, xq_conv3x3_gemm_bf16: the data gradient of
+    the strided conv is its transposed gather, the one of "up" a stride-1 data gradient followed by a 2x2 sum-pool) or, for
+    narrow / small stride-1 layers, the round-1 kernel (csrc/xq_conv.hip); weight gradient: transpose-read MFMA kernel."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, relu):
+    def forward(ctx, x, weight, bias, relu, mode="s1"):
         x_cl = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        y = _conv3x3_call(x_cl, _packed_conv_weight(weight, False), bias, weight.shape[0], relu)
-        ctx.relu = bool(relu)
+        B, Cin, H, W = x_cl.shape
+        Cout = weight.shape[0]
+        wp = _packed_conv_weight(weight, False)
+        if mode == "s1":
+            if _use_gemm_engine(B * H * W, Cout):
+                y = conv3x3_gemm(x_cl, wp, bias, Cout, relu=relu)
+            else:
+                y = _conv3x3_call(x_cl, wp, bias, Cout, relu)
+        elif mode == "down":
+            y = conv3x3_gemm(x_cl, wp, bias, Cout, relu=relu, stride=2, pad=0, out_hw=((H - 2) // 2 + 1, (W - 2) // 2 + 1))
+        else:
+            y = conv3x3_gemm(x_cl, wp, bias, Cout, relu=relu, upsample=True)
+        ctx.relu, ctx.mode = bool(relu), mode
         ctx.save_for_backward(x_cl, weight, y if relu else None)
         ctx.has_bias = bias is not None
         ctx.in_dtype = x.dtype
@@ -614,18 +659,34 @@ class Conv3x3Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x_cl, weight, y = ctx.saved_tensors
+        mode = ctx.mode
         g = g.to(torch.bfloat16)
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)  # one pass: g * (y > 0)
         g = g.contiguous(memory_format=torch.channels_last)
         g_x = g_w = g_b = None
+        B, Cin, H, W = x_cl.shape
         if ctx.needs_input_grad[0]:
-            g_x = _conv3x3_call(g, _packed_conv_weight(weight, True), None, weight.shape[1], False).to(ctx.in_dtype)
+            wpd = _packed_conv_weight(weight, True)
+            if mode == "s1":
+                if _use_gemm_engine(B * H * W, Cin):
+                    g_x = conv3x3_gemm(g, wpd, None, Cin)
+                else:
+                    g_x = _conv3x3_call(g, wpd, None, Cin, False)
+            elif mode == "down":
+                g_x = conv3x3_gemm(g, wpd, None, Cin, stride=2, pad=0, transposed=True, out_hw=(H, W))
+            else:
+                g_up = conv3x3_gemm(g, wpd, None, Cin)                           # gradient w.r.t. the upsampled map (2H x 2W)
+                g_x = torch.empty_like(x_cl)
+                with torch.cuda.device(g.device):
+                    rc = _lib.lib().xq_sumpool2x2_nhwc_bf16(ptr(g_up), B, H, W, Cin, ptr(g_x), _stream(g))
+                check(rc, "xq_sumpool2x2_nhwc_bf16")
+            g_x = g_x.to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            g_w = conv3x3_weight_grad(x_cl, g, weight)
+            g_w = conv3x3_weight_grad(x_cl, g, weight, mode)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            g_b = g.float().sum((0, 2, 3))
-        return g_x, g_w, g_b, None
+            g_b = _channel_sum(g)
+        return g_x, g_w, g_b, None, None
 
 
 def conv3x3_small_cin_supported(x, weight, stride, padding):

@@ -217,6 +217,14 @@ int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B
 int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, int H, int W, int Cin, int Cout, float *dWp,
                                xq_stream_t stream);
 
+/* the same weight gradient for the other 3x3 geometries of the CNN encoder / decoder: X [B][Hi][Wi][Cin], dY [B][Ho][Wo][Cout];
+ * stride 2 / pad 0 = Downsample (xqgan_model.py:697-704, its (0,1,0,1) padding is the out-of-image zero), upsample2x = 1: the
+ * forward conv ran on the nearest-2x upsampled X (Upsample, :682-686). */
+int xq_conv3x3_wgrad_nhwc_bf16_ex(const void *X, const void *dY, int B, int Hi, int Wi, int Ho, int Wo, int Cin, int Cout, int stride, int pad,
+                                  int upsample2x, float *dWp, xq_stream_t stream);
+/* out [B][Ho][Wo][C] = sum over the 2 x 2 blocks of in [B][2 Ho][2 Wo][C] (bf16): the backward of nearest-2x upsampling */
+int xq_sumpool2x2_nhwc_bf16(const void *in, int B, int Ho, int Wo, int C, void *out, xq_stream_t stream);
+
 /* MaxPool2d(kernel_size=2, stride=2) of the VGG16 trunk (lpips.py:118-155), NHWC bf16, even input height/width:
  * X [B][2*Ho][2*Wo][C] -> Y [B][Ho][Wo][C]; the backward recomputes the arg-max from X (first maximum in row-major window
  * order, as ATen) and writes every element of GX [B][2*Ho][2*Wo][C].  C % 8 == 0. */

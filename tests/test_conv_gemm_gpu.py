@@ -72,3 +72,33 @@ def test_data_gradient_transposed_gather(stride, pad, pad_br):
     gx = od.conv3x3_gemm(g, wpd, None, Cin, stride=stride, pad=pad, transposed=True, out_hw=(H, W))
     absprod = torch.autograd.grad(F.conv2d(F.pad(xr, (pad, pad_br, pad, pad_br)), w16.abs(), None, stride=stride), xr, g.float().abs())[0]
     _check(gx, xr.grad, absprod)
+
+
+@pytest.mark.parametrize("mode", ["s1", "down", "up"])
+def test_conv3x3_fn_modes_forward_and_gradients(mode):
+    """Conv3x3Fn (s1 / Downsample / Upsample) vs autograd of the reference formulation in fp32 on the same bf16 operands"""
+    from imagefolder_amd import ops_dense as od
+    B, C, H, W, Cout = 16, 128, 64, 64, 256
+    torch.manual_seed(3)
+    x = torch.randn(B, C, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    w = (torch.randn(Cout, C, 3, 3, device="cuda") * 0.05).requires_grad_(True)
+    b = torch.randn(Cout, device="cuda").requires_grad_(True)
+    y = od.Conv3x3Fn.apply(x, w, b, False, mode)
+    xr = x.detach().float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    if mode == "s1":
+        ref = F.conv2d(xr, wr, br, padding=1)
+    elif mode == "down":
+        ref = F.conv2d(F.pad(xr, (0, 1, 0, 1)), wr, br, stride=2)
+    else:
+        ref = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, br, padding=1)
+    assert tuple(y.shape) == tuple(ref.shape)
+    g = torch.randn_like(ref).to(torch.bfloat16)
+    y.backward(g)
+    ref.backward(g.float())
+    for a, r, tol, name in ((y.detach().float(), ref.detach(), 1e-2, "y"), (x.grad.float(), xr.grad, 1.5e-2, "g_x"),
+                            (w.grad, wr.grad, 2e-3, "g_w"), (b.grad, br.grad, 2e-3, "g_b")):
+        scale = r.abs().max().item()
+        err = (a - r).abs().max().item()
+        assert err <= tol * scale, f"{mode} {name}: max err {err:.3e} vs scale {scale:.3e}"
