@@ -59,6 +59,13 @@ SIGNATURES = {
     "xq_conv3x3_wgrad_nhwc_bf16": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_wgrad_nhwc_bf16_ex": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp]),
     "xq_sumpool2x2_nhwc_bf16": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv3x3_from3_forward": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv3x3_to3_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_im2col27": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv3x3_to3_wgrad_blocks": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
+    "xq_conv3x3_to3_wgrad": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_row_softmax_forward": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
+    "xq_row_softmax_backward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_float, vp, vp]),
     "xq_maxpool2x2_nhwc_bf16_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_maxpool2x2_nhwc_bf16_backward": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_attn_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
@@ -91,6 +98,7 @@ SIGNATURES = {
     "xq_gemm_colpart_rows": (ctypes.c_size_t, [ctypes.c_int64]),
     "xq_gemm_bf16_nn_gelu_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int, vp]),
     "xq_conv3x3_gemm_bf16": (ctypes.c_int, [vp, vp, vp] + [ctypes.c_int] * 12 + [vp, ctypes.c_int, vp]),
+    "xq_gemm_bf16_batched": (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int] + [ctypes.c_int64] * 6 + [vp, vp]),
     "xq_gemm_bf16_tn": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_size_t, ctypes.c_int, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),
     "xq_prof_collect": (ctypes.c_int, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),

@@ -1,0 +1,321 @@
+// xq_convio.hip — the two 3-channel 3x3 convolutions at the ends of the CNN tokenizer (gfx950), bf16 arithmetic / fp32 accumulation.
+//
+//   conv_in  (xqgan_model.py:495: Conv2d(3, 128, 3, 1, 1) on the image)            K = 27:  6.9 kFLOP and 262 B per pixel
+//   conv_out (xqgan_model.py:584: Conv2d(128, 3, 3, 1, 1) producing the pixels)    N = 3:   the same, mirrored
+// Both are HBM-bound (SURVEY.md §8d names conv_in as the layer to report GB/s on): a 128-channel NHWC activation row is read
+// or written once per pixel; the matrix cores have nothing to contribute at 3 channels (an MFMA tile would be > 90 % padding).
+// One thread per pixel, the weights come in through SCALAR loads (uniform index -> s_load, an SGPR operand of every FMA):
+//   conv3x3_from3_kernel : planar 3-channel input [B][3][H][W] (fp32 image or bf16 gradient) -> NHWC bf16 [B][H][W][128]:
+//                          27 x 128 v_fmac with an SGPR weight per pixel (= the fp32 VALU time of the HBM traffic);
+//                          conv_in forward, and the data gradient of conv_out (same kernel on the rotated weights);
+//   conv3x3_to3_kernel   : NHWC bf16 [B][H][W][C] -> planar bf16 [B][3][H][W]: 9 x C/2 v_dot2c_f32_bf16 per output channel;
+//                          conv_out forward;
+//   im2col27_kernel      : the 27 (+5 zero) taps of every pixel as a [pixels][32] bf16 matrix: the weight gradient of conv_in is then
+//                          the split-K TN GEMM  g[pixels][128]^T . cols[pixels][32]  (xq_gemm_bf16_tn);
+//   conv3x3_to3_wgrad_kernel : weight gradient of conv_out: thread = (tap, 8-channel chunk), loops over the pixels of 16 image
+//                          rows, 24 fp32 accumulators, per-block partials summed by the caller (deterministic).
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "../../include/xq_ops.h"
+
+#include <hip/hip_bf16.h>
+
+using namespace xq;
+
+namespace {
+
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float round_bf16(float v) { return __bfloat162float(__float2bfloat16(v)); }
+__device__ __forceinline__ float ld_in(const float *p) { return round_bf16(*p); }          // autocast casts the image to bf16
+__device__ __forceinline__ float ld_in(const __hip_bfloat16 *p) { return __bfloat162float(*p); }
+__device__ __forceinline__ unsigned pack2(float a, float b) {
+    const f2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+
+
+// Wk: fp32 [27][128], k = (ky * 3 + kx) * 3 + ci (values already rounded to bf16); bias fp32 [128] or null
+template <typename TIN, int C3_OUT>
+__global__ __launch_bounds__(256) void conv3x3_from3_kernel(const TIN *__restrict__ X, const float *__restrict__ Wk, const float *__restrict__ bias,
+                                                            int B, int H, int W, __hip_bfloat16 *__restrict__ Y) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * H * W;
+    if (p >= total) return;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const long b = p / ((long)W * H);
+    float in[27];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+                in[(ky * 3 + kx) * 3 + ci] = ok ? ld_in(X + ((b * 3 + ci) * H + yy) * (long)W + xx) : 0.0f;
+        }
+    uint4 *out = reinterpret_cast<uint4 *>(Y + p * C3_OUT);
+#pragma unroll
+    for (int c0 = 0; c0 < C3_OUT; c0 += 32) {        // 32 accumulators at a time: 4 passes over the 27 taps
+        float acc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = bias ? bias[c0 + j] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k)
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(in[k], Wk[k * C3_OUT + c0 + j], acc[j]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            out[c0 / 8 + q] = make_uint4(pack2(acc[8 * q + 0], acc[8 * q + 1]), pack2(acc[8 * q + 2], acc[8 * q + 3]),
+                                         pack2(acc[8 * q + 4], acc[8 * q + 5]), pack2(acc[8 * q + 6], acc[8 * q + 7]));
+    }
+}
+
+// Wq: packed bf16 pairs [3][9][C / 2] as uint32; bias fp32 [3] or null; Y planar bf16 [B][3][H][W]
+__global__ __launch_bounds__(256) void conv3x3_to3_kernel(const __hip_bfloat16 *__restrict__ X, const unsigned *__restrict__ Wq,
+                                                          const float *__restrict__ bias, int B, int H, int W, int C,
+                                                          __hip_bfloat16 *__restrict__ Y) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * H * W;
+    if (p >= total) return;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const long b = p / ((long)W * H);
+    const int C2 = C / 2;
+    float a0 = bias ? bias[0] : 0.0f, a1 = bias ? bias[1] : 0.0f, a2 = bias ? bias[2] : 0.0f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+        if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+        const uint4 *row = reinterpret_cast<const uint4 *>(X + ((b * H + yy) * (long)W + xx) * C);
+        const unsigned *w0 = Wq + (0 * 9 + tap) * C2, *w1 = Wq + (1 * 9 + tap) * C2, *w2 = Wq + (2 * 9 + tap) * C2;
+        for (int j = 0; j < C / 8; ++j) {
+            const uint4 v = row[j];
+            const unsigned e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf2 xv = __builtin_bit_cast(bf2, e[q]);
+                a0 = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(bf2, w0[4 * j + q]), a0, false);
+                a1 = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(bf2, w1[4 * j + q]), a1, false);
+                a2 = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(bf2, w2[4 * j + q]), a2, false);
+            }
+        }
+    }
+    const long plane = (long)H * W, o = b * 3 * plane + (long)y * W + x;
+    Y[o] = __float2bfloat16(a0);
+    Y[o + plane] = __float2bfloat16(a1);
+    Y[o + 2 * plane] = __float2bfloat16(a2);
+}
+
+// cols[p][k] (bf16, k = (ky*3+kx)*3+ci for k < 27, zero for 27..31)
+template <typename TIN>
+__global__ __launch_bounds__(256) void im2col27_kernel(const TIN *__restrict__ X, int B, int H, int W, __hip_bfloat16 *__restrict__ cols) {
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * H * W;
+    if (p >= total) return;
+    const int x = (int)(p % W), y = (int)((p / W) % H);
+    const long b = p / ((long)W * H);
+    float in[32];
+#pragma unroll
+    for (int k = 27; k < 32; ++k) in[k] = 0.0f;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+#pragma unroll
+            for (int ci = 0; ci < 3; ++ci)
+                in[(ky * 3 + kx) * 3 + ci] = ok ? ld_in(X + ((b * 3 + ci) * H + yy) * (long)W + xx) : 0.0f;
+        }
+    uint4 *out = reinterpret_cast<uint4 *>(cols + p * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        out[q] = make_uint4(pack2(in[8 * q + 0], in[8 * q + 1]), pack2(in[8 * q + 2], in[8 * q + 3]), pack2(in[8 * q + 4], in[8 * q + 5]),
+                            pack2(in[8 * q + 6], in[8 * q + 7]));
+}
+
+// part[block][co][tap][c] += sum over this block's rows of g[b][co][y][x] * X[b][y+ky-1][x+kx-1][c]
+constexpr int WG3_ROWS = 16;
+template <typename TG>
+__global__ __launch_bounds__(288) void conv3x3_to3_wgrad_kernel(const __hip_bfloat16 *__restrict__ X, const TG *__restrict__ G, int B, int H, int W, int C,
+                                                                float *__restrict__ part) {
+    const int t = threadIdx.x, r = t % 144, half = t / 144;
+    const int tap = r / 16;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const long row0 = (long)blockIdx.x * WG3_ROWS;
+    const long rows = (long)B * H;
+    const long plane = (long)H * W;
+    for (int cc = (r % 16) * 8; cc < C; cc += 128) {           // 8-channel chunk(s) of this thread
+        float acc[3][8];
+#pragma unroll
+        for (int co = 0; co < 3; ++co)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[co][j] = 0.0f;
+        for (long rr = row0; rr < row0 + WG3_ROWS && rr < rows; ++rr) {
+            const long b = rr / H;
+            const int y = (int)(rr - b * H);
+            const int yy = y + ky - 1;
+            if (yy < 0 || yy >= H) continue;
+            const __hip_bfloat16 *xrow = X + ((b * H + yy) * (long)W) * C + cc;
+            const TG *g0 = G + b * 3 * plane + (long)y * W;
+            const int xb = half * (W / 2), xe = half ? W : W / 2;
+            for (int x = xb; x < xe; ++x) {
+                const int xx = x + kx - 1;
+                if (xx < 0 || xx >= W) continue;
+                const uint4 v = *reinterpret_cast<const uint4 *>(xrow + (long)xx * C);
+                const float ga = ld_in(g0 + x), gb = ld_in(g0 + plane + x), gc = ld_in(g0 + 2 * plane + x);
+                const unsigned e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float lo = __uint_as_float(e[q] << 16), hi = __uint_as_float(e[q] & 0xffff0000u);
+                    acc[0][2 * q] = __builtin_fmaf(ga, lo, acc[0][2 * q]); acc[0][2 * q + 1] = __builtin_fmaf(ga, hi, acc[0][2 * q + 1]);
+                    acc[1][2 * q] = __builtin_fmaf(gb, lo, acc[1][2 * q]); acc[1][2 * q + 1] = __builtin_fmaf(gb, hi, acc[1][2 * q + 1]);
+                    acc[2][2 * q] = __builtin_fmaf(gc, lo, acc[2][2 * q]); acc[2][2 * q + 1] = __builtin_fmaf(gc, hi, acc[2][2 * q + 1]);
+                }
+            }
+        }
+        // the two halves of the row share (tap, chunk): combine through LDS, fixed order
+        __shared__ float red[144][24];
+        if (half == 1) {
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) red[r][co * 8 + j] = acc[co][j];
+        }
+        __syncthreads();
+        if (half == 0) {
+            float *o = part + (size_t)blockIdx.x * 27 * C;
+#pragma unroll
+            for (int co = 0; co < 3; ++co)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[(co * 9 + tap) * C + cc + j] = acc[co][j] + red[r][co * 8 + j];
+        }
+        __syncthreads();
+    }
+}
+
+// row softmax of the AttnBlock scores (xqgan_model.py:652-653): s = bf16(S * scale) (the bf16 product of the bmm output with the
+// Python scalar), p = softmax(s) in fp32 (autocast runs softmax in fp32); p32 is kept for the backward, p16 feeds the second bmm
+__global__ __launch_bounds__(256) void row_softmax_fwd_kernel(const __hip_bfloat16 *__restrict__ S, long rows, int N, float scale,
+                                                              float *__restrict__ P32, __hip_bfloat16 *__restrict__ P16) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const __hip_bfloat16 *s = S + row * N;
+    float v[16];
+    float mx = -__builtin_inff();
+    const int per = N / 64;
+    for (int j = 0; j < per; ++j) {
+        v[j] = round_bf16(__bfloat162float(s[j * 64 + lane]) * scale);
+        mx = fmaxf(mx, v[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.0f;
+    for (int j = 0; j < per; ++j) { v[j] = expf(v[j] - mx); sum += v[j]; }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < per; ++j) {
+        const float p = v[j] * inv;
+        P32[row * N + j * 64 + lane] = p;
+        P16[row * N + j * 64 + lane] = __float2bfloat16(p);
+    }
+}
+
+// dS = bf16(bf16(p * (dP - sum_j p_j dP_j)) * scale)
+__global__ __launch_bounds__(256) void row_softmax_bwd_kernel(const float *__restrict__ P32, const __hip_bfloat16 *__restrict__ dP, long rows, int N,
+                                                              float scale, __hip_bfloat16 *__restrict__ dS) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float p[16], g[16];
+    float dot = 0.0f;
+    const int per = N / 64;
+    for (int j = 0; j < per; ++j) {
+        p[j] = P32[row * N + j * 64 + lane];
+        g[j] = __bfloat162float(dP[row * N + j * 64 + lane]);
+        dot = __builtin_fmaf(p[j], g[j], dot);
+    }
+    dot = wave_sum(dot);
+    for (int j = 0; j < per; ++j) dS[row * N + j * 64 + lane] = __float2bfloat16(round_bf16(p[j] * (g[j] - dot)) * scale);
+}
+
+}  // namespace
+
+extern "C" int xq_row_softmax_forward(const void *S, int64_t rows, int N, float scale, float *P32, void *P16, xq_stream_t stream) {
+    const char *fn = "xq_row_softmax_forward";
+    if (rows < 0 || N < 64 || N % 64 || N > 1024) return xq_set_error(XQ_EINVAL, "%s: N must be a multiple of 64, <= 1024", fn);
+    if (rows == 0) return XQ_OK;
+    if (!S || !P32 || !P16) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(row_softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)S, (long)rows, N,
+                       scale, P32, (__hip_bfloat16 *)P16);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_row_softmax_backward(const float *P32, const void *dP, int64_t rows, int N, float scale, void *dS, xq_stream_t stream) {
+    const char *fn = "xq_row_softmax_backward";
+    if (rows < 0 || N < 64 || N % 64 || N > 1024) return xq_set_error(XQ_EINVAL, "%s: N must be a multiple of 64, <= 1024", fn);
+    if (rows == 0) return XQ_OK;
+    if (!P32 || !dP || !dS) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(row_softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, P32, (const __hip_bfloat16 *)dP, (long)rows,
+                       N, scale, (__hip_bfloat16 *)dS);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, const float *w_kc, const float *bias, int B, int H, int W, int Cout,
+                                        void *y_nhwc, xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_from3_forward";
+    if (B < 0 || H < 1 || W < 1 || (Cout != 64 && Cout != 128)) return xq_set_error(XQ_EINVAL, "%s: bad shape (Cout 64 or 128)", fn);
+    if (B == 0) return XQ_OK;
+    if (!x_planar || !w_kc || !y_nhwc) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * H * W;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    __hip_bfloat16 *y = (__hip_bfloat16 *)y_nhwc;
+#define FROM3(T, CO) hipLaunchKernelGGL((conv3x3_from3_kernel<T, CO>), dim3(blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, y)
+    if (x_is_bf16) { if (Cout == 128) FROM3(__hip_bfloat16, 128); else FROM3(__hip_bfloat16, 64); }
+    else { if (Cout == 128) FROM3(float, 128); else FROM3(float, 64); }
+#undef FROM3
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_conv3x3_to3_forward(const void *x_nhwc, const void *w_pairs, const float *bias, int B, int H, int W, int C, void *y_planar,
+                                      xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_to3_forward";
+    if (B < 0 || H < 1 || W < 1 || C < 8 || C % 8) return xq_set_error(XQ_EINVAL, "%s: bad shape (C %% 8 == 0)", fn);
+    if (B == 0) return XQ_OK;
+    if (!x_nhwc || !w_pairs || !y_planar) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * H * W;
+    hipLaunchKernelGGL(conv3x3_to3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)x_nhwc,
+                       (const unsigned *)w_pairs, bias, B, H, W, C, (__hip_bfloat16 *)y_planar);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_im2col27(const void *x_planar, int x_is_bf16, int B, int H, int W, void *cols, xq_stream_t stream) {
+    const char *fn = "xq_im2col27";
+    if (B < 0 || H < 1 || W < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (B == 0) return XQ_OK;
+    if (!x_planar || !cols) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * H * W;
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_is_bf16) hipLaunchKernelGGL((im2col27_kernel<__hip_bfloat16>), dim3(blocks), dim3(256), 0, s, (const __hip_bfloat16 *)x_planar, B, H, W, (__hip_bfloat16 *)cols);
+    else hipLaunchKernelGGL((im2col27_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)x_planar, B, H, W, (__hip_bfloat16 *)cols);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_conv3x3_to3_wgrad_blocks(int B, int H) { return (int)(((long)B * H + WG3_ROWS - 1) / WG3_ROWS); }
+
+extern "C" int xq_conv3x3_to3_wgrad(const void *x_nhwc, const void *g_planar, int g_is_bf16, int B, int H, int W, int C, float *partials,
+                                    xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_to3_wgrad";
+    if (B < 0 || H < 1 || W < 2 || W % 2 || C < 8 || C % 128) return xq_set_error(XQ_EINVAL, "%s: bad shape (even W, C %% 128 == 0)", fn);
+    if (B == 0) return XQ_OK;
+    if (!x_nhwc || !g_planar || !partials) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const unsigned blocks = (unsigned)xq_conv3x3_to3_wgrad_blocks(B, H);
+    hipStream_t s = (hipStream_t)stream;
+    if (g_is_bf16) hipLaunchKernelGGL((conv3x3_to3_wgrad_kernel<__hip_bfloat16>), dim3(blocks), dim3(288), 0, s, (const __hip_bfloat16 *)x_nhwc, (const __hip_bfloat16 *)g_planar, B, H, W, C, partials);
+    else hipLaunchKernelGGL((conv3x3_to3_wgrad_kernel<float>), dim3(blocks), dim3(288), 0, s, (const __hip_bfloat16 *)x_nhwc, (const float *)g_planar, B, H, W, C, partials);
+    return xq_check_launch(fn);
+}

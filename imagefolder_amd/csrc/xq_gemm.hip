@@ -52,6 +52,8 @@ struct GemmArgs {
     int ktiles;             // 64-deep K tiles per split (split s < kt_rem runs one more)
     int kt_rem;
     int tiles_m, tiles_n, splits;
+    // batched products (simple schedule, blockIdx.y = batch index): element strides between consecutive matrices
+    long batch_a, batch_b, batch_c;
     // persistent schedule (gemm_pring_kernel): items [0, main_items) are whole tiles with the bf16 epilogue; the remaining
     // tail_tiles tiles are cut into tail_splits K ranges each, every range writing an fp32 slab [item][256][256] in `slabs`
     long main_items;
@@ -291,7 +293,7 @@ __device__ __forceinline__ bool tile_of_block(const GemmArgs &g, int BN, long &m
 // simple schedule: stage tile t+1, compute tile t, vmcnt(0) + barrier
 // =====================================================================================================================
 template <int AK, int BK, int BN, int EPI>
-__global__ __launch_bounds__(GT) void gemm_simple_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(GT) void gemm_simple_kernel(const GemmArgs g0) {
     constexpr int NFJ = BN / 128;            // 32-wide column fragments per wave (2 or 1)
     constexpr int WTN = BN / 4;
     constexpr int NPB = 2 + NFJ;             // pieces of B... A-top, A-bottom, B-left (, B-right)
@@ -301,7 +303,13 @@ __global__ __launch_bounds__(GT) void gemm_simple_kernel(const GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     long m0, n0, split;
-    if (!tile_of_block(g, BN, m0, n0, split)) return;
+    if (!tile_of_block(g0, BN, m0, n0, split)) return;
+    GemmArgs g = g0;
+    if (gridDim.y > 1) {     // batched: matrix blockIdx.y
+        g.A += (long)blockIdx.y * g0.batch_a * 2;
+        g.B += (long)blockIdx.y * g0.batch_b * 2;
+        g.C += (long)blockIdx.y * g0.batch_c * (EPI == EPI_BF16 ? 2 : 4);
+    }
     const long k0 = (split * (long)g.ktiles + (split < g.kt_rem ? split : g.kt_rem)) * gm::BKT;
     const int KT = g.ktiles + (split < g.kt_rem ? 1 : 0);
 
@@ -1137,4 +1145,46 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     g.cv_transposed = transposed ? 1 : 0;
     return launch_gemm<gm::KMAJOR_CONV, gm::KMAJOR, EPI_BF16>(g, BN, impl, nullptr, 0, (hipStream_t)stream, fn, 2.0 * (double)M * (double)K * Cout,
                                                               XQ_PROF_CONV3X3);
+}
+
+// ---- batched small products (simple schedule; one launch for `batch` independent matrices): the single-head spatial attention of
+//      the CNN AttnBlock (xqgan_model.py:646-656) is five of them per direction -----------------------------------------------------
+extern "C" int xq_gemm_bf16_batched(int op, const void *a, const void *b, int batch, int64_t M, int64_t N, int64_t K, int64_t stride_a,
+                                    int64_t stride_b, int64_t stride_c, void *c, xq_stream_t stream) {
+    const char *fn = "xq_gemm_bf16_batched";
+    if (batch < 0 || M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
+    if (batch == 0 || M == 0 || N == 0) return XQ_OK;
+    if (!a || !b || !c) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (K < 64 || K % 64 || N % 8 || N < 32 || (op == XQ_GEMM_OP_TN && (M % 8 || M < 32)))
+        return xq_set_error(XQ_EINVAL, "%s: needs K %% 64 == 0, N (and M for TN) %% 8 == 0 and >= 32 (N=%ld K=%ld)", fn, (long)N, (long)K);
+    if (batch > 65535) return xq_set_error(XQ_EINVAL, "%s: batch > 65535", fn);
+    const int BN = pick_bn(N);
+    GemmArgs g{};
+    g.nt_store = 1;
+    g.A = (const char *)a; g.B = (const char *)b; g.C = (char *)c;
+    g.M = M; g.N = N; g.ldc = N;
+    g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
+    g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + BN - 1) / BN);
+    g.batch_a = stride_a; g.batch_b = stride_b; g.batch_c = stride_c;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(g.tiles_m * g.tiles_n), (unsigned)batch);
+    const int lds = (BN == 256 ? 8 : 6) * gm::PIECE_BYTES;
+    const int pslot = prof_begin(XQ_PROF_GEMM, 2.0 * batch * (double)M * (double)N * (double)K, s);
+#define BATCHED(AKK, BKK, EPII)                                                                                                     \
+    do {                                                                                                                             \
+        if (BN == 256) {                                                                                                             \
+            if (set_lds<gemm_simple_kernel<AKK, BKK, 256, EPII>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn); \
+            hipLaunchKernelGGL((gemm_simple_kernel<AKK, BKK, 256, EPII>), grid, dim3(GT), lds, s, g);                                \
+        } else {                                                                                                                     \
+            if (set_lds<gemm_simple_kernel<AKK, BKK, 128, EPII>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn); \
+            hipLaunchKernelGGL((gemm_simple_kernel<AKK, BKK, 128, EPII>), grid, dim3(GT), lds, s, g);                                \
+        }                                                                                                                            \
+    } while (0)
+    if (op == XQ_GEMM_OP_NT) { g.lda = K; g.ldb = K; BATCHED(gm::KMAJOR, gm::KMAJOR, EPI_BF16); }
+    else if (op == XQ_GEMM_OP_NN) { g.lda = K; g.ldb = N; BATCHED(gm::KMAJOR, gm::KSTRIDED, EPI_BF16); }
+    else if (op == XQ_GEMM_OP_TN) { g.lda = M; g.ldb = N; BATCHED(gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB); }
+    else return xq_set_error(XQ_EINVAL, "%s: unknown op", fn);
+#undef BATCHED
+    prof_end(pslot, s);
+    return xq_check_launch(fn);
 }

@@ -147,7 +147,12 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
             IMPL["conv2d"] = "hip (3x3 s1 p1, C % 64 == 0: fwd + data grad) + library (rest, weight grad)"
             return ops_dense.Conv3x3Fn.apply(x, weight, bias, relu)
         if ops_dense.conv3x3_small_cin_supported(x, weight, stride, padding):
+            IMPL["conv2d_from_rgb"] = "hip (conv3x3_from3_kernel; dgrad conv3x3_to3_kernel; wgrad im2col27 + TN GEMM)"
             return ops_dense.Conv3x3SmallCinFn.apply(x, weight, bias, relu)
+        if ops_dense.conv3x3_to3_supported(x, weight, stride, padding) and x.shape[1] in (64, 128):
+            IMPL["conv2d_to_rgb"] = "hip (conv3x3_to3_kernel; dgrad conv3x3_from3_kernel; wgrad conv3x3_to3_wgrad_kernel)"
+            y = ops_dense.Conv3x3ToRgbFn.apply(x, weight, bias)
+            return torch.relu(y) if relu else y
         if tuple(weight.shape[2:]) == (1, 1) and stride == 1 and padding == 0 and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 \
                 and weight.shape[0] >= 32:
             # 1x1 conv = a GEMM over the channel axis of the channels-last map (nin_shortcut, AttnBlock q / k / v / proj_out)
@@ -212,6 +217,11 @@ def spatial_attention(q, k, v):
     if q.is_cuda and ops_f32.eligible(q, k, v):
         IMPL["spatial_attention_fp32_inference"] = "hip (xq_attention_f32)"
         return ops_f32.spatial_attention(q, k, v)
+    if q.is_cuda:
+        from . import ops_dense
+        if ops_dense.spatial_attention_supported(q):
+            IMPL["spatial_attention"] = "hip (batched MFMA GEMMs + row softmax kernels, fwd + bwd)"
+            return ops_dense.SpatialAttentionFn.apply(q, k, v)
     b, c, hh, ww = q.shape
     qq = q.reshape(b, c, hh * ww).permute(0, 2, 1)
     w_ = F.softmax(torch.bmm(qq, k.reshape(b, c, hh * ww)) * (int(c) ** (-0.5)), dim=2)

@@ -689,47 +689,192 @@ class Conv3x3Fn(torch.autograd.Function):
         return g_x, g_w, g_b, None, None
 
 
+# ---- the 3-channel convolutions (csrc/xq_convio.hip): conv_in / conv_out of the CNN tokenizer, conv1_1 of the VGG16 trunk -------------
+def _planar(t):
+    """(B, 3, H, W) tensor as a contiguous planar buffer of fp32 or bf16"""
+    t = t.detach()
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        t = t.float()
+    return t.contiguous()
+
+
+def _from3(x_planar, w_kc, bias, Cout):
+    B, _, H, W = x_planar.shape
+    y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=x_planar.device)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    with torch.cuda.device(x_planar.device):
+        rc = _lib.lib().xq_conv3x3_from3_forward(ptr(x_planar), int(x_planar.dtype == torch.bfloat16), ptr(w_kc), ptr(b32), B, H, W, Cout, ptr(y),
+                                                 _stream(x_planar))
+    check(rc, "xq_conv3x3_from3_forward")
+    return y.permute(0, 3, 1, 2)
+
+
+def _to3(x_cl, w_pairs, bias):
+    B, C, H, W = x_cl.shape
+    y = torch.empty(B, 3, H, W, dtype=torch.bfloat16, device=x_cl.device)
+    b32 = None if bias is None else bias.detach().float().contiguous()
+    with torch.cuda.device(x_cl.device):
+        rc = _lib.lib().xq_conv3x3_to3_forward(ptr(x_cl), ptr(w_pairs), ptr(b32), B, H, W, C, ptr(y), _stream(x_cl))
+    check(rc, "xq_conv3x3_to3_forward")
+    return y
+
+
+def _w16f(weight):
+    return weight.detach().to(torch.bfloat16).float()
+
+
 def conv3x3_small_cin_supported(x, weight, stride, padding):
-    """first-layer convs (Cin = 3): forward on the library conv, data gradient on the hand-written kernel with the input
-    channels zero-padded to 64 (MIOpen's bwd-data solver for Cin = 3 takes 27 ms at 128 x 256 x 256: profiles/r01)."""
+    """3 -> 64 / 128 channel 3x3 convs (conv_in of the CNN encoder, conv1_1 of the VGG16 trunk)"""
     return (x.is_cuda and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and padding == 1
-            and weight.shape[1] < 64 and weight.shape[0] % 64 == 0 and x.requires_grad)
+            and weight.shape[1] == 3 and weight.shape[0] in (64, 128))
 
 
 class Conv3x3SmallCinFn(torch.autograd.Function):
+    """y = [relu](conv3x3(x, W) + b) for a 3-channel input: forward on conv3x3_from3_kernel (planar image in, NHWC bf16 out), data
+    gradient on conv3x3_to3_kernel with the rotated weights, weight gradient = im2col27 + the split-K TN GEMM."""
+
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        x_cl = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
-        w16 = weight.detach().to(torch.bfloat16)
-        y = F.conv2d(x_cl, w16, None if bias is None else bias.detach().to(torch.bfloat16), stride=1, padding=1)
+        xp = _planar(x)
+        Cout = weight.shape[0]
+        w_kc = _w16f(weight).permute(2, 3, 1, 0).reshape(27, Cout).contiguous()          # [(ky*3+kx)*3+ci][co]
+        y = _from3(xp, w_kc, bias, Cout)
         if relu:
             y = torch.relu_(y)
         ctx.relu = bool(relu)
-        ctx.save_for_backward(x_cl, weight, y if relu else None)
+        ctx.save_for_backward(xp, weight, y if relu else None)
         ctx.has_bias = bias is not None
         ctx.in_dtype = x.dtype
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x_cl, weight, y = ctx.saved_tensors
+        xp, weight, y = ctx.saved_tensors
         g = g.to(torch.bfloat16)
         if ctx.relu:
             g = torch.ops.aten.threshold_backward(g, y, 0)
         g = g.contiguous(memory_format=torch.channels_last)
         g_x = g_w = g_b = None
-        Cin = weight.shape[1]
+        Cout = weight.shape[0]
+        B, _, H, W = xp.shape
         if ctx.needs_input_grad[0]:
-            wp = _packed_conv_weight(weight, True)
-            g_x = _conv3x3_call(g, wp, None, wp.shape[0], False)[:, :Cin].to(ctx.in_dtype)
-            # the kernel ran with the Cin input channels zero-padded to wp.shape[0]: only the un-padded flops are algorithmic
-            Bn, _, Hh, Ww = g.shape
-            _lib.lib().xq_prof_add_work(1, -2.0 * Bn * Hh * Ww * 9.0 * weight.shape[0] * (wp.shape[0] - Cin))
+            # g_x[ci] = sum_{tap, co} g[co] (shifted) W[co][ci][2-ky][2-kx]: a C -> 3 conv with w'[ci][tap][co]
+            wq = weight.detach().flip(2, 3).permute(1, 2, 3, 0).reshape(3, 9, Cout).to(torch.bfloat16).contiguous()
+            g_x = _to3(g, wq, None).to(ctx.in_dtype)
         if ctx.needs_input_grad[1]:
-            g_w = conv3x3_weight_grad(x_cl, g, weight)
+            cols = torch.empty(B * H * W, 32, dtype=torch.bfloat16, device=xp.device)
+            with torch.cuda.device(xp.device):
+                rc = _lib.lib().xq_im2col27(ptr(xp), int(xp.dtype == torch.bfloat16), B, H, W, ptr(cols), _stream(xp))
+            check(rc, "xq_im2col27")
+            d32 = gemm_tn(g.permute(0, 2, 3, 1).reshape(B * H * W, Cout), cols)               # [Cout][32]
+            g_w = d32[:, :27].reshape(Cout, 3, 3, 3).permute(0, 3, 1, 2).to(weight.dtype)      # [co][ky][kx][ci] -> [co][ci][ky][kx]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            g_b = g.float().sum((0, 2, 3))
+            g_b = _channel_sum(g)
         return g_x, g_w, g_b, None
+
+
+def conv3x3_to3_supported(x, weight, stride, padding):
+    """C -> 3 channel 3x3 conv (conv_out of the CNN decoder)"""
+    return (x.is_cuda and x.dim() == 4 and tuple(weight.shape[2:]) == (3, 3) and stride == 1 and padding == 1 and weight.shape[0] == 3
+            and weight.shape[1] % 128 == 0 and x.shape[3] % 2 == 0)
+
+
+class Conv3x3ToRgbFn(torch.autograd.Function):
+    """y (B, 3, H, W) = conv3x3(x, W) + b for a 3-channel output: forward on conv3x3_to3_kernel, data gradient on conv3x3_from3_kernel with
+    the rotated weights, weight gradient on conv3x3_to3_wgrad_kernel (per-block partials, summed in a fixed order)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x_cl = x.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        C = weight.shape[1]
+        wq = weight.detach().permute(0, 2, 3, 1).reshape(3, 9, C).to(torch.bfloat16).contiguous()
+        y = _to3(x_cl, wq, bias)
+        ctx.save_for_backward(x_cl, weight)
+        ctx.has_bias = bias is not None
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x_cl, weight = ctx.saved_tensors
+        gp = _planar(g)
+        B, C, H, W = x_cl.shape
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            # g_x[ci] = sum_{tap', co} g[co](y + ky' - 1, x + kx' - 1) W[co][ci][2-ky'][2-kx']: a 3 -> C conv with w_kc[(tap')*3+co][ci]
+            w_kc = _w16f(weight).flip(2, 3).permute(2, 3, 0, 1).reshape(27, C).contiguous()
+            if C in (64, 128):
+                g_x = _from3(gp, w_kc, None, C).to(ctx.in_dtype)
+            else:
+                raise XqError(f"conv_out data gradient: {C} input channels (kernel instantiated for 64 / 128)")
+        if ctx.needs_input_grad[1]:
+            nb = _lib.lib().xq_conv3x3_to3_wgrad_blocks(B, H)
+            part = torch.empty(nb, 3, 9, C, dtype=torch.float32, device=x_cl.device)
+            with torch.cuda.device(x_cl.device):
+                rc = _lib.lib().xq_conv3x3_to3_wgrad(ptr(x_cl), ptr(gp), int(gp.dtype == torch.bfloat16), B, H, W, C, ptr(part), _stream(x_cl))
+            check(rc, "xq_conv3x3_to3_wgrad")
+            g_w = part.sum(0).reshape(3, 3, 3, C).permute(0, 3, 1, 2).to(weight.dtype)         # [co][ky][kx][ci] -> [co][ci][ky][kx]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            g_b = gp.float().sum((0, 2, 3))
+        return g_x, g_w, g_b
+
+
+# ---- single-head spatial attention of the CNN AttnBlock (xqgan_model.py:646-656) on batched GEMMs + row softmax ---------------------
+def _bgemm(op, a, b, batch, M, N, K, sa, sb, out_dtype):
+    c = torch.empty(batch, M, N, dtype=out_dtype, device=a.device)
+    with torch.cuda.device(a.device):
+        rc = _lib.lib().xq_gemm_bf16_batched(op, ptr(a), ptr(b), batch, M, N, K, sa, sb, M * N, ptr(c), _stream(a))
+    check(rc, "xq_gemm_bf16_batched")
+    return c
+
+
+def spatial_attention_supported(q):
+    B, C, H, W = q.shape
+    n = H * W
+    return (q.is_cuda and (q.dtype == torch.bfloat16 or torch.is_autocast_enabled("cuda")) and C % 64 == 0 and n % 64 == 0 and 64 <= n <= 1024
+            and B <= 65535)
+
+
+class SpatialAttentionFn(torch.autograd.Function):
+    """h = v . softmax(q^T k * C^-1/2)^T over the H*W positions of one image (AttnBlock, xqgan_model.py:646-656), token-major:
+    S = Q K^T (batched NT), P = row softmax, O = P V (batched NN); backward: dP = dO V^T (NT), dV = P^T dO (TN), dS = softmax', dQ = dS K
+    (NN), dK = dS^T Q (TN).  Roundings follow the reference under autocast: bf16 products, the scale applied to the bf16 scores, fp32
+    softmax."""
+
+    @staticmethod
+    def forward(ctx, q, k, v):
+        B, C, H, W = q.shape
+        N = H * W
+        tok = lambda t: t.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(B, N, C)
+        Q, K, V = tok(q), tok(k), tok(v)
+        scale = float(int(C) ** (-0.5))
+        S = _bgemm(0, Q, K, B, N, N, C, N * C, N * C, torch.bfloat16)                 # [B][N(q)][N(k)]
+        P32 = torch.empty(B, N, N, dtype=torch.float32, device=q.device)
+        P16 = torch.empty(B, N, N, dtype=torch.bfloat16, device=q.device)
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().xq_row_softmax_forward(ptr(S), B * N, N, ctypes.c_float(scale), ptr(P32), ptr(P16), _stream(q))
+        check(rc, "xq_row_softmax_forward")
+        O = _bgemm(1, P16, V, B, N, C, N, N * N, N * C, torch.bfloat16)               # [B][N][C]
+        ctx.save_for_backward(Q, K, V, P32, P16)
+        ctx.meta = (B, C, H, W, scale, q.dtype)
+        return O.view(B, H, W, C).permute(0, 3, 1, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        Q, K, V, P32, P16 = ctx.saved_tensors
+        B, C, H, W, scale, in_dtype = ctx.meta
+        N = H * W
+        dO = g.detach().to(torch.bfloat16).contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(B, N, C)
+        dP = _bgemm(0, dO, V, B, N, N, C, N * C, N * C, torch.bfloat16)
+        dV = _bgemm(2, P16, dO, B, N, C, N, N * N, N * C, torch.float32)
+        dS = torch.empty(B, N, N, dtype=torch.bfloat16, device=g.device)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().xq_row_softmax_backward(ptr(P32), ptr(dP), B * N, N, ctypes.c_float(scale), ptr(dS), _stream(g))
+        check(rc, "xq_row_softmax_backward")
+        dQ = _bgemm(1, dS, K, B, N, C, N, N * N, N * C, torch.bfloat16)
+        dK = _bgemm(2, dS, Q, B, N, C, N, N * N, N * C, torch.float32)
+        back = lambda t: t.view(B, H, W, C).permute(0, 3, 1, 2).to(in_dtype)
+        return back(dQ), back(dK), back(dV)
 
 
 # ---- DinoDisc heads (csrc/xq_disc.hip) ------------------------------------------------------------------------------------

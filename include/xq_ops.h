@@ -225,6 +225,32 @@ int xq_conv3x3_wgrad_nhwc_bf16_ex(const void *X, const void *dY, int B, int Hi, 
 /* out [B][Ho][Wo][C] = sum over the 2 x 2 blocks of in [B][2 Ho][2 Wo][C] (bf16): the backward of nearest-2x upsampling */
 int xq_sumpool2x2_nhwc_bf16(const void *in, int B, int Ho, int Wo, int C, void *out, xq_stream_t stream);
 
+/* ---- the 3-channel 3x3 convolutions at the ends of the CNN tokenizer / at the mouth of the VGG16 trunk (csrc/xq_convio.hip):
+ *      HBM-bound, one thread per pixel, weights through scalar loads; bf16 arithmetic, fp32 accumulation. -------------------------- */
+/* y [B][H][W][Cout] bf16 (NHWC) = conv3x3(x planar [B][3][H][W], fp32 or bf16; pad 1) + bias; w_kc fp32 [27][Cout],
+ * row k = (ky * 3 + kx) * 3 + ci, values rounded to bf16 by the caller.  Cout 64 or 128.  conv_in (xqgan_model.py:495), VGG conv1_1
+ * (lpips.py:118-155), and — on rotated weights — the data gradient of conv_out. */
+int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, const float *w_kc, const float *bias, int B, int H, int W, int Cout,
+                             void *y_nhwc, xq_stream_t stream);
+/* y planar [B][3][H][W] bf16 = conv3x3(x [B][H][W][C] bf16 NHWC; pad 1) + bias; w_pairs = bf16 [3][9][C] (tap = ky * 3 + kx).
+ * conv_out (xqgan_model.py:584) and — on rotated weights — the data gradient of conv_in / VGG conv1_1.  C % 8 == 0. */
+int xq_conv3x3_to3_forward(const void *x_nhwc, const void *w_pairs, const float *bias, int B, int H, int W, int C, void *y_planar,
+                           xq_stream_t stream);
+/* cols [B*H*W][32] bf16: the 27 taps (k as above) of every pixel + 5 zeros; with it the weight gradient of a 3 -> Cout conv is
+ * xq_gemm_bf16_tn(g [pixels][Cout], cols). */
+int xq_im2col27(const void *x_planar, int x_is_bf16, int B, int H, int W, void *cols, xq_stream_t stream);
+/* weight gradient of a C -> 3 conv: partials fp32 [xq_conv3x3_to3_wgrad_blocks(B, H)][3][9][C], to be summed over the first axis
+ * (fixed order: deterministic).  g planar [B][3][H][W] (bf16 or fp32).  W even, C % 128 == 0. */
+int xq_conv3x3_to3_wgrad_blocks(int B, int H);
+int xq_conv3x3_to3_wgrad(const void *x_nhwc, const void *g_planar, int g_is_bf16, int B, int H, int W, int C, float *partials,
+                         xq_stream_t stream);
+
+/* row softmax of the AttnBlock scores (xqgan_model.py:652-653): p = softmax(bf16(S * scale)) over the N columns, fp32 (P32, kept for
+ * the backward) and bf16 (P16, the operand of the second product); backward: dS = bf16(bf16(p * (dP - <p, dP>)) * scale).
+ * S, dP, P16, dS bf16 [rows][N]; N % 64 == 0, N <= 1024. */
+int xq_row_softmax_forward(const void *S, int64_t rows, int N, float scale, float *P32, void *P16, xq_stream_t stream);
+int xq_row_softmax_backward(const float *P32, const void *dP, int64_t rows, int N, float scale, void *dS, xq_stream_t stream);
+
 /* MaxPool2d(kernel_size=2, stride=2) of the VGG16 trunk (lpips.py:118-155), NHWC bf16, even input height/width:
  * X [B][2*Ho][2*Wo][C] -> Y [B][Ho][Wo][C]; the backward recomputes the arg-max from X (first maximum in row-major window
  * order, as ATen) and writes every element of GX [B][2*Ho][2*Wo][C].  C % 8 == 0. */
@@ -356,6 +382,11 @@ int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int6
  * Cin % 64 == 0, Cout % 8 == 0, Cout >= 64. */
 int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int Ho, int Wo,
                          int stride, int pad, int upsample2x, int transposed, int relu, void *y, int impl, xq_stream_t stream);
+/* `batch` independent products in one launch (matrix i at a + i * stride_a etc., strides in elements): op NT / NN write bf16
+ * c[M][N], op TN (a [K][M], b [K][N], K % 64 == 0) writes fp32 c[M][N].  Used by the single-head spatial attention of the CNN
+ * AttnBlock (xqgan_model.py:646-656: 256 positions x 512 channels per image). */
+int xq_gemm_bf16_batched(int op, const void *a, const void *b, int batch, int64_t M, int64_t N, int64_t K, int64_t stride_a,
+                         int64_t stride_b, int64_t stride_c, void *c, xq_stream_t stream);
 /* weight gradient: g_w[P][Q] (fp32) = g_y[R][P]^T . x[R][Q], the token axis R split over the chip into fp32 slabs in
  * `workspace` that a second kernel sums in a fixed order (deterministic, no atomics).
  * P, Q multiples of 8 and >= 32; any R >= 0. */
