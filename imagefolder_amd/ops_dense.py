@@ -617,12 +617,23 @@ def _channel_sum(g_cl):
     rows = B * H * W
     if C % 8:
         return g_cl.float().sum((0, 2, 3))
-    g2 = g_cl.permute(0, 2, 3, 1).reshape(rows, C)
-    out = torch.empty(C, dtype=torch.float32, device=g_cl.device)
+    # the column-sum kernel wants wide rows (one thread per 8 columns): view r consecutive pixels as one row of r * C columns
+    r = 1
+    while r * C < 2048 and rows % (2 * r) == 0:
+        r *= 2
+    if r > 1:
+        wide = _channel_sum_rows(g_cl.permute(0, 2, 3, 1).reshape(rows // r, r * C))
+        return wide.view(r, C).sum(0)
+    return _channel_sum_rows(g_cl.permute(0, 2, 3, 1).reshape(rows, C))
+
+
+def _channel_sum_rows(g2):
+    rows, C = g2.shape
+    out = torch.empty(C, dtype=torch.float32, device=g2.device)
     nb = _lib.lib().xq_row_partials_blocks(rows * 4)
-    part = torch.empty(nb * C, dtype=torch.float32, device=g_cl.device)
-    with torch.cuda.device(g_cl.device):
-        rc = _lib.lib().xq_colsum(ptr(g2), rows, C, 1, ptr(out), 0, ptr(part), _stream(g_cl))
+    part = torch.empty(nb * C, dtype=torch.float32, device=g2.device)
+    with torch.cuda.device(g2.device):
+        rc = _lib.lib().xq_colsum(ptr(g2), rows, C, 1, ptr(out), 0, ptr(part), _stream(g2))
     check(rc, "xq_colsum")
     return out
 
