@@ -103,7 +103,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const short *__restric
     const short *base = qkv + (long)b * N * RS + h * 64;
     const short *kbase = base + H * 64, *vbase = base + 2 * H * 64;
 
-    const int qn = qb * 128 + wave * 32 + li;
+    // the block's four 32-query groups rotate over the waves (= SIMDs) with the (batch, head) index: N = 128 j + 1 (class
+    // token) leaves a block with ONE live group per (batch, head), which would otherwise always load SIMD 0
+    const int wq = (wave + g) & 3;
+    const int qn = qb * 128 + wq * 32 + li;
     const int qc = qn < N ? qn : N - 1;
     bf16x8 qf0, qf1, qf2, qf3;
     {
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const short *__restric
     // rare wave-uniform branch); the row sums come out of the matrix pipe (ones x P^T) instead of 32 VALU adds per tile.
     float m_run = -INFINITY, l_run = 0.0f;
     const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-    const bool wave_live = qb * 128 + wave * 32 < N;   // waves whose 32 queries are all padding only help with staging
+    const bool wave_live = qb * 128 + wq * 32 < N;   // waves whose 32 queries are all padding only help with staging
 
     const int ntiles = (N + 63) / 64;
     FW_LOAD(0)
@@ -297,7 +300,8 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__rest
     const short *kbase = base + H * 64, *vbase = base + 2 * H * 64;
     const float c = scale * 1.4426950408889634f;
 
-    const int qn = qb * 128 + wave * 32 + li;
+    const int wq = (wave + g) & 3;      // query groups rotate over the SIMDs (see attn_fwd_kernel)
+    const int qn = qb * 128 + wq * 32 + li;
     const int qc = qn < N ? qn : N - 1;
     bf16x8 qf0, qf1, qf2, qf3, df0, df1, df2, df3;
     {
@@ -337,7 +341,7 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__rest
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
 
-    const bool wave_live = qb * 128 + wave * 32 < N;   // waves whose 32 queries are all padding only help with staging
+    const bool wave_live = qb * 128 + wq * 32 < N;   // waves whose 32 queries are all padding only help with staging
     const int ntiles = (N + 63) / 64;
     DQ_LOAD(0)
     DQ_STORE(0)
@@ -434,8 +438,9 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(const short *__re
     const float *lseb = lse + ((long)b * H + h) * N, *delb = delta + ((long)b * H + h) * N;
     const float c = scale * 1.4426950408889634f;
 
-    const int kn = kb * 128 + wave * 32 + li;
-    const bool wave_live = kb * 128 + wave * 32 < N;   // waves whose 32 keys are all padding only help with staging
+    const int wk = (wave + g) & 3;      // key groups rotate over the SIMDs (see attn_fwd_kernel)
+    const int kn = kb * 128 + wk * 32 + li;
+    const bool wave_live = kb * 128 + wk * 32 < N;   // waves whose 32 keys are all padding only help with staging
     bf16x8 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
     {
         const bool ok = kn < N;

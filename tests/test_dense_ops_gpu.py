@@ -211,7 +211,8 @@ def _attn_ref(qkv, H):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,N,H", [(2, 513, 12), (3, 197, 6), (1, 64, 1), (2, 1, 2), (1, 129, 3), (5, 257, 12)])
+@pytest.mark.parametrize("B,N,H", [(2, 513, 12), (3, 197, 6), (1, 64, 1), (2, 1, 2), (1, 129, 3), (5, 257, 12), (2, 65, 2), (1, 769, 4),
+                                   (2, 128, 1), (1, 379, 6), (2, 63, 1), (1, 2, 1)])
 def test_attention_forward_backward(B, N, H):
     from imagefolder_amd import ops_dense
     torch.manual_seed(B * 1000 + N)
