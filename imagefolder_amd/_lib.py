@@ -25,8 +25,9 @@ SIGNATURES = {
                                  vp, ctypes.c_size_t, vp]),
     "xq_vq_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_size_t, vp]),
+    "xq_vq_backward_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "xq_vq_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp,
-                                      vp, vp, vp, ctypes.c_float, vp, vp, vp]),
+                                      vp, vp, vp, ctypes.c_float, vp, vp, vp, ctypes.c_size_t, vp]),
     "xq_perturb_workspace_bytes": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int, ctypes.c_int]),
     "xq_perturb_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int, vp, vp, vp, vp, ctypes.c_size_t, vp]),

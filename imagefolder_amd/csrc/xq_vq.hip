@@ -428,59 +428,160 @@ __global__ __launch_bounds__(256) void reduce_partials_kernel(const float *__res
 
 // ------------------------------------------------------------------------------------------------
 // backward of VectorQuantizer.forward (SURVEY §8a "Backward structure")
+//
+// g_z is token-parallel.  The codebook gradient g_E[v] = sum over the tokens that chose code v of their row ge[n] is a
+// scatter-reduce; it is done WITHOUT floating-point atomics so that the result is deterministic (bit-identical from run to run):
+//   pass 1 (this kernel, one block = one chunk of 256 consecutive tokens): the rows ge[n][C] are staged in LDS; every token
+//           finds the next token of the chunk with the same code (an LDS broadcast scan) and whether it is the first of its
+//           code; each first token heads a chain that is summed in ascending token order, C lanes per chain (one per
+//           channel), into partial[chunk][slot][C]; first[chunk][code] = slot + 1 (table zeroed by a memset node);
+//   pass 2 (vq_codebook_grad_kernel): 4 lanes per code walk the chunks in ascending order (a quarter each) and add the
+//           chunk partials; the four sums meet in a fixed order.
+// A collapsed codebook (all tokens on a few codes) costs 256 sequential adds per channel lane in pass 1 and <= nchunks rows
+// per code in pass 2 — no contention, unlike atomics.
 // ------------------------------------------------------------------------------------------------
+static constexpr int BWD_CHUNK = 256;
+
 template <int C, bool NORMED>
 __global__ __launch_bounds__(256) void vq_backward_kernel(const float *__restrict__ z, long N, int HW,
-                                                          const float *__restrict__ E,
+                                                          const float *__restrict__ E, int V,
                                                           const int64_t *__restrict__ idx_in,
                                                           const float *__restrict__ g_out,
                                                           const float *__restrict__ g_vq,
                                                           const float *__restrict__ g_commit, float beta,
-                                                          float *__restrict__ g_z, float *__restrict__ g_E) {
-    const long n = (long)blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const float inv = 1.0f / ((float)N * (float)C);
-    const float cc = (g_commit ? g_commit[0] : 0.0f) * beta * 2.0f * inv;  // commit: d/dzhat of beta*mean((sg(eh)-zh)^2)
-    const float cv = (g_vq ? g_vq[0] : 0.0f) * 2.0f * inv;                 // vq:     d/dehat of mean((eh-sg(zh))^2)
-    const long idx = idx_in[n];
-    const long b = n / HW;
-    const int hw = (int)(n - b * HW);
-    const size_t off = (size_t)b * C * HW + hw;
-    float x[C], zh[C], e[C], eh[C];
-#pragma unroll
-    for (int k = 0; k < C; ++k) x[k] = z[off + (size_t)k * HW];
-    const float4 *row = reinterpret_cast<const float4 *>(E + (size_t)idx * C);
-#pragma unroll
-    for (int q = 0; q < C / 4; ++q) {
-        float4 v = row[q];
-        e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+                                                          float *__restrict__ g_z, float *__restrict__ partial,
+                                                          unsigned short *__restrict__ first) {
+    extern __shared__ __attribute__((aligned(16))) char bwd_smem[];
+    int *sidx = reinterpret_cast<int *>(bwd_smem);                       // [256] code of each token of the chunk
+    short *snxt = reinterpret_cast<short *>(sidx + BWD_CHUNK);           // [256] next token with the same code, -1 = none
+    short *heads = snxt + BWD_CHUNK;                                     // [256] first token of every code present
+    int *nheads = reinterpret_cast<int *>(heads + BWD_CHUNK);            // [1] (+3 pad)
+    float *sge = reinterpret_cast<float *>(nheads + 4);                  // [256][C + 1]
+    const int t = threadIdx.x;
+    const long n = (long)blockIdx.x * BWD_CHUNK + t;
+    const bool valid = n < N;
+    const bool scatter = partial != nullptr;
+    const int code = valid ? (int)idx_in[n] : -1 - t;       // padding tokens: unique negative codes, never heads
+    if (scatter) {
+        sidx[t] = code;
+        if (t == 0) nheads[0] = 0;
     }
-    float nz = 1.0f, ne = 1.0f;
-    if (NORMED) {
-        nz = l2norm_row<C>(x, zh);
-        ne = l2norm_row<C>(e, eh);
+    float ge[C];
+    if (valid) {
+        const float inv = 1.0f / ((float)N * (float)C);
+        const float cc = (g_commit ? g_commit[0] : 0.0f) * beta * 2.0f * inv;  // commit: d/dzhat of beta*mean((sg(eh)-zh)^2)
+        const float cv = (g_vq ? g_vq[0] : 0.0f) * 2.0f * inv;                 // vq:     d/dehat of mean((eh-sg(zh))^2)
+        const long b = n / HW;
+        const int hw = (int)(n - b * HW);
+        const size_t off = (size_t)b * C * HW + hw;
+        float x[C], zh[C], e[C], eh[C];
+#pragma unroll
+        for (int k = 0; k < C; ++k) x[k] = z[off + (size_t)k * HW];
+        const float4 *row = reinterpret_cast<const float4 *>(E + (size_t)code * C);
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+            float4 v = row[q];
+            e[4 * q + 0] = v.x; e[4 * q + 1] = v.y; e[4 * q + 2] = v.z; e[4 * q + 3] = v.w;
+        }
+        float nz = 1.0f, ne = 1.0f;
+        if (NORMED) {
+            nz = l2norm_row<C>(x, zh);
+            ne = l2norm_row<C>(e, eh);
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) { zh[k] = x[k]; eh[k] = e[k]; }
+        }
+        float gzh[C], geh[C];
+        float dz = 0.0f, de = 0.0f;
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const float go = g_out ? g_out[off + (size_t)k * HW] : 0.0f;
+            const float diff = zh[k] - eh[k];
+            gzh[k] = __builtin_fmaf(cc, diff, go);
+            geh[k] = -cv * diff;
+            dz = __builtin_fmaf(gzh[k], zh[k], dz);
+            de = __builtin_fmaf(geh[k], eh[k], de);
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            const float gz = NORMED ? (gzh[k] - zh[k] * dz) / nz : gzh[k];
+            ge[k] = NORMED ? (geh[k] - eh[k] * de) / ne : geh[k];
+            g_z[off + (size_t)k * HW] = gz;
+        }
     } else {
 #pragma unroll
-        for (int k = 0; k < C; ++k) { zh[k] = x[k]; eh[k] = e[k]; }
+        for (int k = 0; k < C; ++k) ge[k] = 0.0f;
     }
-    float gzh[C], geh[C];
-    float dz = 0.0f, de = 0.0f;
+    if (!scatter) return;
+#pragma unroll
+    for (int k = 0; k < C; ++k) sge[t * (C + 1) + k] = ge[k];      // row pitch C + 1: lane t, word t (C + 1) + k -> bank (t + k) mod 32
+    __syncthreads();
+    bool has_prev = false;
+    int next = -1;
+#pragma unroll 8
+    for (int u = 0; u < BWD_CHUNK; ++u) {          // every lane reads the same word: an LDS broadcast
+        const bool eq = sidx[u] == code;
+        has_prev |= eq && u < t;
+        if (eq && u > t && next < 0) next = u;
+    }
+    snxt[t] = (short)next;
+    if (valid && !has_prev) {
+        const int slot = atomicAdd(nheads, 1);     // slot numbering is arbitrary; every chain's sum is not
+        heads[slot] = (short)t;
+        first[(size_t)blockIdx.x * V + code] = (unsigned short)(slot + 1);
+    }
+    __syncthreads();
+    const int nh = nheads[0];
+    const int k = t % C;
+    for (int e = t / C; e < nh; e += BWD_CHUNK / C) {
+        int u = heads[e];
+        float acc = 0.0f;
+        do {
+            acc += sge[u * (C + 1) + k];
+            u = snxt[u];
+        } while (u >= 0);
+        partial[((size_t)blockIdx.x * BWD_CHUNK + e) * C + k] = acc;
+    }
+}
+
+// g_E[v][:] = sum over the chunks (ascending inside each quarter of the chunk range) of the chunk partial of code v
+template <int C>
+__global__ __launch_bounds__(256) void vq_codebook_grad_kernel(const float *__restrict__ partial, const unsigned short *__restrict__ first,
+                                                               int V, int nchunks, float *__restrict__ g_E) {
+    const int v = blockIdx.x * 64 + (threadIdx.x >> 2), q = threadIdx.x & 3;
+    const int vc = v < V ? v : V - 1;
+    const int per = (nchunks + 3) / 4;
+    const int c0 = q * per, c1 = min(nchunks, c0 + per);
+    float acc[C];
+#pragma unroll
+    for (int k = 0; k < C; ++k) acc[k] = 0.0f;
+    for (int cb = c0; cb < c1; cb += 8) {
+        unsigned short s8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] = cb + j < c1 ? first[(size_t)(cb + j) * V + vc] : (unsigned short)0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (s8[j]) {
+                const float4 *row = reinterpret_cast<const float4 *>(partial + ((size_t)(cb + j) * BWD_CHUNK + (s8[j] - 1)) * C);
+#pragma unroll
+                for (int r = 0; r < C / 4; ++r) {
+                    const float4 w = row[r];
+                    acc[4 * r] += w.x; acc[4 * r + 1] += w.y; acc[4 * r + 2] += w.z; acc[4 * r + 3] += w.w;
+                }
+            }
+        }
+    }
+    // quarters meet in a fixed order: ((q0 + q1) + q2) + q3, computed on the q = 0 lane
+    const int l0 = threadIdx.x & 60;
 #pragma unroll
     for (int k = 0; k < C; ++k) {
-        const float go = g_out ? g_out[off + (size_t)k * HW] : 0.0f;
-        const float diff = zh[k] - eh[k];
-        gzh[k] = __builtin_fmaf(cc, diff, go);
-        geh[k] = -cv * diff;
-        dz = __builtin_fmaf(gzh[k], zh[k], dz);
-        de = __builtin_fmaf(geh[k], eh[k], de);
+        const float a1 = __shfl(acc[k], l0 + 1), a2 = __shfl(acc[k], l0 + 2), a3 = __shfl(acc[k], l0 + 3);
+        acc[k] = ((acc[k] + a1) + a2) + a3;
     }
-    float *ge_row = g_E + (size_t)idx * C;
+    if (q == 0 && v < V) {
+        float4 *dst = reinterpret_cast<float4 *>(g_E + (size_t)v * C);
 #pragma unroll
-    for (int k = 0; k < C; ++k) {
-        const float gz = NORMED ? (gzh[k] - zh[k] * dz) / nz : gzh[k];
-        const float ge = NORMED ? (geh[k] - eh[k] * de) / ne : geh[k];
-        g_z[off + (size_t)k * HW] = gz;
-        if (cv != 0.0f) atomicAdd(ge_row + k, ge);
+        for (int r = 0; r < C / 4; ++r) dst[r] = make_float4(acc[4 * r], acc[4 * r + 1], acc[4 * r + 2], acc[4 * r + 3]);
     }
 }
 
@@ -624,30 +725,82 @@ extern "C" int xq_vq_forward(const float *z, int B, int C, int HW, const float *
     return XQ_OK;
 }
 
+struct BwdWs {
+    float *partial;           // [nchunks][256][C] chunk partial sums, one row per code present in the chunk
+    unsigned short *first;    // [nchunks][V]      slot + 1 of the code's row in the chunk, 0 = absent
+    size_t first_bytes;
+};
+static size_t bwd_ws_layout(long N, int C, int V, char *base, BwdWs *ws) {
+    const long nchunks = (N + BWD_CHUNK - 1) / BWD_CHUNK;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off = xq::align_up(off + bytes, 256); return o; };
+    const size_t o_part = take((size_t)nchunks * BWD_CHUNK * C * 4), o_first = take((size_t)nchunks * V * 2);
+    if (ws) {
+        ws->partial = (float *)(base + o_part);
+        ws->first = (unsigned short *)(base + o_first);
+        ws->first_bytes = (size_t)nchunks * V * 2;
+    }
+    return off;
+}
+extern "C" size_t xq_vq_backward_workspace_bytes(int64_t N, int C, int V) {
+    if (N < 0 || V < 1 || C < 1) return 0;
+    return bwd_ws_layout((long)N, C, V, nullptr, nullptr);
+}
+
 template <int C>
-static void launch_bwd(bool normed, const float *z, long N, int HW, const float *E, const int64_t *idx, const float *g_out,
-                       const float *g_vq, const float *g_commit, float beta, float *g_z, float *g_E, hipStream_t s) {
-    const int blocks = (int)((N + 255) / 256);
+static void launch_bwd(bool normed, const float *z, long N, int HW, const float *E, int V, const int64_t *idx, const float *g_out,
+                       const float *g_vq, const float *g_commit, float beta, float *g_z, float *g_E, const BwdWs *ws, hipStream_t s) {
+    const int blocks = (int)((N + BWD_CHUNK - 1) / BWD_CHUNK);
+    float *partial = ws ? ws->partial : nullptr;
+    unsigned short *first = ws ? ws->first : nullptr;
+    const size_t lds = ws ? (size_t)BWD_CHUNK * 4 + BWD_CHUNK * 2 * 2 + 16 + (size_t)BWD_CHUNK * (C + 1) * 4 : 0;
+    if (ws) {
+        (void)hipMemsetAsync(ws->first, 0, ws->first_bytes, s);
+        static bool attr_set = false;       // C = 64 needs 68 KiB of dynamic LDS
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_backward_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_backward_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_set = true;
+        }
+    }
     if (normed)
-        hipLaunchKernelGGL((vq_backward_kernel<C, true>), dim3(blocks), dim3(256), 0, s, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E);
+        hipLaunchKernelGGL((vq_backward_kernel<C, true>), dim3(blocks), dim3(256), lds, s, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z,
+                           partial, first);
     else
-        hipLaunchKernelGGL((vq_backward_kernel<C, false>), dim3(blocks), dim3(256), 0, s, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E);
+        hipLaunchKernelGGL((vq_backward_kernel<C, false>), dim3(blocks), dim3(256), lds, s, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z,
+                           partial, first);
+    if (ws)
+        hipLaunchKernelGGL((vq_codebook_grad_kernel<C>), dim3((V + 63) / 64), dim3(256), 0, s, partial, first, V, blocks, g_E);
+    else
+        (void)hipMemsetAsync(g_E, 0, (size_t)V * C * 4, s);
 }
 
 extern "C" int xq_vq_backward(const float *z, int B, int C, int HW, const float *E, int V, int codebook_norm,
                               const int64_t *idx, const float *g_out, const float *g_vq, const float *g_commit, float beta,
-                              float *g_z, float *g_E, xq_stream_t stream) {
+                              float *g_z, float *g_E, void *workspace, size_t workspace_bytes, xq_stream_t stream) {
     int rc = check_common("xq_vq_backward", z, B, C, HW, E, V);
     if (rc) return rc;
     if (!idx || !g_z || !g_E) return xq_set_error(XQ_EINVAL, "%s: null idx/g_z/g_E", "xq_vq_backward");
     const long N = (long)B * HW;
-    if (N == 0) return XQ_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        (void)hipMemsetAsync(g_E, 0, (size_t)V * C * 4, s);
+        return XQ_OK;
+    }
+    BwdWs ws;
+    const bool scatter = g_vq != nullptr;       // without a vq-loss gradient the codebook receives none
+    if (scatter) {
+        const size_t need = bwd_ws_layout(N, C, V, nullptr, nullptr);
+        if (!workspace || workspace_bytes < need)
+            return xq_set_error(XQ_EINVAL, "%s: workspace too small (need %ld bytes, got %ld)", "xq_vq_backward", (long)need, (long)workspace_bytes);
+        bwd_ws_layout(N, C, V, (char *)workspace, &ws);
+    }
+    const BwdWs *w = scatter ? &ws : nullptr;
     switch (C) {
-        case 8: launch_bwd<8>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
-        case 16: launch_bwd<16>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
-        case 32: launch_bwd<32>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
-        case 64: launch_bwd<64>(codebook_norm != 0, z, N, HW, E, idx, g_out, g_vq, g_commit, beta, g_z, g_E, s); break;
+        case 8: launch_bwd<8>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
+        case 16: launch_bwd<16>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
+        case 32: launch_bwd<32>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
+        case 64: launch_bwd<64>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "vq_backward_kernel: %s", hipGetErrorString(e)); return XQ_ELAUNCH; }

@@ -119,10 +119,13 @@ class VQStraightThrough(torch.autograd.Function):
         gv = None if g_vq is None else g_vq.float().reshape(1).contiguous()
         gc = None if g_commit is None else g_commit.float().reshape(1).contiguous()
         g_z = torch.empty_like(z32)
-        g_E = torch.zeros_like(E)
+        g_E = torch.empty_like(E)           # overwritten: deterministic chained scatter, no atomics
+        nbytes = _lib.lib().xq_vq_backward_workspace_bytes(B * HW, C, V) if gv is not None else 0
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
         with torch.cuda.device(dev):
             rc = _lib.lib().xq_vq_backward(ptr(z32), B, C, HW, ptr(E), V, int(ctx.codebook_norm), ptr(idx), ptr(g_out),
-                                           ptr(gv), ptr(gc), ctypes.c_float(ctx.beta), ptr(g_z), ptr(g_E), _stream(z32))
+                                           ptr(gv), ptr(gc), ctypes.c_float(ctx.beta), ptr(g_z), ptr(g_E), ptr(ws), ws.numel(),
+                                           _stream(z32))
         check(rc, "xq_vq_backward")
         return g_z.to(ctx.in_dtype), g_E.to(weight.dtype), None, None
 

@@ -74,11 +74,15 @@ int xq_vq_forward(const float *z, int B, int C, int HW, const float *E, int V, i
  * Backward of VectorQuantizer.forward (autograd-derived upstream; formulas in SURVEY.md §8a):
  *   g_out (nullable) [B][C][HW] grad of the returned z_q; g_vq, g_commit: DEVICE scalars (nullable = 0),
  *   the upstream grads of vq_loss / commit_loss; beta = commit_loss_beta.
- *   g_z [B][C][HW] is overwritten; g_E [V][C] is ACCUMULATED into (caller zeroes it).
+ *   g_z [B][C][HW] and g_E [V][C] are overwritten.  g_E[v] = sum over the tokens that chose code v, formed without
+ *   floating-point atomics in a fixed order (ascending token inside 256-token chunks, chunk sums ascending inside four
+ *   ranges that meet as ((r0 + r1) + r2) + r3): bit-identical from run to run.  workspace: xq_vq_backward_workspace_bytes
+ *   (chunk partial sums + first-of-code table); not needed when g_vq is NULL (g_E = 0 then).
  */
+size_t xq_vq_backward_workspace_bytes(int64_t N, int C, int V);
 int xq_vq_backward(const float *z, int B, int C, int HW, const float *E, int V, int codebook_norm,
                    const int64_t *idx, const float *g_out, const float *g_vq, const float *g_commit, float beta,
-                   float *g_z, float *g_E, xq_stream_t stream);
+                   float *g_z, float *g_E, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 
 /* ---- RobustTok latent perturbation (latent_perturbation.py:4-35) --------------------------------------- */
 

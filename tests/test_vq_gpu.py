@@ -134,3 +134,39 @@ def test_full_size_configs_bit_exact_and_properties(oracle, cfg):
     perm = torch.randperm(B, generator=gen)
     idx_p = ops.assign(z[perm].to(dev()), E.to(dev()), 0).view(B, 256)
     assert torch.equal(idx_p, idx.view(B, 256)[perm.to(dev())])
+
+
+@pytest.mark.parametrize("case", ["spread", "collapsed", "ragged"])
+def test_vq_backward_codebook_grad_is_deterministic_and_matches_oracle(oracle, case):
+    """g_E is a scatter-reduce over the tokens of each code: formed without floating-point atomics, so two runs are
+    bit-identical; covers a collapsed codebook (every token on 3 codes: chains of hundreds of tokens inside one chunk),
+    a token count that is not a multiple of the 256-token chunk and codes that no token chose (rows of zeros)."""
+    from imagefolder_amd.xqgan_model import VectorQuantizer
+    rng = np.random.default_rng(5)
+    B, C, H, W, V = {"spread": (8, 32, 16, 16, 1024), "collapsed": (4, 32, 16, 16, 512), "ragged": (3, 16, 7, 9, 100)}[case]
+    E = rng.standard_normal((V, C)).astype(np.float32)
+    z = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    if case == "collapsed":      # tokens sit next to one of three codes
+        pick = rng.integers(0, 3, size=(B, 1, H, W))
+        z = (E[:3].T[None, :, :, None, None] * np.eye(3)[pick[:, 0]].transpose(0, 3, 1, 2)[:, None]).sum(2).astype(np.float32) \
+            + 0.01 * rng.standard_normal((B, C, H, W)).astype(np.float32)
+    g_out = rng.standard_normal(z.shape).astype(np.float32)
+    grads = []
+    for _ in range(2):
+        q = VectorQuantizer(V, C, 0.25, True).to(dev()).train()
+        with torch.no_grad():
+            q.embedding.weight.copy_(t(E))
+        zt = t(z).requires_grad_(True)
+        zq, _, vq, commit, _ = q(zt)
+        (zq * t(g_out)).sum().add(vq * 1.7).add(commit * 0.3).backward()
+        grads.append((zt.grad.cpu().numpy().copy(), q.embedding.weight.grad.cpu().numpy().copy(), q._last_indices.cpu().numpy().copy()))
+    np.testing.assert_array_equal(grads[0][1], grads[1][1])
+    np.testing.assert_array_equal(grads[0][0], grads[1][0])
+    idx = grads[0][2]
+    if case == "collapsed":
+        assert len(np.unique(idx)) <= 3
+    gz, gE = oracle.vq_backward(z, E, idx, g_out, 1.7, 0.3, 0.25, True)
+    assert np.abs(grads[0][0] - gz).max() <= 2e-6 * max(np.abs(gz).max(), 1.0) + 1e-7
+    assert np.abs(grads[0][1] - gE).max() <= 2e-5 * max(np.abs(gE).max(), 1e-30)
+    unused = np.setdiff1d(np.arange(V), idx)
+    assert unused.size > 0 and not grads[0][1][unused].any()
