@@ -15,6 +15,7 @@ import torch
 from torch import distributed as tdist, nn as nn
 from torch.nn import functional as F
 
+from .lazy import lazy_list
 from . import ops
 
 
@@ -196,8 +197,8 @@ class VectorQuantizer2(nn.Module):
         world = tdist.get_world_size() if _dist_ready() else 1
         margin = world * (f.numel() / f.shape[1]) / self.vocab_size * 0.08
         if ret_usages:
-            # one device->host transfer for all scales (the reference does SN .item() syncs, quant.py:140)
-            usages = ((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100).tolist()
+            # one ASYNCHRONOUS device->host copy for all scales, waited for when read (the reference does SN .item() syncs, quant.py:140)
+            usages = lazy_list((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100)
         else:
             usages = None
         self._last_indices = idx_all
@@ -308,6 +309,6 @@ class VectorQuantizer2Var(VectorQuantizer2):
         B, C, H, W = f.shape
         world = tdist.get_world_size() if _dist_ready() else 1
         margin = world * (B * H * W) / self.vocab_size * 0.08
-        usages = ((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100).tolist() if ret_usages else None
+        usages = lazy_list((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100) if ret_usages else None
         self._last_indices = idx_all
         return f_hat, usages, mean_vq_loss

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.distributed as tdist
 
+from .lazy import LazyFloat
 from . import nn_ops, ops
 from .cliploss import ClipLoss
 from .cnn import Encoder, Decoder
@@ -75,7 +76,8 @@ class VectorQuantizer(nn.Module):
                 self.ema_vocab_hit_SV.mul_(0.99).add_(hit_V.mul(0.01))
             self.record_hit += 1
             margin = world * (z.numel() / self.z_channels) / self.vocab_size * 0.08
-            codebook_usage = (self.ema_vocab_hit_SV >= margin).float().mean().item() * 100
+            # read lazily: no device synchronisation inside the forward (the reference calls .item() here, :788)
+            codebook_usage = LazyFloat((self.ema_vocab_hit_SV >= margin).float().mean() * 100)
         else:
             # the reference leaves `codebook_usage` unbound here and dies with UnboundLocalError
             # (xqgan_model.py:773-788,801); same error type, clearer message.
