@@ -336,7 +336,7 @@ def main():
                 "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                 "trainable_params": n_params,
                 "op_impl": dict(nn_ops.IMPL, quantizer="hip", latent_perturbation="hip", adamw_ema="hip",
-                                grad_allreduce="rccl"),
+                                grad_allreduce="rccl" if world > 1 or os.environ.get("XQ_FORCE_DIST") else "not run (single process)"),
                 "loss": args.loss,
                 "not_in_timed_region": ((None if args.loss == "full" else
                                          "VQLoss perceptual (LPIPS-VGG16) and adversarial (DinoDisc) terms + discriminator step")

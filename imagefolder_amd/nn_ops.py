@@ -13,17 +13,12 @@ import torch.nn.functional as F
 
 # op name -> what ran last ("hip": hand-written gfx950 kernel; "library": PyTorch-ROCm op = hipBLASLt / MIOpen / ATen).
 # Filled in by the dispatchers below as they execute, so bench.py reports what the timed step actually used.
-IMPL = {
-    "layer_norm": "library",
-    "linear": "library (hipBLASLt GEMM)",   # plain GEMM (+bias): a library call by design
-    "gelu": "library",
-    "attention": "library (SDPA)",
-    "residual_scale_add": "library",
-    "patch_embed": "library (GEMM over patchified pixels)",
-    "group_norm_silu": "library",
-    "conv2d": "library (MIOpen)",
-    "max_pool2x2": "library",
-}
+IMPL = {}
+
+
+def _lib_ran(name, what):
+    """a library fallback executed: say so (on the GPU only — CPU runs are the host mirror, not the product path)"""
+    IMPL[name] = what
 
 # ViT blocks as fused HIP row kernels + attention kernels + library GEMMs (ops_dense.run_blocks) instead of per-op ATen calls
 FUSED_BLOCKS = True
@@ -38,7 +33,6 @@ def vit_blocks(blocks, x, final_norm):
             IMPL["vit_block_rows"] = "hip"
             IMPL["layer_norm"] = IMPL["residual_scale_add"] = "hip (fused residual + LayerScale + DropPath + LayerNorm rows)"
             IMPL["gelu"] = "hip"
-            IMPL["linear"] = "library (hipBLASLt GEMM; split-K weight grads, bias grads from the hip row kernels)"
             return ops_dense.run_blocks(list(blocks), x, final_norm, act)
     IMPL["vit_block_rows"] = "library (per-op)"
     x = blocks(x)
@@ -46,14 +40,27 @@ def vit_blocks(blocks, x, final_norm):
 
 
 def layer_norm(x, weight, bias, eps):
+    if x.is_cuda:
+        _lib_ran("layer_norm", "library (ATen layer_norm, outside the fused blocks)")
     return F.layer_norm(x, (x.shape[-1],), weight, bias, eps)
 
 
 def linear(x, weight, bias=None):
+    """nn.Linear outside the fused transformer blocks (patch embeddings, ToPixel, projection heads): the hand-written GEMMs
+    under bf16 autocast (what autocast would hand F.linear: bf16 operands, bf16 result), the fp32-MFMA kernel on the fp32
+    parity path, the library on the CPU."""
     from . import ops_f32
     if ops_f32.eligible(x, weight, bias) and x.numel():
         IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"
         return ops_f32.linear(x, weight, bias)
+    if x.is_cuda and x.numel() and weight.dim() == 2:
+        act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
+        if act == torch.bfloat16 and x.dtype in (torch.bfloat16, torch.float32):
+            from . import ops_dense
+            if ops_dense.GEMM_IMPL == "hip":
+                return ops_dense.LinearFn.apply(x.to(torch.bfloat16), weight, bias, False)
+    if x.is_cuda:
+        _lib_ran("linear_library", "library (hipBLASLt: fp32 training / GEMM_IMPL != hip)")
     return F.linear(x, weight, bias)
 
 
@@ -74,6 +81,8 @@ def attention_qkvpacked(qkv, num_heads):
     B, N, C3 = qkv.shape
     C = C3 // 3
     q, k, v = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+    if qkv.is_cuda:
+        _lib_ran("attention_library", "library (SDPA: head_dim != 64 or fp32 training)")
     x = F.scaled_dot_product_attention(q, k, v)
     return x.transpose(1, 2).reshape(B, N, C)
 
@@ -88,6 +97,7 @@ def residual_scale_add(x, y, gamma=None, mask=None):
 
 
 def patch_embed(x, weight, bias, patch):
+    IMPL["patch_embed"] = "linear over patchified pixels (see `linear`)"
     """Conv2d(kernel = stride = patch) + flatten(2).transpose(1, 2): (B,3,H,W) -> (B, (H/p)*(W/p), D).
     A non-overlapping conv is a GEMM over patchified pixels: (B*gh*gw, 3*p*p) @ W^T.  (MIOpen has no tuned bf16
     solver for this shape on gfx950 and falls back to naive_conv_* kernels: 35 % of the step in profiles/r01.)"""
@@ -122,6 +132,8 @@ def group_norm_silu(x, groups, weight, bias, eps, silu=True):
         if x.dim() == 4 and ops_f32.eligible(x, weight, bias):
             IMPL["group_norm_silu_fp32_inference"] = "hip (xq_groupnorm_silu_f32)"
             return ops_f32.group_norm_silu(x, groups, weight, bias, eps, silu)
+    if x.is_cuda:
+        _lib_ran("group_norm_library", "library (ATen group_norm: shapes outside the NHWC bf16 kernels)")
     y = F.group_norm(x, groups, weight, bias, eps)
     return y * torch.sigmoid(y) if silu else y
 
@@ -144,7 +156,7 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
     if x.is_cuda and (x.dtype == torch.bfloat16 or torch.is_autocast_enabled("cuda")):
         from . import ops_dense
         if ops_dense.conv3x3_supported(x, weight, stride, padding):
-            IMPL["conv2d"] = "hip (3x3 s1 p1, C % 64 == 0: fwd + data grad) + library (rest, weight grad)"
+            IMPL["conv2d"] = "hip (3x3: implicit GEMM on the tile engine / 128-pixel kernel; fwd, data grad, weight grad)"
             return ops_dense.Conv3x3Fn.apply(x, weight, bias, relu)
         if ops_dense.conv3x3_small_cin_supported(x, weight, stride, padding):
             IMPL["conv2d_from_rgb"] = "hip (conv3x3_from3_kernel; dgrad conv3x3_to3_kernel; wgrad im2col27 + TN GEMM)"
@@ -159,6 +171,8 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
             IMPL["conv1x1"] = "hip (xq_gemm_bf16_*)"
             y = conv1x1(x.to(torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype), weight, bias)
             return torch.relu(y) if relu else y
+    if x.is_cuda:
+        _lib_ran("conv2d_library", f"library (MIOpen): {tuple(weight.shape)} stride {stride} pad {padding}")
     y = _conv2d_library(x, weight, bias, stride, padding)
     return torch.relu(y) if relu else y
 
@@ -170,6 +184,8 @@ def max_pool2x2(x):
         if ops_dense.maxpool2x2_supported(x):
             IMPL["max_pool2x2"] = "hip"
             return ops_dense.MaxPool2x2Fn.apply(x)
+    if x.is_cuda:
+        _lib_ran("max_pool2x2_library", "library (ATen)")
     return F.max_pool2d(x, kernel_size=2, stride=2)
 
 

@@ -272,14 +272,29 @@ class LinearFn(torch.autograd.Function):
         shp = x.shape
         x2 = x.detach().reshape(-1, shp[-1])
         hip = False
+        pad_k = pad_n = 0
+        n_out = weight.shape[0]
         if x2.dtype == torch.bfloat16:
             W = _w16(weight)
-            hip = (GEMM_IMPL == "hip" and x2.is_cuda and W.is_contiguous() and _gemm_ok(x2.shape[0], W.shape[0], W.shape[1]))
+            hip = GEMM_IMPL == "hip" and x2.is_cuda and x2.shape[0] > 0
             if hip:
+                # widths outside the kernels' contract (reduction depths % 64 — K forward, N in the data gradient: patch embedding
+                # K = 588, ToPixel N = 588, the 1x1 convs around the quantizer K = 32) are zero-padded to it and sliced off again
+                pad_k = (-W.shape[1]) % 64
+                pad_n = (-n_out) % 64
+                if pad_k or pad_n:
+                    W = F.pad(W, (0, pad_k, 0, pad_n))
+                    x2 = F.pad(x2, (0, pad_k)) if pad_k else x2
+                if not W.is_contiguous():
+                    W = W.contiguous()
                 if not x2.is_contiguous():
                     x2 = x2.contiguous()
                 b32 = None if bias is None else bias.detach().float().contiguous()
+                if b32 is not None and pad_n:
+                    b32 = F.pad(b32, (0, pad_n))
                 y = gemm_nt(x2, W, b32)
+                if pad_n:
+                    y = y[:, :n_out]
                 nn_ops.IMPL["linear"] = "hip (xq_gemm_bf16_nt / nn / tn: MFMA GEMMs, bias epilogue, split-K weight grads)"
             else:
                 b = None if bias is None else bias.detach().to(torch.bfloat16)
@@ -294,27 +309,29 @@ class LinearFn(torch.autograd.Function):
         if not hip:
             y = torch.addmm(b, x2, W.t()) if b is not None else torch.mm(x2, W.t())
         ctx.save_for_backward(x2, W)
-        ctx.meta = (shp, weight.dtype, bias is not None and not bias_grad_external, bias is not None)
-        return y.view(*shp[:-1], W.shape[0])
+        ctx.meta = (shp, weight.dtype, bias is not None and not bias_grad_external, bias is not None, hip, pad_k, pad_n, tuple(weight.shape))
+        return y.reshape(*shp[:-1], n_out)
 
     @staticmethod
     def backward(ctx, g):
         x2, W = ctx.saved_tensors
-        shp, wdtype, want_bias, has_bias = ctx.meta
+        shp, wdtype, want_bias, has_bias, hip, pad_k, pad_n, wshape = ctx.meta
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
             g2 = g2.contiguous()
-        hip = (GEMM_IMPL == "hip" and g2.is_cuda and g2.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16
-               and W.dtype == torch.bfloat16 and W.is_contiguous() and x2.is_contiguous())
+        hip = hip and g2.dtype == torch.bfloat16 and g2.shape[0] > 0
         g_x = g_w = None
+        gp = F.pad(g2, (0, pad_n)) if (hip and pad_n) else g2       # zero columns for the padded outputs
         if ctx.needs_input_grad[0]:
-            if hip and _gemm_ok(g2.shape[0], W.shape[1], W.shape[0]):
-                g_x = gemm_nn(g2, W).view(shp)
+            if hip:
+                g_x = gemm_nn(gp, W)
+                g_x = (g_x[:, :wshape[1]] if pad_k else g_x).reshape(shp)
             else:
                 g_x = torch.mm(g2, W).view(shp)
         if ctx.needs_input_grad[1]:
-            if hip and W.shape[0] % 8 == 0 and W.shape[1] % 8 == 0 and min(W.shape) >= 32:
-                g_w = gemm_tn(g2, x2).to(wdtype)
+            if hip:
+                g_w = gemm_tn(gp, x2)
+                g_w = (g_w[:wshape[0], :wshape[1]] if (pad_k or pad_n) else g_w).to(wdtype)
             else:
                 g_w = _weight_grad(g2, x2, wdtype)
         g_b = None

@@ -433,3 +433,37 @@ def test_groupnorm_silu_kernels(B, C, H, W, silu):
     assert (gx - gxr).abs().max().item() <= 2e-2 * max(1.0, gxr.abs().max().item())
     assert ((gw - gwr).norm() / gwr.norm()).item() <= 1e-2
     assert ((gb - gbr).norm() / gbr.norm()).item() <= 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(200, 588, 768), (300, 768, 588), (77, 32, 768), (64, 96, 1), (130, 588, 12)])
+def test_linear_with_widths_outside_the_gemm_contract_is_zero_padded_onto_it(M, K, N):
+    """patch embedding (K = 3*14*14), ToPixel (N = 588), the 1x1 convs around the quantizer (K = 32), 1-logit heads: nn_ops.linear
+    under bf16 autocast runs the hand-written GEMMs in all three passes (no library GEMM) and matches fp32 autograd"""
+    from imagefolder_amd import nn_ops, ops_dense
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", requires_grad=True)
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).requires_grad_(True)
+    b = torch.randn(N, device="cuda", requires_grad=True)
+    g = torch.randn(M, N, device="cuda")
+    calls = []
+    saved = (torch.mm, torch.addmm, F.linear)
+    torch.mm = lambda *a, **k: (calls.append("mm"), saved[0](*a, **k))[1]
+    torch.addmm = lambda *a, **k: (calls.append("addmm"), saved[1](*a, **k))[1]
+    F.linear = lambda *a, **k: (calls.append("linear"), saved[2](*a, **k))[1]
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = nn_ops.linear(x, w, b)
+        gx, gw, gb = torch.autograd.grad(y.float(), (x, w, b), g)
+    finally:
+        torch.mm, torch.addmm, F.linear = saved
+    assert not calls, calls
+    assert y.dtype == torch.bfloat16 and tuple(y.shape) == (M, N)
+    xr = x.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr = w.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = b.detach().clone().requires_grad_(True)
+    yr = xr @ wr.t() + br
+    gxr, gwr, gbr = torch.autograd.grad(yr, (xr, wr, br), g.to(torch.bfloat16).float())
+    for a, r, name in ((y.float(), yr, "y"), (gx, gxr, "gx"), (gw, gwr, "gw"), (gb, gbr, "gb")):
+        err = (a - r).abs().max().item()
+        assert err <= 2e-2 * max(1.0, r.abs().max().item()), (name, err)
