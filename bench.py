@@ -229,11 +229,20 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    # XQ_FORCE_DIST=1: initialise RCCL and run every collective of the step at world size 1 too (tests/test_bench_nccl_gpu.py:
-    # the 8-GPU runs are the driver's, this keeps the "nccl" branch exercised on the 1-GPU box)
+    # XQ_FORCE_DIST=1: initialise RCCL and run every collective of the step at world size 1 too
+    # (tests/test_train_arena_gpu.py::test_bench_runs_its_rccl_branch_at_world_size_1: the 8-GPU runs are the driver's, this keeps
+    # the "nccl" branch exercised on the 1-GPU box)
     force_dist = os.environ.get("XQ_FORCE_DIST", "0") == "1"
     use_dist = world > 1 or force_dist
     disc_group = None
+    # flops of one step per image (for "mfu"): counted on rank 0 BEFORE the process group exists — the counting pass builds its own
+    # train step, which would otherwise see world > 1 and issue collectives that no other rank joins
+    flops_img, mfu_error = None, None
+    if rank == 0 and args.workload == "train_step" and not args.no_mfu:
+        try:
+            flops_img = count_flops_per_image(args, dev)
+        except Exception as e:  # noqa: BLE001 - the bench line must still print
+            mfu_error = f"{type(e).__name__}: {e}"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -343,8 +352,8 @@ def main():
                                         if full else "everything but the quantizer"),
             },
         }
-        # one roofline entry per instrumented hand-written kernel; "roofline" = the one with the most GPU time in the
-        # timed region (the step's plain GEMMs are library kernels, see op_impl)
+        # one roofline entry per instrumented hand-written kernel family; "roofline" = the one with the most GPU time in the
+        # timed region (every MFMA kernel of the step is hand-written: see op_impl)
         entries = [{"bound": "mfma", "kernel": f"assign_kernel<C={CFG['C']}> (v_mfma_f32_32x32x2_f32, quantizer code search)",
                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops,
@@ -385,12 +394,8 @@ def main():
                                 "comm_dtype": args.grad_comm, "chunks": len(ts.reducer.chunks),
                                 "launch": "per-chunk from backward hooks, generator and discriminator on separate communicators",
                                 "exposed_ms_per_step": (sum(exposed) / len(exposed)) if exposed else None}
-            flops_img = None
-            if not args.no_mfu:
-                try:
-                    flops_img = count_flops_per_image(args, dev)
-                except Exception as e:  # noqa: BLE001 - the bench line must still print
-                    out["mfu_error"] = f"{type(e).__name__}: {e}"
+            if mfu_error:
+                out["mfu_error"] = mfu_error
             out["mfu"] = None if flops_img is None else {
                 "flops_per_image": flops_img, "source": "torch.utils.flop_counter formulas over every ATen op of one complete step on the library formulation (fp32, B=2) + 2*N*V*C of the code search",
                 "achieved_tflops": flops_img * out["value"] / 1e12, "peak_tflops": PEAK_BF16_MFMA_TFLOPS * world,

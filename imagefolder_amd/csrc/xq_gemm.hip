@@ -73,6 +73,13 @@ struct GemmArgs {
     int nt_store;           // non-temporal bf16 output stores (default; XQ_GEMM_PLAIN_STORE turns them off): the 128 KiB a CU
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
+    int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
+    int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
+                            // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
+                            // ONE range of g / x rows through its L2 for all of that range's output tiles; tile-major order (0, the
+                            // tail tiles of NT / NN, whose splits share the operand panels of one tile) made every output tile of the
+                            // weight gradient fetch its two full-height operand panels by itself: 1.2 - 1.6 GB per launch against
+                            // 0.4 - 0.5 GB algorithmic (profiles/r02_kernel_hbm_traffic_shapes.json), i.e. fabric-bound at ~5 TB/s
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -534,10 +541,12 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
     else {
         const long q = p - g.main_items;
         nsplit = g.tail_splits;
-        tile = g.main_items + q / nsplit;
-        split = q - (q / nsplit) * nsplit;
+        long tl;
+        if (g.split_major) { split = q / g.tail_tiles; tl = q - split * g.tail_tiles; }
+        else { tl = q / nsplit; split = q - tl * nsplit; }
+        tile = g.main_items + tl;
         it.slab = 1;
-        it.slab_idx = q;
+        it.slab_idx = tl * nsplit + split;       // slab layout [tile][split] whatever the execution order (slab_reduce_kernel)
     }
     it.m0 = (tile / g.tiles_n) * gm::BM;
     it.n0 = (tile % g.tiles_n) * 256;
@@ -952,6 +961,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         g.main_items = pl.main_items;
         g.tail_tiles = pl.tail_tiles;
         g.tail_splits = pl.tail_splits;
+        g.split_major = (EPI == EPI_F32_SLAB && !g.tile_major_debug) ? 1 : 0;
         g.slabs = (float *)ws;
         const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
         const long grid = items < num_cus() ? items : num_cus();
@@ -1054,6 +1064,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     if (P % 8 || Q % 8 || P < 32 || Q < 32) return xq_set_error(XQ_EINVAL, "%s: needs P, Q multiples of 8 and >= 32 (P=%ld Q=%ld)", fn, (long)P, (long)Q);
     hipStream_t s = (hipStream_t)stream;
     const int BN = pick_bn(Q, impl);
+    const int tile_major_debug = (impl & XQ_GEMM_TILE_MAJOR) ? 1 : 0;
     impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
@@ -1068,6 +1079,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
         g.splits = splits; g.ktiles = (int)(kt_all / splits); g.kt_rem = (int)(kt_all % splits); g.kt_full = (int)kt_all;
         if (impl == XQ_GEMM_AUTO) impl = BN == 256 ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
         compact = impl == XQ_GEMM_PERSISTENT;
+        g.tile_major_debug = tile_major_debug;
         if (!compact && (ws_bytes < (size_t)splits * P * Q * 4 || !ws)) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
         const int rc = launch_gemm<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, ws, ws_bytes, s, fn, 2.0 * P * Q * (double)(kt_all * 64));
         if (rc) return rc;

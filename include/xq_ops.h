@@ -50,7 +50,7 @@ size_t xq_assign_workspace_bytes(int64_t N, int C, int V);
 /*
  * idx[n] = argmin_j score(z_n, E_j) (lowest index among equal scores), n in [0, B*HW).
  *   z [B][C][HW], E [V][C]; idx int64 [B*HW]; best (nullable) fp32 [B*HW] = winning score.
- *   C in {8,16,32,64,128,256}; V >= 1.
+ *   C in {8,16,32,64} (XQ_EINVAL otherwise: the reference configs use 8 ... 64); V >= 1.
  */
 int xq_assign(const float *z, int B, int C, int HW, const float *E, int V, int mode, int64_t *idx, float *best,
               void *workspace, size_t workspace_bytes, xq_stream_t stream);
@@ -350,6 +350,7 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
                                 cut along K into fp32 slabs (256-column tiles, >= 2 K tiles per item)                       */
 #define XQ_GEMM_WIDE_TILES 0x100 /* OR-ed into impl: 256-column tiles even when N is not a multiple of 256 (ragged last tile) */
 #define XQ_GEMM_DEBUG_NO_STORE 0x200 /* OR-ed into impl (NT, persistent schedule): skip the output stores — timing experiments, result unusable */
+#define XQ_GEMM_TILE_MAJOR 0x400 /* OR-ed into impl (TN, persistent schedule): execute the K-split items tile-major instead of split-major (A/B timing) */
 #define XQ_GEMM_PLAIN_STORE 0x800 /* OR-ed into impl (persistent schedule): plain instead of non-temporal output stores (A/B timing) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1

@@ -16,7 +16,7 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 groups = {"conv3x3_kernel": "conv3x3", "attn_fwd_kernel": "attn_fwd", "attn_bwd_dkdv_kernel": "attn_bwd_dkdv", "attn_bwd_dq_kernel": "attn_bwd_dq",
-          "assign_kernel": "assign", "res_ln_bwd_kernel": "res_ln_bwd", "res_ln_fwd_kernel": "res_ln_fwd", "adamw_ema_kernel": "adamw_ema"}
+          "assign_kernel": "assign", "gemm_": "gemm", "gelu_fwd": "gelu_fwd", "gelu_bwd": "gelu_bwd", "conv3x3_wgrad": "conv3x3_wgrad", "res_ln_bwd_kernel": "res_ln_bwd", "res_ln_fwd_kernel": "res_ln_fwd", "adamw_ema_kernel": "adamw_ema"}
 out = {}
 for key, name in groups.items():
     fr = [v for k, vs in fetch.items() if key in k for v in vs]
@@ -28,5 +28,5 @@ for key, name in groups.items():
                  "write_bytes_per_launch": 1024.0 * sum(wr) / max(1, len(wr)),
                  "raw_fetch_size_kb_avg": sum(fr) / max(1, len(fr)), "raw_write_size_kb_avg": sum(wr) / max(1, len(wr))}
     out[name]["hbm_bytes_per_launch"] = out[name]["read_bytes_per_launch"] + out[name]["write_bytes_per_launch"]
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 3 --warmup 2",
+print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-mfu",
                   "corrections": "FETCH_SIZE KB x 1024 x 2 (gfx950 wide-read under-count); WRITE_SIZE KB x 1024", "kernels": out}, indent=1))
