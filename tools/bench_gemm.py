@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rows", type=int, nargs="*", default=[65664, 65792])
     ap.add_argument("--dims", type=int, nargs="*", default=[768])
     ap.add_argument("--scheds", type=str, nargs="*", default=["3"], help="impl values: 1 simple, 2 ring, 3 persistent, 0x103 = persistent with forced 256-column tiles")
+    ap.add_argument("--only", default=None, choices=[None, "nt", "nn", "tn"], help="time one pass only (library + hip)")
     a = ap.parse_args()
     lines = []
 
@@ -52,7 +53,7 @@ def main():
                     ("gx   library mm", lambda: torch.mm(g, w)),
                     ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
                 ]
-                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores"}.get(int(x, 0), x)) for x in a.scheds]:
+                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)"}.get(int(x, 0), x)) for x in a.scheds]:
                     def mk(f, sched=sched):
                         def run():
                             od.GEMM_SCHEDULE = sched
@@ -66,12 +67,15 @@ def main():
                         (f"gx   hip nn {tag}", mk(lambda: od.gemm_nn(g, w))),
                         (f"gW   hip tn {tag}", mk(lambda: od.gemm_tn(g, x))),
                     ]
+                if a.only:
+                    key = {"nt": "fwd", "nn": "gx", "tn": "gW"}[a.only]
+                    cases = [c for c in cases if c[0].startswith(key)]
                 for label, fn in cases:
                     try:
                         ms = timeit(fn)
-                        emit(f"D{D} M{M} {name:5s} N{N:5d} K{K:5d} {label:28s} {ms:8.3f} ms {fl / ms / 1e9:8.1f} TF/s")
+                        emit(f"D{D} M{M} {name:5s} N{N:5d} K{K:5d} {label:44s} {ms:8.3f} ms {fl / ms / 1e9:8.1f} TF/s")
                     except Exception as e:  # noqa: BLE001
-                        emit(f"D{D} M{M} {name:5s} {label:28s} FAILED: {e}")
+                        emit(f"D{D} M{M} {name:5s} {label:44s} FAILED: {e}")
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         with open(a.out, "w") as f:

@@ -1,8 +1,8 @@
 #!/bin/bash
 # One gpurun call: GPU test suite, default bench line, rocprofv3 kernel trace of the same command, PMC traffic passes.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_check.sh <tag> [parts]'
-# parts: any of  tests bench trace pmc shapes   (default: all)
-TAG=${1:-check}
+# parts: any of  tests bench trace pmc shapes gemmtests gemmab configs   (default: the first five)
+TAG=${1:-check}; export XQ_TAG=$TAG
 PARTS=${2:-"tests bench trace pmc shapes"}
 export TMPDIR=/tmp
 OUT=gpurun_out/$TAG
@@ -40,4 +40,27 @@ if has shapes; then
   done
   python tools/pmc_shapes.py parse /tmp/pmcs_${TAG}_FETCH_SIZE /tmp/pmcs_${TAG}_WRITE_SIZE > $OUT/kernel_hbm_traffic_shapes.json 2> $OUT/shapes_parse.err
   tail -5 $OUT/shapes_parse.err; head -c 600 $OUT/kernel_hbm_traffic_shapes.json; echo
+fi
+if has gemmtests; then
+  timeout 600 python -m pytest tests/test_gemm_gpu.py tests/test_dense_ops_gpu.py -m gpu -x -q > $OUT/pytest_gemm.log 2>&1
+  echo "gemm pytest rc=$?"; tail -2 $OUT/pytest_gemm.log
+fi
+if has gemmab; then
+  # weight-gradient item order A/B: 3 = persistent (split-major, default), 0x403 = persistent with the old tile-major order
+  timeout 300 python tools/bench_gemm.py --rows 65664 --scheds 3 0x403 --only tn --out $OUT/gemm_tn_order.txt > /dev/null 2> $OUT/gemmab.err
+  cat $OUT/gemm_tn_order.txt
+fi
+if has configs; then
+  for CFG in VP2-16384 MSVR10P2-4096 RobustTok; do
+    timeout 300 python bench.py --config $CFG --steps 8 --warmup 3 --no-cpu-baseline --no-mfu >> $OUT/bench_configs.jsonl 2>> $OUT/bench_configs.err
+    echo "$CFG rc=$?"
+  done
+  timeout 400 python bench.py --config VQ-4096-cnn --batch 32 --steps 5 --warmup 2 --no-mfu >> $OUT/bench_configs.jsonl 2>> $OUT/bench_configs.err
+  echo "cnn B=32 rc=$?"
+  python - <<'PY'
+import json
+for l in open("gpurun_out/" + __import__("os").environ.get("XQ_TAG", "x") + "/bench_configs.jsonl"):
+    if l.startswith("{"):
+        d = json.loads(l); print(d["config"]["workload"][:40], d["config"]["per_gpu_batch"], round(d["value"], 1), "img/s", round(d["ms_per_step"], 1), "ms")
+PY
 fi
