@@ -26,7 +26,7 @@ static constexpr int GN_MAX_SLABS = 64;
 __device__ __forceinline__ void gn_load8(const bf16 *p, float (&v)[8]) { load_vec<bf16, 8>(p, v); }
 
 __device__ __forceinline__ float gn_silu_grad(float pre) {
-    const float sg = 1.0f / (1.0f + __expf(-pre));
+    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-pre));
     return sg * (1.0f + pre * (1.0f - sg));
 }
 
@@ -131,50 +131,77 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
     else { out0[b * G + g] = s1 / n; out1[b * G + g] = s2 / n; }
 }
 
+// element-wise passes: block (slab, sample); a thread keeps its 8 channels for the whole slab (as in gn_reduce_kernel), so the
+// per-channel constants live in registers and the loop body is load -> 8 x (fma, [silu]) -> store — no index arithmetic per element
+// (the first version derived (sample, group, channel) from a flat index with 64-bit divisions and re-read mean / rstd / w / b per
+// element: 0.9 TB/s at 128 channels x 256^2, profiles/r02_cnn_b32_kernel_stats_v1.txt)
+__device__ __forceinline__ float gn_sigmoid(float pre) { return __builtin_amdgcn_rcpf(1.0f + __expf(-pre)); }
+
 __global__ __launch_bounds__(256) void gn_apply_fwd_kernel(const bf16 *__restrict__ x, const float *__restrict__ w, const float *__restrict__ bias,
-                                                           const float *__restrict__ mean, const float *__restrict__ rstd, int B, int HW, int C,
-                                                           int G, int silu, bf16 *__restrict__ y) {
-    const int cv = C / 8, cg = C / G;
-    const long total = (long)B * HW * cv;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ci = (int)(i % cv);
-        const long bp = i / cv;
-        const int b = (int)(bp / HW);
+                                                           const float *__restrict__ mean, const float *__restrict__ rstd, int HW, int C,
+                                                           int G, int silu, int slab_px, bf16 *__restrict__ y) {
+    const int cv = C / 8, PL = 256 / cv;
+    const int cidx = threadIdx.x % cv, pl = threadIdx.x / cv;
+    const int b = blockIdx.y, cg = C / G;
+    const int p0 = blockIdx.x * slab_px;
+    int p1 = p0 + slab_px;
+    if (p1 > HW) p1 = HW;
+    float mu[8], rs[8], ww[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cidx * 8 + j, g = c / cg;
+        mu[j] = mean[b * G + g];
+        rs[j] = rstd[b * G + g];
+        ww[j] = w ? w[c] : 1.0f;
+        bb[j] = bias ? bias[c] : 0.0f;
+    }
+    const long base = ((long)b * HW) * C + cidx * 8;
+    for (int p = p0 + pl; p < p1; p += PL) {
         float v[8], o[8];
-        gn_load8(x + i * 8, v);
+        gn_load8(x + base + (long)p * C, v);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = ci * 8 + j, g = c / cg;
-            const float pre = fmaf((v[j] - mean[b * G + g]) * rstd[b * G + g], w ? w[c] : 1.0f, bias ? bias[c] : 0.0f);
-            o[j] = silu ? pre / (1.0f + __expf(-pre)) : pre;
+            const float pre = fmaf((v[j] - mu[j]) * rs[j], ww[j], bb[j]);
+            o[j] = silu ? pre * gn_sigmoid(pre) : pre;
         }
-        store_vec<bf16, 8>(y + i * 8, o);
+        store_vec<bf16, 8>(y + base + (long)p * C, o);
     }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_bwd_kernel(const bf16 *__restrict__ x, const bf16 *__restrict__ dy, const float *__restrict__ w,
                                                            const float *__restrict__ bias, const float *__restrict__ mean,
                                                            const float *__restrict__ rstd, const float *__restrict__ m1,
-                                                           const float *__restrict__ m2, int B, int HW, int C, int G, int silu,
+                                                           const float *__restrict__ m2, int HW, int C, int G, int silu, int slab_px,
                                                            bf16 *__restrict__ dx) {
-    const int cv = C / 8, cg = C / G;
-    const long total = (long)B * HW * cv;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int ci = (int)(i % cv);
-        const long bp = i / cv;
-        const int b = (int)(bp / HW);
+    const int cv = C / 8, PL = 256 / cv;
+    const int cidx = threadIdx.x % cv, pl = threadIdx.x / cv;
+    const int b = blockIdx.y, cg = C / G;
+    const int p0 = blockIdx.x * slab_px;
+    int p1 = p0 + slab_px;
+    if (p1 > HW) p1 = HW;
+    float mu[8], rs[8], ww[8], bb[8], a1[8], a2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cidx * 8 + j, g = c / cg;
+        mu[j] = mean[b * G + g];
+        rs[j] = rstd[b * G + g];
+        ww[j] = w ? w[c] : 1.0f;
+        bb[j] = bias ? bias[c] : 0.0f;
+        a1[j] = m1[b * G + g];
+        a2[j] = m2[b * G + g];
+    }
+    const long base = ((long)b * HW) * C + cidx * 8;
+    for (int p = p0 + pl; p < p1; p += PL) {
         float v[8], g8[8], o[8];
-        gn_load8(x + i * 8, v);
-        gn_load8(dy + i * 8, g8);
+        gn_load8(x + base + (long)p * C, v);
+        gn_load8(dy + base + (long)p * C, g8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int c = ci * 8 + j, g = c / cg;
-            const float rs = rstd[b * G + g], wc = w ? w[c] : 1.0f;
-            const float xh = (v[j] - mean[b * G + g]) * rs;
-            const float dpre = silu ? g8[j] * gn_silu_grad(fmaf(xh, wc, bias ? bias[c] : 0.0f)) : g8[j];
-            o[j] = rs * (dpre * wc - m1[b * G + g] - xh * m2[b * G + g]);
+            const float xh = (v[j] - mu[j]) * rs[j];
+            const float dpre = silu ? g8[j] * gn_silu_grad(fmaf(xh, ww[j], bb[j])) : g8[j];
+            o[j] = rs[j] * (dpre * ww[j] - a1[j] - xh * a2[j]);
         }
-        store_vec<bf16, 8>(dx + i * 8, o);
+        store_vec<bf16, 8>(dx + base + (long)p * C, o);
     }
 }
 
@@ -191,6 +218,14 @@ static int gn_slabs(int HW, int C, int *slab_px) {
     if (ns > GN_MAX_SLABS) ns = GN_MAX_SLABS;
     if (ns < 1) ns = 1;
     *slab_px = (HW + ns - 1) / ns;
+    return (HW + *slab_px - 1) / *slab_px;
+}
+
+// slabs of the element-wise passes: ~8 pixels per thread (enough independent 16-byte loads in flight per wave, >= 4 blocks per CU
+// from 32 x 32 maps on)
+static int gn_apply_slabs(int HW, int C, int *slab_px) {
+    const int PL = 256 / (C / 8);
+    *slab_px = PL * 8;
     return (HW + *slab_px - 1) / *slab_px;
 }
 
@@ -217,11 +252,9 @@ extern "C" int xq_groupnorm_silu_forward(const void *x, const float *w, const fl
     hipLaunchKernelGGL((gn_reduce_kernel<1>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
                        workspace, (float *)nullptr);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, workspace, ns, G, n, eps, 1, rstd, (float *)nullptr);
-    const long total = (long)B * HW * (C / 8);
-    long blocks = (total + 255) / 256;
-    const long cap = (long)num_cus() * 32;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, xp, w, bias, mean, rstd, B, HW, C, G, silu, (bf16 *)y);
+    int apx;
+    const int ans = gn_apply_slabs(HW, C, &apx);
+    hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(ans, B), dim3(256), 0, s, xp, w, bias, mean, rstd, HW, C, G, silu, apx, (bf16 *)y);
     return xq_check_launch(fn);
 }
 
@@ -246,11 +279,9 @@ extern "C" int xq_groupnorm_silu_backward(const void *x, const void *dy, const f
     hipLaunchKernelGGL((gn_reduce_kernel<2>), dim3(ns, B), dim3(256), 0, s, (const bf16 *)x, (const bf16 *)dy, w, bias, mean, rstd, HW, C, G, silu,
                        spx, part_g, g_wb_partials);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, part_g, ns, G, n, 0.0f, 2, m1, m2);
-    const long total = (long)B * HW * (C / 8);
-    long blocks = (total + 255) / 256;
-    const long cap = (long)num_cus() * 32;
-    if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const bf16 *)x, (const bf16 *)dy, w, bias, mean, rstd, m1, m2, B,
-                       HW, C, G, silu, (bf16 *)dx);
+    int apx;
+    const int ans = gn_apply_slabs(HW, C, &apx);
+    hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(ans, B), dim3(256), 0, s, (const bf16 *)x, (const bf16 *)dy, w, bias, mean, rstd, m1, m2, HW, C, G,
+                       silu, apx, (bf16 *)dx);
     return xq_check_launch(fn);
 }

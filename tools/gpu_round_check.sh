@@ -64,3 +64,9 @@ for l in open("gpurun_out/" + __import__("os").environ.get("XQ_TAG", "x") + "/be
         d = json.loads(l); print(d["config"]["workload"][:40], d["config"]["per_gpu_batch"], round(d["value"], 1), "img/s", round(d["ms_per_step"], 1), "ms")
 PY
 fi
+if has cnntrace; then
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/profc_$TAG -o step -- python bench.py --config VQ-4096-cnn --batch 32 --steps 4 --warmup 2 --no-cpu-baseline --no-mfu > $OUT/cnn_trace_bench.json 2> $OUT/cnn_trace.err
+  DB=$(find /tmp/profc_$TAG -name '*.db' | head -1)
+  if [ -n "$DB" ]; then python tools/rocpd_stats.py $DB 45 > $OUT/cnn_kernel_stats.txt; fi
+  head -40 $OUT/cnn_kernel_stats.txt | cut -c1-180
+fi
