@@ -70,3 +70,9 @@ if has cnntrace; then
   if [ -n "$DB" ]; then python tools/rocpd_stats.py $DB 45 > $OUT/cnn_kernel_stats.txt; fi
   head -40 $OUT/cnn_kernel_stats.txt | cut -c1-180
 fi
+if has sections; then
+  XQ_MARKERS=1 timeout 400 rocprofv3 --kernel-trace -d /tmp/profs_$TAG -o step -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-mfu > $OUT/sections_bench.json 2> $OUT/sections.err
+  DB=$(find /tmp/profs_$TAG -name '*.db' | head -1)
+  if [ -n "$DB" ]; then python tools/rocpd_sections.py $DB 8 > $OUT/train_step_sections.txt 2>> $OUT/sections.err; fi
+  grep -E "^ +[0-9.]+ +[0-9.]+ +[0-9]+ +\[" $OUT/train_step_sections.txt
+fi
