@@ -54,13 +54,14 @@ SIGNATURES = {
     "xq_colsum": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "xq_lpips_level_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_lpips_level_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_lpips_level_backward_fused": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_pack_weights": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_nhwc_bf16": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, vp, vp]),
     "xq_conv3x3_wgrad_nhwc_bf16": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_wgrad_nhwc_bf16_ex": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp]),
     "xq_sumpool2x2_nhwc_bf16": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
-    "xq_conv3x3_from3_forward": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv3x3_from3_forward": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_to3_forward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_im2col27": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_to3_wgrad_blocks": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),

@@ -39,7 +39,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 // Wk: fp32 [27][128], k = (ky * 3 + kx) * 3 + ci (values already rounded to bf16); bias fp32 [128] or null
 template <typename TIN, int C3_OUT>
 __global__ __launch_bounds__(256) void conv3x3_from3_kernel(const TIN *__restrict__ X, const float *__restrict__ Wk, const float *__restrict__ bias,
-                                                            int B, int H, int W, __hip_bfloat16 *__restrict__ Y) {
+                                                            int B, int H, int W, int relu, __hip_bfloat16 *__restrict__ Y) {
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
     const long total = (long)B * H * W;
     if (p >= total) return;
@@ -66,6 +66,10 @@ __global__ __launch_bounds__(256) void conv3x3_from3_kernel(const TIN *__restric
         for (int k = 0; k < 27; ++k)
 #pragma unroll
             for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(in[k], Wk[k * C3_OUT + c0 + j], acc[j]);
+        if (relu) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] = fmaxf(acc[j], 0.0f);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             out[c0 / 8 + q] = make_uint4(pack2(acc[8 * q + 0], acc[8 * q + 1]), pack2(acc[8 * q + 2], acc[8 * q + 3]),
@@ -286,7 +290,7 @@ extern "C" int xq_row_softmax_backward(const float *P32, const void *dP, int64_t
 }
 
 extern "C" int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, const float *w_kc, const float *bias, int B, int H, int W, int Cout,
-                                        void *y_nhwc, xq_stream_t stream) {
+                                        int relu, void *y_nhwc, xq_stream_t stream) {
     const char *fn = "xq_conv3x3_from3_forward";
     if (B < 0 || H < 1 || W < 1 || (Cout != 64 && Cout != 128)) return xq_set_error(XQ_EINVAL, "%s: bad shape (Cout 64 or 128)", fn);
     if (B == 0) return XQ_OK;
@@ -295,7 +299,7 @@ extern "C" int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, con
     const unsigned blocks = (unsigned)((total + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
     __hip_bfloat16 *y = (__hip_bfloat16 *)y_nhwc;
-#define FROM3(T, CO) hipLaunchKernelGGL((conv3x3_from3_kernel<T, CO>), dim3(blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, y)
+#define FROM3(T, CO) hipLaunchKernelGGL((conv3x3_from3_kernel<T, CO>), dim3(blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, relu, y)
     if (x_is_bf16) { if (Cout == 128) FROM3(__hip_bfloat16, 128); else FROM3(__hip_bfloat16, 64); }
     else { if (Cout == 128) FROM3(float, 128); else FROM3(float, 64); }
 #undef FROM3

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void lpips_level_fwd_kernel(const T *__restric
 template <typename T, int C>
 __global__ __launch_bounds__(256) void lpips_level_bwd_kernel(const T *__restrict__ f0, const T *__restrict__ f1,
                                                               const float *__restrict__ w, const float *__restrict__ gout,
-                                                              int HW, T *__restrict__ g1) {
+                                                              const T *__restrict__ g_add, int relu_mask, int HW, T *__restrict__ g1) {
     constexpr int LPP = C / 8;
     constexpr int PPW = 64 / LPP;
     const int b = blockIdx.y;
@@ -460,20 +460,30 @@ __global__ __launch_bounds__(256) void lpips_level_bwd_kernel(const T *__restric
         float out[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] = gu[j] * i1 - c[j] * k;
+        if (g_add) {       // gradient from the deeper VGG slices (hand-driven backward: xq_lpips_level_backward_fused)
+            float ga[8];
+            load_vec<T, 8>(g_add + base + (size_t)p * C + sub * 8, ga);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] += ga[j];
+        }
+        if (relu_mask) {   // f1 is a ReLU output: gradient w.r.t. the pre-activation
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = c[j] > 0.0f ? out[j] : 0.0f;
+        }
         store_vec<T, 8>(g1 + base + (size_t)p * C + sub * 8, out);
     }
 }
 
 template <typename T>
 static int lpips_dispatch(bool bwd, const T *f0, const T *f1, const float *w, const float *gout, int B, int HW, int C, float *val,
-                          T *g1, hipStream_t s) {
+                          T *g1, hipStream_t s, const T *g_add = nullptr, int relu_mask = 0) {
     int bx = (HW + 31) / 32;
     const int cap = (num_cus() * 8 + B - 1) / B;
     if (bx > cap) bx = cap < 1 ? 1 : cap;
     dim3 grid(bx, B), block(256);
 #define LP_CASE(CC)                                                                                                      \
     case CC:                                                                                                             \
-        if (bwd) hipLaunchKernelGGL((lpips_level_bwd_kernel<T, CC>), grid, block, 0, s, f0, f1, w, gout, HW, g1);        \
+        if (bwd) hipLaunchKernelGGL((lpips_level_bwd_kernel<T, CC>), grid, block, 0, s, f0, f1, w, gout, g_add, relu_mask, HW, g1);        \
         else hipLaunchKernelGGL((lpips_level_fwd_kernel<T, CC>), grid, block, 0, s, f0, f1, w, HW, val);                 \
         break;
     switch (C) {
@@ -501,4 +511,14 @@ extern "C" int xq_lpips_level_backward(const void *f0, const void *f1, const flo
     hipStream_t s = (hipStream_t)stream;
     if (act_bf16) return lpips_dispatch<bf16>(true, (const bf16 *)f0, (const bf16 *)f1, w, gout, B, HW, C, nullptr, (bf16 *)g1, s);
     return lpips_dispatch<float>(true, (const float *)f0, (const float *)f1, w, gout, B, HW, C, nullptr, (float *)g1, s);
+}
+
+extern "C" int xq_lpips_level_backward_fused(const void *f0, const void *f1, const float *w, const float *gout, const void *g_add, int relu_mask,
+                                             int B, int HW, int C, int act_bf16, void *g1, xq_stream_t stream) {
+    if (B == 0) return XQ_OK;
+    if (!f0 || !f1 || !w || !gout || !g1) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_lpips_level_backward_fused");
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16)
+        return lpips_dispatch<bf16>(true, (const bf16 *)f0, (const bf16 *)f1, w, gout, B, HW, C, nullptr, (bf16 *)g1, s, (const bf16 *)g_add, relu_mask);
+    return lpips_dispatch<float>(true, (const float *)f0, (const float *)f1, w, gout, B, HW, C, nullptr, (float *)g1, s, (const float *)g_add, relu_mask);
 }

@@ -539,6 +539,92 @@ class LpipsLevelFn(torch.autograd.Function):
         return None, g1, None
 
 
+class _ManualCtx:
+    """Stand-in for the autograd ctx when the forward / backward halves of a Function are driven by hand (LpipsVggFn)."""
+
+    def __init__(self, needs_input_grad):
+        self.needs_input_grad = needs_input_grad
+        self.saved_tensors = ()
+
+    def save_for_backward(self, *tensors):
+        self.saved_tensors = tensors
+
+
+class LpipsVggFn(torch.autograd.Function):
+    """val[b] = sum_k LPIPS level k (lpips.py:83-96,118-164) of the reconstruction against precomputed features of the data:
+    the frozen VGG16 trunk and the five level comparisons as ONE autograd node whose backward walks the trunk by hand.
+    Per-op autograd pays, for every tapped map, an add_ (gradient from the deeper slices + the level's own) and a
+    threshold_backward (ReLU) pass over the largest activations of the step (1 GB at 64 channels x 256^2 x 128 images); here both
+    are folded into the level kernel (xq_lpips_level_backward_fused), and conv1_1's ReLU sits in its kernel's epilogue.
+    x1: the scaled reconstruction (B, 3, H, W); vgg: vq_loss._VGG16Slices (frozen); f0s: its five outputs for the data;
+    lins: the five (C,) level weights."""
+
+    @staticmethod
+    def forward(ctx, x1, vgg, f0s, lins):
+        import torch.nn as nn
+        layers, f1s = [], []
+        x = x1.detach()
+        val = None
+        for si in range(1, 6):
+            mods = list(getattr(vgg, f"slice{si}"))
+            i = 0
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, nn.Conv2d):
+                    fn = Conv3x3SmallCinFn if m.weight.shape[1] == 3 else Conv3x3Fn
+                    c = _ManualCtx((True, False, False, False, False))
+                    x = fn.forward(c, x, m.weight, m.bias, True)
+                    layers.append(("conv", fn, c))
+                    i += 2                                    # the ReLU that follows is in the kernel's epilogue
+                else:
+                    c = _ManualCtx((True,))
+                    x = MaxPool2x2Fn.forward(c, x)
+                    layers.append(("pool", MaxPool2x2Fn, c))
+                    i += 1
+            k = si - 1
+            f1c = x.contiguous(memory_format=torch.channels_last)
+            f0c = f0s[k].detach().contiguous(memory_format=torch.channels_last).to(f1c.dtype)
+            wc = lins[k].detach().float().reshape(-1).contiguous()
+            B, C, H, W = f1c.shape
+            v = torch.empty(B, dtype=torch.float32, device=f1c.device)
+            with torch.cuda.device(f1c.device):
+                rc = _lib.lib().xq_lpips_level_forward(ptr(f0c), ptr(f1c), ptr(wc), B, H * W, C, _act_flag(f1c.dtype), ptr(v), _stream(f1c))
+            check(rc, "xq_lpips_level_forward")
+            val = v if val is None else val + v
+            layers.append(("tap", None, (f0c, f1c, wc)))
+        ctx.layers = layers
+        ctx.in_dtype = x1.dtype
+        return val
+
+    @staticmethod
+    def backward(ctx, gval):
+        gv = gval.detach().float().contiguous()
+        layers = ctx.layers
+        g = None
+        for li in range(len(layers) - 1, -1, -1):
+            kind, fn, c = layers[li]
+            if kind == "tap":
+                f0c, f1c, wc = c
+                B, C, H, W = f1c.shape
+                g1 = torch.empty_like(f1c, memory_format=torch.channels_last)
+                ga = None if g is None else g.to(f1c.dtype).contiguous(memory_format=torch.channels_last)
+                with torch.cuda.device(f1c.device):
+                    rc = _lib.lib().xq_lpips_level_backward_fused(ptr(f0c), ptr(f1c), ptr(wc), ptr(gv), ptr(ga), 1, B, H * W, C,
+                                                                  _act_flag(f1c.dtype), ptr(g1), _stream(f1c))
+                check(rc, "xq_lpips_level_backward_fused")
+                g = g1                                            # gradient w.r.t. the pre-activation of the conv that made f1
+            elif kind == "pool":
+                g = fn.backward(c, g)                             # w.r.t. the tapped map below: the tap entry adds + masks
+            else:
+                c.relu = False                                    # the ReLU mask is already in g
+                g = fn.backward(c, g)[0]
+                if li > 0 and layers[li - 1][0] == "conv":        # conv -> conv inside a slice: mask by the ReLU output below
+                    y_prev = layers[li - 1][2].saved_tensors[2]
+                    g = torch.ops.aten.threshold_backward(g.to(y_prev.dtype), y_prev, 0)
+        ctx.layers = None
+        return g.to(ctx.in_dtype), None, None, None
+
+
 def _packed_conv_weight(weight, for_data_grad: bool):
     """bf16 K-major pack of a conv3x3 weight, cached on the parameter and refreshed when it changes."""
     key = "_xq_pack_dgrad" if for_data_grad else "_xq_pack_fwd"
@@ -726,13 +812,13 @@ def _planar(t):
     return t.contiguous()
 
 
-def _from3(x_planar, w_kc, bias, Cout):
+def _from3(x_planar, w_kc, bias, Cout, relu=False):
     B, _, H, W = x_planar.shape
     y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=x_planar.device)
     b32 = None if bias is None else bias.detach().float().contiguous()
     with torch.cuda.device(x_planar.device):
-        rc = _lib.lib().xq_conv3x3_from3_forward(ptr(x_planar), int(x_planar.dtype == torch.bfloat16), ptr(w_kc), ptr(b32), B, H, W, Cout, ptr(y),
-                                                 _stream(x_planar))
+        rc = _lib.lib().xq_conv3x3_from3_forward(ptr(x_planar), int(x_planar.dtype == torch.bfloat16), ptr(w_kc), ptr(b32), B, H, W, Cout,
+                                                 int(bool(relu)), ptr(y), _stream(x_planar))
     check(rc, "xq_conv3x3_from3_forward")
     return y.permute(0, 3, 1, 2)
 
@@ -766,9 +852,7 @@ class Conv3x3SmallCinFn(torch.autograd.Function):
         xp = _planar(x)
         Cout = weight.shape[0]
         w_kc = _w16f(weight).permute(2, 3, 1, 0).reshape(27, Cout).contiguous()          # [(ky*3+kx)*3+ci][co]
-        y = _from3(xp, w_kc, bias, Cout)
-        if relu:
-            y = torch.relu_(y)
+        y = _from3(xp, w_kc, bias, Cout, relu=relu)      # ReLU in the kernel's epilogue
         ctx.relu = bool(relu)
         ctx.save_for_backward(xp, weight, y if relu else None)
         ctx.has_bias = bias is not None

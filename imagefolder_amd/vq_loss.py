@@ -53,6 +53,7 @@ def lecam_reg(real_pred, fake_pred, lecam_ema):
 
 
 # ---- LPIPS (lpips.py) -------------------------------------------------------------------------------------------
+FUSED_VGG_BACKWARD = __import__("os").environ.get("XQ_FUSED_VGG", "1") == "1"
 _VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]  # features[0:30]
 
 
@@ -134,14 +135,18 @@ class LPIPS(nn.Module):
     def forward(self, input, target):
         """`input` is the data (no gradient), `target` the reconstruction — the order VQLoss calls it in (vq_loss.py:169)."""
         if target.is_cuda and not input.requires_grad:
-            from .ops_dense import LpipsLevelFn
+            from . import ops_dense
             with torch.no_grad():
                 f0 = self.net((input - self.shift) / self.scale)
-            f1 = self.net((target - self.shift) / self.scale)
+            lins = [getattr(self, f"lin{k}").model[-1].weight for k in range(len(self.chns))]
+            x1 = (target - self.shift) / self.scale
+            if FUSED_VGG_BACKWARD and torch.is_autocast_enabled("cuda") and all(f.dtype == torch.bfloat16 for f in f0):
+                # the trunk + the five level comparisons as one node with a hand-driven backward (ops_dense.LpipsVggFn)
+                return ops_dense.LpipsVggFn.apply(x1, self.net, f0, lins).view(-1, 1, 1, 1)
+            f1 = self.net(x1)
             val = 0
             for k in range(len(self.chns)):
-                wk = getattr(self, f"lin{k}").model[-1].weight
-                val = val + LpipsLevelFn.apply(f0[k], f1[k], wk)
+                val = val + ops_dense.LpipsLevelFn.apply(f0[k], f1[k], lins[k])
             return val.view(-1, 1, 1, 1)
         f0 = self.net((input - self.shift) / self.scale)
         f1 = self.net((target - self.shift) / self.scale)

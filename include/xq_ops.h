@@ -201,6 +201,12 @@ int xq_lpips_level_forward(const void *f0, const void *f1, const float *w, int B
 /* g1 [B][HW][C] (dtype of f1) = gout[b] * d val[b] / d f1 */
 int xq_lpips_level_backward(const void *f0, const void *f1, const float *w, const float *gout, int B, int HW, int C,
                             int act_bf16, void *g1, xq_stream_t stream);
+/* The same gradient inside a hand-driven backward pass of the VGG trunk (lpips.py:118-155: every tapped feature map f1 is the
+ * output of a ReLU and also feeds the next slice):  g1 = (gout[b] * d val[b] / d f1 + g_add) * [f1 > 0 if relu_mask]
+ * — g_add (nullable, layout and dtype of f1) is the gradient arriving from the deeper slices; with relu_mask the result is already
+ * the gradient w.r.t. the PRE-activation of the convolution that produced f1.  Replaces autograd's add_ + threshold_backward passes. */
+int xq_lpips_level_backward_fused(const void *f0, const void *f1, const float *w, const float *gout, const void *g_add, int relu_mask,
+                                  int B, int HW, int C, int act_bf16, void *g1, xq_stream_t stream);
 
 /* ---- 3x3 convolution, stride 1, pad 1, NHWC bf16, implicit GEMM on MFMA (xqgan_model.py:454-622 conv3x3 layers;
  *      lpips.py:118-155 VGG16 trunk) ------------------------------------------------------------------------------------ */
@@ -235,7 +241,7 @@ int xq_sumpool2x2_nhwc_bf16(const void *in, int B, int Ho, int Wo, int C, void *
  * row k = (ky * 3 + kx) * 3 + ci, values rounded to bf16 by the caller.  Cout 64 or 128.  conv_in (xqgan_model.py:495), VGG conv1_1
  * (lpips.py:118-155), and — on rotated weights — the data gradient of conv_out. */
 int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, const float *w_kc, const float *bias, int B, int H, int W, int Cout,
-                             void *y_nhwc, xq_stream_t stream);
+                             int relu, void *y_nhwc, xq_stream_t stream);
 /* y planar [B][3][H][W] bf16 = conv3x3(x [B][H][W][C] bf16 NHWC; pad 1) + bias; w_pairs = bf16 [3][9][C] (tap = ky * 3 + kx).
  * conv_out (xqgan_model.py:584) and — on rotated weights — the data gradient of conv_in / VGG conv1_1.  C % 8 == 0. */
 int xq_conv3x3_to3_forward(const void *x_nhwc, const void *w_pairs, const float *bias, int B, int H, int W, int C, void *y_planar,

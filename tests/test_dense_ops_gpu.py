@@ -174,6 +174,39 @@ def test_lpips_level_kernel_vs_reference_expression(C, HW, dt):
     assert (f1.grad.float() - r1.grad)[ok].abs().max() <= tol * r1.grad[ok].abs().max() * 2
 
 
+def test_lpips_hand_driven_vgg_backward_equals_per_op_autograd():
+    """ops_dense.LpipsVggFn (one node: VGG16 trunk + five level comparisons, tap-gradient add and ReLU masks folded into the
+    level kernel) against the same kernels chained by autograd op by op: same value, same gradient w.r.t. the reconstruction."""
+    from imagefolder_amd import vq_loss as vl
+    torch.manual_seed(3)
+    lp = vl.LPIPS().cuda().eval()
+    with torch.no_grad():   # random-init trunk with O(1) activations through all 13 layers
+        for m in lp.net.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                torch.nn.init.kaiming_normal_(m.weight, nonlinearity="relu")
+                m.bias.normal_(0.0, 0.1)
+        for k in range(5):
+            getattr(lp, f"lin{k}").model[-1].weight.uniform_(0.0, 1.0)
+    x = torch.rand(3, 3, 64, 64, device="cuda") * 2 - 1
+    res = {}
+    for fused in (True, False):
+        vl.FUSED_VGG_BACKWARD = fused
+        r = (x + 0.3 * torch.randn(3, 3, 64, 64, device="cuda", generator=torch.Generator("cuda").manual_seed(5))).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            val = lp(x, r)
+        gout = torch.tensor([1.0, 0.5, 2.0], device="cuda").view(-1, 1, 1, 1)
+        (val * gout).sum().backward()
+        res[fused] = (val.detach().float().view(-1), r.grad.detach().float())
+    vl.FUSED_VGG_BACKWARD = True
+    assert torch.isfinite(res[True][1]).all()
+    assert (res[True][0] - res[False][0]).abs().max() <= 1e-6 * res[False][0].abs().max()      # identical forward kernels
+    scale = res[False][1].abs().max().item()
+    assert scale > 0
+    # the fused path adds the tap gradients in fp32 before ONE rounding to bf16 (per-op: two roundings): bf16-level agreement
+    assert (res[True][1] - res[False][1]).abs().max().item() <= 3e-2 * scale
+    assert ((res[True][1] - res[False][1]).norm() / res[False][1].norm()).item() <= 1e-2
+
+
 @pytest.mark.parametrize("shape", [(2, 64, 64, 16, 16), (3, 64, 128, 9, 11), (1, 128, 256, 32, 32), (2, 512, 512, 5, 7), (1, 64, 192, 8, 8)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_conv3x3_implicit_gemm_vs_aten_fp32(shape, relu):
