@@ -97,6 +97,33 @@ class FlatArena:
             if p.grad is None or p.grad.data_ptr() != self.g.data_ptr() + 4 * o:
                 p.grad = self.g[o:o + p.numel()].view(p.shape)
 
+    def release_grads(self):
+        """Before a backward pass: p.grad = None for every parameter.  autograd's AccumulateGrad then ADOPTS the gradient tensor
+        each backward node returns instead of adding it into an existing .grad — one `add_` launch per parameter per step
+        (~500 for the ViT-B tokenizer, 2.2 ms of GPU time: profiles/r02_glue_vq8192.txt) becomes the few multi-tensor copies of
+        collect()."""
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def collect(self, lo: int = 0, hi: Optional[int] = None):
+        """After (part of) a backward pass: move the gradients of params[lo:hi] that live outside the arena into their arena slots
+        (torch._foreach_copy_: multi-tensor kernels) and re-point p.grad at the slots.  The slots are zero beforehand (the
+        optimizer kernel clears them), so parameters that received no gradient contribute zeros, as with accumulation."""
+        hi = len(self.params) if hi is None else hi
+        base = self.g.data_ptr()
+        dst, src = [], []
+        for i in range(lo, hi):
+            p, o = self.params[i], self.offsets[i]
+            g = p.grad
+            view = self.g[o:o + p.numel()].view(p.shape)
+            if g is not None and g.data_ptr() != base + 4 * o:
+                dst.append(view)
+                src.append(g if g.dtype == torch.float32 else g.float())
+            p.grad = view
+        if dst:
+            torch._foreach_copy_(dst, src)
+
     def ema_state_dict(self, names: List[str]):
         return {n: self.ema[o:o + p.numel()].view(p.shape) for n, p, o in zip(names, self.params, self.offsets)}
 
@@ -115,23 +142,25 @@ class GradAllReducer:
     is the arena's fp32, which is what DDP reduces.  always=True runs the collectives at world size 1 too (tests)."""
 
     def __init__(self, flat_grad: torch.Tensor, group=None, chunk_bytes: int = 64 << 20, params=None, offsets=None,
-                 comm_dtype: Optional[torch.dtype] = None, always: bool = False):
+                 comm_dtype: Optional[torch.dtype] = None, always: bool = False, collect_fn: Optional[Callable] = None):
         self.g = flat_grad
+        self.collect_fn = collect_fn          # collect_fn(lo, hi): bring the gradients of params[lo:hi] into the flat buffer
         self.group = group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.active = self.world > 1 or (always and dist.is_available() and dist.is_initialized())
         self.comm_dtype = comm_dtype if comm_dtype not in (None, flat_grad.dtype) else None
         per = max(1, chunk_bytes // 4)
         n = flat_grad.numel()
-        self.chunks, self._chunk_of_param = [], []
+        self.chunks, self._chunk_of_param, self._param_range = [], [], []
         if params is not None and offsets is not None and len(params):
-            start, cur = 0, 0
+            start, cur, first = 0, 0, 0
             for i, (p, o) in enumerate(zip(params, offsets)):
                 end = offsets[i + 1] if i + 1 < len(params) else n
                 self._chunk_of_param.append(cur)
                 if end - start >= per or i + 1 == len(params):
                     self.chunks.append((start, end))
-                    start, cur = end, cur + 1
+                    self._param_range.append((first, i + 1))
+                    start, cur, first = end, cur + 1, i + 1
         else:
             self.chunks = [(s, min(s + per, n)) for s in range(0, n, per)]
         self._need = [0] * len(self.chunks)
@@ -159,6 +188,8 @@ class GradAllReducer:
     def _launch(self, ci):
         s, e = self.chunks[ci]
         self._launched[ci] = True
+        if self.collect_fn is not None and self._param_range:
+            self.collect_fn(*self._param_range[ci])
         if self.comm_dtype is not None:
             buf = self.g[s:e].to(self.comm_dtype)
             w = dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -221,7 +252,7 @@ class ArenaOptimizer:
         self.arena = FlatArena(params, with_ema=use_ema)
         self.reducer = GradAllReducer(self.arena.g, group=group, chunk_bytes=chunk_bytes,
                                       params=self.arena.params if hooks else None, offsets=self.arena.offsets if hooks else None,
-                                      comm_dtype=comm_dtype, always=always_reduce)
+                                      comm_dtype=comm_dtype, always=always_reduce, collect_fn=self.arena.collect if hooks else None)
         self.world = self.reducer.world
 
     # -- checkpointing: the layout of torch.optim.AdamW.state_dict() (what the reference saves as "optimizer" /
@@ -324,7 +355,7 @@ class TokenizerTrainStep:
 
     # -- one train step -----------------------------------------------------------------------------------------
     def step(self, imgs, epoch=0, alpha=0.0, beta=0.0, delta=100):
-        self.arena.rebind_grads()
+        self.arena.release_grads()                 # backward nodes' gradient tensors are adopted, not added (FlatArena.collect)
         dev_type = imgs.device.type
         with torch.autocast(device_type=dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             out = self.model(imgs, epoch, alpha, beta, delta)
@@ -333,7 +364,9 @@ class TokenizerTrainStep:
         self.reducer.arm()                         # chunks leave from the backward hooks as soon as they are complete
         loss_gen.backward()
         _marker(62)
-        self.reducer.start()                       # the rest; RCCL over xGMI, overlapped with ...
+        if not (self.reducer.active and self.reducer.collect_fn is not None):
+            self.arena.collect()                   # single process (or hook-less reducer): everything at once
+        self.reducer.start()                       # the rest (collected chunk by chunk); RCCL over xGMI, overlapped with ...
         if self.disc_step_fn is not None:
             self.disc_step_fn(imgs, out[0].detach())   # ... the discriminator step (needs only recons.detach())
         self.reducer.wait()
@@ -370,14 +403,15 @@ class DiscriminatorStep:
         self.fade_blur_schedule = sd.get("fade_blur_schedule", 0)
 
     def __call__(self, imgs, recons_detached):
-        self.opt.arena.rebind_grads()
         self.opt.zero_grad()  # drops what the generator backward left on the heads (upstream: optimizer_disc.zero_grad())
+        self.opt.arena.release_grads()
         with torch.autocast(device_type=imgs.device.type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
             loss_disc = self.vq_loss(None, None, None, None, imgs, recons_detached, optimizer_idx=1,
                                      global_step=self.global_step + 1, fade_blur_schedule=self.fade_blur_schedule)
         _marker(43)
         loss_disc.backward()
         _marker(44)
+        self.opt.arena.collect()
         self.opt.reducer.start()
         self.opt.reducer.wait()
         self.opt.step()
