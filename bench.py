@@ -72,6 +72,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mfu", action="store_true", help="skip the FlopCounterMode pass (mfu = null)")
     p.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the links")
+    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
+                   help="replay the train step from a hipGraph (train.CapturedStep): auto = single process and a config without "
+                        "per-step host randomness, falling back to the eager step if the capture fails")
     return p.parse_args()
 
 
@@ -283,13 +286,33 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # hipGraph: record the complete step once, replay it in the timed region (same kernels, same buffers; torch's device RNG
+    # advances per replay; nothing of the step is skipped).  The per-kernel HIP-event instrumentation is not part of the graph:
+    # in graph mode the roofline timings come from PROF_STEPS instrumented eager steps run right after the timed region.
+    captured, graph_note = None, "off"
+    if args.workload == "train_step" and args.graph != "off":
+        if use_dist:
+            graph_note = "off (collectives are not recorded: eager step with world > 1)"
+        else:
+            try:
+                captured = ts.capture(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"], warmup=1)
+                for _ in range(2):
+                    captured.replay()
+                graph_note = "on (torch.cuda.CUDAGraph over the whole step: train.CapturedStep)"
+            except Exception as e:  # noqa: BLE001 - fall back to the eager step, say why
+                if args.graph == "on":
+                    raise
+                captured, graph_note = None, f"off (capture failed: {type(e).__name__}: {str(e)[:200]})"
+    run = captured.replay if captured is not None else step
+    torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    lib.xq_prof_enable(1)
+    if captured is None:
+        lib.xq_prof_enable(1)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        run()
         if use_dist and args.workload == "train_step":
             ts.reducer.collect_exposed_ms()   # (elapsed_time of the previous step's events: no extra synchronisation)
     torch.cuda.synchronize()
@@ -297,6 +320,14 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    PROF_STEPS = 3
+    prof_steps = args.steps
+    if captured is not None:
+        lib.xq_prof_enable(1)
+        for _ in range(PROF_STEPS):
+            step()
+        torch.cuda.synchronize()
+        prof_steps = PROF_STEPS
     exposed = ts.reducer.collect_exposed_ms() if args.workload == "train_step" else []
     ms_tot, n_launch = ctypes.c_double(0.0), ctypes.c_int(0)
     kinds = {}
@@ -321,7 +352,7 @@ def main():
         # product branch (single scale) or once per branch and scale (ladder, N_s = B*pn^2)
         tokens_per_branch = B * (sum(p * p for p in CFG["pns"]) if len(CFG["pns"]) > 1 else CFG["L"])
         flops_step = 2.0 * tokens_per_branch * CFG["V"] * CFG["C"] * CFG["P"]
-        launches_step = max(1, n_launch.value // max(1, args.steps))
+        launches_step = max(1, n_launch.value // max(1, prof_steps))
         flops = flops_step / launches_step  # average per launch
         N = tokens_per_branch
         k_ms = ms_tot.value / max(1, n_launch.value)
@@ -347,6 +378,10 @@ def main():
                 "op_impl": dict(nn_ops.IMPL, quantizer="hip", latent_perturbation="hip", adamw_ema="hip",
                                 grad_allreduce="rccl" if world > 1 or os.environ.get("XQ_FORCE_DIST") else "not run (single process)"),
                 "loss": args.loss,
+                "hip_graph": graph_note,
+                "roofline_timing": ("HIP events around every instrumented launch over the timed region" if captured is None else
+                                    f"HIP events around every instrumented launch over {PROF_STEPS} eager steps of the same workload run "
+                                    "right after the timed replays (the graph holds the same kernels without the event records)"),
                 "not_in_timed_region": ((None if args.loss == "full" else
                                          "VQLoss perceptual (LPIPS-VGG16) and adversarial (DinoDisc) terms + discriminator step")
                                         if full else "everything but the quantizer"),
@@ -357,12 +392,12 @@ def main():
         entries = [{"bound": "mfma", "kernel": f"assign_kernel<C={CFG['C']}> (v_mfma_f32_32x32x2_f32, quantizer code search)",
                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops,
-                    "avg_launch_ms": k_ms, "launches": n_launch.value, "ms_per_step": ms_tot.value / args.steps}]
+                    "avg_launch_ms": k_ms, "launches": n_launch.value, "ms_per_step": ms_tot.value / prof_steps}]
         for name, (t_ms, n, work) in kinds.items():
             ach = work / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
             entries.append({"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "flops_per_launch": work / n,
-                            "avg_launch_ms": t_ms / n, "launches": n, "ms_per_step": t_ms / args.steps})
+                            "avg_launch_ms": t_ms / n, "launches": n, "ms_per_step": t_ms / prof_steps})
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE, separate
         # passes, gfx950 read correction applied: tools/pmc_traffic.py); null when that profile does not cover the kernel
         traffic = {}

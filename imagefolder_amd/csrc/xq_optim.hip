@@ -18,6 +18,8 @@
 struct AdamArgs {
     float lr, beta1, beta2, eps, weight_decay, step_size, inv_bc2_sqrt, ema_decay, grad_scale;
     int zero_grad, has_ema;
+    const float *coeffs;   // device [2] = {step_size, inv_bc2_sqrt} (xq_adamw_ema_step_dev: the step count lives on the device so that
+                           // the launch can sit in a hipGraph and still see an advancing step) or null
 };
 
 __device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, float &e, const AdamArgs &a) {
@@ -34,6 +36,7 @@ __device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, fl
 __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, float *__restrict__ g, float *__restrict__ m,
                                                         float *__restrict__ v, float *__restrict__ ema,
                                                         __hip_bfloat16 *__restrict__ p16, long n, AdamArgs a) {
+    if (a.coeffs) { a.step_size = a.coeffs[0]; a.inv_bc2_sqrt = a.coeffs[1]; }
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * 256;
     float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g), *m4 = reinterpret_cast<float4 *>(m),
@@ -64,20 +67,24 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, f
     }
 }
 
-extern "C" int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr,
-                                 float beta1, float beta2, float eps, float weight_decay, int64_t step, float ema_decay,
-                                 float grad_scale, int zero_grad, xq_stream_t stream) {
+static int adamw_launch(const char *fn, float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr, float beta1,
+                        float beta2, float eps, float weight_decay, int64_t step, const float *coeffs, float ema_decay, float grad_scale,
+                        int zero_grad, xq_stream_t stream) {
     if (n == 0) return XQ_OK;
-    if (!p || !g || !m || !v) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_adamw_ema_step");
-    if (n < 0 || step < 1) return xq_set_error(XQ_EINVAL, "%s: bad n/step (%ld, %ld)", "xq_adamw_ema_step", (long)n, (long)step);
+    if (!p || !g || !m || !v) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (n < 0 || (!coeffs && step < 1)) return xq_set_error(XQ_EINVAL, "%s: bad n/step (%ld, %ld)", fn, (long)n, (long)step);
     if ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) != 0)
-        return xq_set_error(XQ_EINVAL, "%s: arenas must be 16-byte aligned", "xq_adamw_ema_step");
+        return xq_set_error(XQ_EINVAL, "%s: arenas must be 16-byte aligned", fn);
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    a.step_size = (float)((double)lr / bc1);
-    a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    a.coeffs = coeffs;
+    if (coeffs) { a.step_size = 0.0f; a.inv_bc2_sqrt = 0.0f; }
+    else {
+        const double bc1 = 1.0 - pow((double)beta1, (double)step);
+        const double bc2 = 1.0 - pow((double)beta2, (double)step);
+        a.step_size = (float)((double)lr / bc1);
+        a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    }
     a.ema_decay = ema_decay; a.grad_scale = grad_scale;
     a.zero_grad = zero_grad; a.has_ema = ema != nullptr;
     long blocks = (n / 4 + 255) / 256;
@@ -87,4 +94,19 @@ extern "C" int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (__hip_bfloat16 *)p_bf16,
                        (long)n, a);
     return xq_check_launch("adamw_ema_kernel");
+}
+
+extern "C" int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int64_t step, float ema_decay,
+                                 float grad_scale, int zero_grad, xq_stream_t stream) {
+    return adamw_launch("xq_adamw_ema_step", p, g, m, v, ema, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, ema_decay,
+                        grad_scale, zero_grad, stream);
+}
+
+extern "C" int xq_adamw_ema_step_dev(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr,
+                                     float beta1, float beta2, float eps, float weight_decay, const float *coeffs, float ema_decay,
+                                     float grad_scale, int zero_grad, xq_stream_t stream) {
+    if (!coeffs) return xq_set_error(XQ_EINVAL, "%s: null coefficient pointer", "xq_adamw_ema_step_dev");
+    return adamw_launch("xq_adamw_ema_step_dev", p, g, m, v, ema, p_bf16, n, lr, beta1, beta2, eps, weight_decay, 0, coeffs, ema_decay,
+                        grad_scale, zero_grad, stream);
 }

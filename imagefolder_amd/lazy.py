@@ -7,13 +7,18 @@ import torch
 
 
 class LazyFloat:
-    __slots__ = ("_host", "_event", "_scale", "_value")
+    __slots__ = ("_host", "_event", "_scale", "_value", "_dev")
 
     def __init__(self, device_scalar: torch.Tensor, scale: float = 1.0):
         self._scale = scale
         self._value = None
         t = device_scalar.detach().reshape(())
-        if t.is_cuda:
+        self._dev = None
+        if t.is_cuda and torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture (train.TokenizerTrainStep.capture): no host copy, no event — the scalar lives in the graph's
+            # memory pool and is rewritten by every replay; reading it synchronises (a logging-time cost, not a per-step one)
+            self._host, self._event, self._dev = None, None, t
+        elif t.is_cuda:
             self._host = torch.empty((), dtype=t.dtype, pin_memory=True)
             self._host.copy_(t, non_blocking=True)
             self._event = torch.cuda.Event()
@@ -22,6 +27,8 @@ class LazyFloat:
             self._host, self._event = t.clone(), None
 
     def _get(self) -> float:
+        if self._dev is not None:          # captured: always re-read (the graph may have been replayed since)
+            return float(self._dev.item()) * self._scale
         if self._value is None:
             if self._event is not None:
                 self._event.synchronize()
@@ -98,6 +105,8 @@ def lazy_list(device_vector: torch.Tensor, scale: float = 1.0):
     v = device_vector.detach().reshape(-1)
     if not v.is_cuda:
         return [float(x) * scale for x in v.tolist()]
+    if torch.cuda.is_current_stream_capturing():
+        return [LazyFloat(v[i], scale) for i in range(v.numel())]
     host = torch.empty(v.shape, dtype=v.dtype, pin_memory=True)
     host.copy_(v, non_blocking=True)
     ev = torch.cuda.Event()
@@ -105,6 +114,6 @@ def lazy_list(device_vector: torch.Tensor, scale: float = 1.0):
     out = []
     for i in range(v.numel()):
         lf = LazyFloat.__new__(LazyFloat)
-        lf._host, lf._event, lf._scale, lf._value = host[i], ev, scale, None
+        lf._host, lf._event, lf._scale, lf._value, lf._dev = host[i], ev, scale, None, None
         out.append(lf)
     return out

@@ -302,16 +302,39 @@ class ArenaOptimizer:
         a.step_count += 1
         a.epoch += 1            # masters change through raw pointers below: derived caches must refresh
         if a.p.is_cuda:
+            stream = ctypes.c_void_p(torch.cuda.current_stream(a.p.device).cuda_stream)
             with torch.cuda.device(a.p.device):
+                if torch.cuda.is_current_stream_capturing():
+                    # hipGraph capture (CapturedStep): the step count must advance on every REPLAY, so it lives on the device:
+                    # counter += 1 and the two bias-correction factors are (captured) tensor ops in double, the kernel reads them
+                    if getattr(self, "_step_dev", None) is None:
+                        raise RuntimeError("ArenaOptimizer.prepare_capture() must run before the step is captured")
+                    with torch.no_grad():
+                        self._step_dev.add_(1.0)
+                        bc1 = 1.0 - torch.pow(torch.full_like(self._step_dev, self.betas[0]), self._step_dev)
+                        bc2 = 1.0 - torch.pow(torch.full_like(self._step_dev, self.betas[1]), self._step_dev)
+                        self._coeffs.copy_(torch.cat([self.lr / bc1, torch.rsqrt(bc2)]).float())
+                    rc = _lib.lib().xq_adamw_ema_step_dev(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
+                                                          ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
+                                                          ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
+                                                          ctypes.c_float(self.weight_decay), ptr(self._coeffs),
+                                                          ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
+                    check(rc, "xq_adamw_ema_step_dev")
+                    return
                 rc = _lib.lib().xq_adamw_ema_step(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
                                                   ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
                                                   ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
                                                   ctypes.c_float(self.weight_decay), a.step_count,
-                                                  ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1,
-                                                  ctypes.c_void_p(torch.cuda.current_stream(a.p.device).cuda_stream))
+                                                  ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
             check(rc, "xq_adamw_ema_step")
         else:
             self._step_host()
+
+    def prepare_capture(self):
+        """device-resident step counter (= the steps taken so far) + coefficient buffer for a captured step"""
+        dev = self.arena.p.device
+        self._step_dev = torch.full((1,), float(self.arena.step_count), dtype=torch.float64, device=dev)
+        self._coeffs = torch.zeros(2, dtype=torch.float32, device=dev)
 
     @torch.no_grad()
     def _step_host(self):
@@ -374,6 +397,66 @@ class TokenizerTrainStep:
         self.opt.step()                            # AdamW + EMA + zero_grad + 1/world in one pass
         _marker(71)
         return loss_gen.detach()
+
+    def capture(self, imgs, epoch=0, alpha=0.0, beta=0.0, delta=100, **kw) -> "CapturedStep":
+        """record this step into a hipGraph: see CapturedStep"""
+        return CapturedStep(self, imgs, epoch, alpha, beta, delta, **kw)
+
+
+class CapturedStep:
+    """The complete train step of a TokenizerTrainStep recorded once into a hipGraph (torch.cuda.CUDAGraph) and replayed.
+
+    Why: at B = 128 the GPU kernels of a step take ~204 ms but the eager step ~212 ms — a few thousand small launches
+    (discriminator heads, spectral norm, loss assembly) leave bubbles that the 200+ us GEMMs around them do not cover; the replay
+    has none (profiles/r02_hipgraph_probe.txt).  What a replay is: the same kernels on the same buffers — new data is copied into
+    `static_imgs` first (replay(imgs) does it), torch's CUDA generator advances its Philox offset per replay (DropPath masks,
+    DiffAug draws, perturbation draws differ from step to step as in eager mode), the optimizer's step counter lives on the device.
+    What is FROZEN at capture time: every host-side decision — DiffAug's three branch draws (constant anyway at the reference's
+    aug_prob = 1.0), the quantizer-dropout depths of codebook_drop > 0 configs (numpy draws upstream), epoch / alpha / beta / delta,
+    learning rates.  capture() refuses models with codebook_drop > 0 unless allow_frozen_host_rng=True.
+    Single process only (collectives are not recorded): with world > 1 use the eager step."""
+
+    def __init__(self, ts: "TokenizerTrainStep", imgs: torch.Tensor, epoch=0, alpha=0.0, beta=0.0, delta=100, warmup: int = 2,
+                 allow_frozen_host_rng: bool = False):
+        if ts.reducer.active:
+            raise RuntimeError("CapturedStep: the gradient all-reduce is not recorded; use TokenizerTrainStep.step with world > 1")
+        if not allow_frozen_host_rng and float(getattr(ts.model, "codebook_drop", 0.0) or 0.0) > 0:
+            raise RuntimeError("CapturedStep: codebook_drop > 0 draws the dropout depths on the host every step; a replay would "
+                               "freeze them (allow_frozen_host_rng=True to accept that)")
+        self.ts = ts
+        self.static_imgs = imgs.clone()
+        side = torch.cuda.Stream(device=imgs.device)
+        side.wait_stream(torch.cuda.current_stream(imgs.device))
+        with torch.cuda.stream(side):                 # warm-up on a side stream (lazy initialisations, allocator, workspace caches)
+            for _ in range(warmup):
+                ts.step(self.static_imgs, epoch, alpha, beta, delta)
+        torch.cuda.current_stream(imgs.device).wait_stream(side)
+        ts.opt.prepare_capture()
+        disc = ts.disc_step_fn if isinstance(ts.disc_step_fn, DiscriminatorStep) else None
+        if disc is not None:
+            disc.opt.prepare_capture()
+        self.graph = torch.cuda.CUDAGraph()
+        c0 = (ts.arena.step_count, ts.arena.epoch)
+        with torch.cuda.graph(self.graph):
+            self.loss = ts.step(self.static_imgs, epoch, alpha, beta, delta)
+        # the capture pass ran the host bookkeeping once without executing anything: take it back; replay() redoes it per step
+        ts.arena.step_count, ts.arena.epoch = c0
+        if disc is not None:
+            disc.opt.arena.step_count -= 1
+            disc.global_step -= 1
+        self._disc = disc
+
+    def replay(self, imgs: Optional[torch.Tensor] = None):
+        if imgs is not None and imgs.data_ptr() != self.static_imgs.data_ptr():
+            self.static_imgs.copy_(imgs, non_blocking=True)
+        self.graph.replay()
+        self.ts.arena.step_count += 1
+        self.ts.arena.epoch += 1
+        if self._disc is not None:
+            self._disc.opt.arena.step_count += 1
+            self._disc.opt.arena.epoch += 1
+            self._disc.global_step += 1
+        return self.loss
 
 
 class DiscriminatorStep:

@@ -35,14 +35,26 @@ def adopt_weight(weight, global_step, threshold=0, value=0.):
 
 
 class LeCAM_EMA(object):
+    """vq_loss.py:37-48 upstream: running means of the discriminator logits.  Upstream reads both means back with .item() —
+    two device synchronisations in the middle of every train step; here the pair lives in a 2-element device tensor updated in
+    place (no host round trip, hipGraph-capturable); on CPU tensors the host-float arithmetic of the reference is kept."""
+
     def __init__(self, init=0., decay=0.999):
         self.logits_real_ema = init
         self.logits_fake_ema = init
         self.decay = decay
+        self._dev = None
 
     def update(self, logits_real, logits_fake):
-        # upstream syncs twice per step here (.item()); one transfer for both means
-        means = torch.stack([logits_real.detach().mean(), logits_fake.detach().mean()]).tolist()
+        m_real, m_fake = logits_real.detach().float().mean(), logits_fake.detach().float().mean()
+        if logits_real.is_cuda:
+            if self._dev is None:
+                self._dev = torch.tensor([float(self.logits_real_ema), float(self.logits_fake_ema)], dtype=torch.float32,
+                                         device=logits_real.device)
+                self.logits_real_ema, self.logits_fake_ema = self._dev[0], self._dev[1]      # views: follow the in-place updates
+            self._dev.mul_(self.decay).add_(torch.stack([m_real, m_fake]), alpha=1 - self.decay)
+            return
+        means = torch.stack([m_real, m_fake]).tolist()
         self.logits_real_ema = self.logits_real_ema * self.decay + means[0] * (1 - self.decay)
         self.logits_fake_ema = self.logits_fake_ema * self.decay + means[1] * (1 - self.decay)
 
@@ -236,11 +248,15 @@ class DiffAug(object):
             ch, cw = round(H * self.cutout), round(W * self.cutout)
             oh = rand01[5].mul(H + (1 - ch % 2)).floor().long()
             ow = rand01[6].mul(W + (1 - cw % 2)).floor().long()
-            gb, gh, gw = self._grids(B, ch, cw, dev)
-            gh = (gh + oh).sub(ch // 2).clamp(min=0, max=H - 1)
-            gw = (gw + ow).sub(cw // 2).clamp(min=0, max=W - 1)
-            mask = torch.ones(B, H, W, dtype=BCHW.dtype, device=dev)
-            mask[gb, gh, gw] = 0
+            # upstream zeroes mask[b, clamp(i + oh - ch//2), clamp(j + ow - cw//2)] for the ch x cw grid (diffaug.py:103-113).  The box
+            # always overlaps the image (0 <= oh - ch//2 + ch - 1 and oh - ch//2 <= H - 1), so the clamped index set is the
+            # intersection of the box with the image: an outer product of a row and a column indicator — no index_put (which is
+            # not capturable in a hipGraph and sorts its indices)
+            s_h, s_w = oh.view(B, 1) - ch // 2, ow.view(B, 1) - cw // 2
+            ar_h, ar_w = torch.arange(H, device=dev).view(1, H), torch.arange(W, device=dev).view(1, W)
+            rows = ((ar_h >= s_h) & (ar_h <= s_h + (ch - 1))).to(BCHW.dtype)
+            cols = ((ar_w >= s_w) & (ar_w <= s_w + (cw - 1))).to(BCHW.dtype)
+            mask = 1 - rows.unsqueeze(2) * cols.unsqueeze(1)
             BCHW = BCHW.mul(mask.unsqueeze(1))
         return BCHW
 

@@ -157,6 +157,12 @@ int xq_msvq_backward(const float *f, int B, int C, int H, int W, int V, const in
 int xq_adamw_ema_step(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr, float beta1,
                       float beta2, float eps, float weight_decay, int64_t step, float ema_decay, float grad_scale,
                       int zero_grad, xq_stream_t stream);
+/* The same step with the bias-correction factors read from device memory: coeffs [2] = { lr / (1 - beta1^step), 1 / sqrt(1 - beta2^step) }
+ * computed by the caller from a device-resident step counter, so that the launch can be recorded in a hipGraph (train.CapturedStep) and
+ * still see the step advance on every replay. */
+int xq_adamw_ema_step_dev(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, const float *coeffs, float ema_decay, float grad_scale,
+                          int zero_grad, xq_stream_t stream);
 
 /* ---- fused row kernels of the ViT blocks (dino_enc/vision_transformer.py:280-339; timm Mlp) ------------------------
  * Activations are [rows][D] row-major; act_bf16 selects their dtype (1 = bf16, 0 = fp32); the residual stream,
