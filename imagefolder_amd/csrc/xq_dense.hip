@@ -23,8 +23,14 @@
 
 using namespace xq;
 
+#ifndef XQ_MAX_ROW_BLOCKS
+#define XQ_MAX_ROW_BLOCKS 512
+#endif
+#ifndef XQ_FWD_BLOCKS_PER_CU
+#define XQ_FWD_BLOCKS_PER_CU 2
+#endif
 static constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows in flight per block
-static constexpr int MAX_ROW_BLOCKS = 512;   // also the number of partial rows the finalize kernel reduces
+static constexpr int MAX_ROW_BLOCKS = XQ_MAX_ROW_BLOCKS;   // also the number of partial rows the finalize kernel reduces
 
 // element index of (chunk k, lane l, j): k*64*VEC + l*VEC + j  -> each wave instruction reads 64*VEC contiguous elements
 template <typename T, int NV, int VEC>
@@ -274,6 +280,14 @@ static int row_blocks(long rows) {
 
 extern "C" int xq_row_partials_blocks(int64_t rows) { return row_blocks((long)rows); }
 
+// kernels without column partials (the forward passes): the block count is only a question of bytes in flight
+static int row_blocks_fwd(long rows) {
+    long b = (rows + 3) / 4;
+    const long cap = (long)num_cus() * XQ_FWD_BLOCKS_PER_CU;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
 #define DISPATCH_D(D, F)                                                           \
     switch (D) {                                                                   \
         case 64: F(1, 1); break;                                                   \
@@ -294,7 +308,7 @@ extern "C" int xq_res_ln_forward(const float *x, const void *y, const float *gam
     if (!x || !lnw || !lnb || !a || !mean || !rstd) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     if (rows < 0 || rows_per_sample < 1) return xq_set_error(XQ_EINVAL, "%s: bad rows", fn);
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = row_blocks(rows);
+    const int blocks = row_blocks_fwd(rows);
 #define FWD_BF16(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const bf16 *)y, \
         gamma, mask, (long)rows, rows_per_sample, lnw, lnb, eps, x_new, (bf16 *)a, mean, rstd)
 #define FWD_F32(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const float *)y, \
