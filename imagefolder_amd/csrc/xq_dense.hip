@@ -24,10 +24,10 @@
 using namespace xq;
 
 #ifndef XQ_MAX_ROW_BLOCKS
-#define XQ_MAX_ROW_BLOCKS 512
+#define XQ_MAX_ROW_BLOCKS 2048   // 8 blocks = 32 waves per CU: the row kernels are bound by bytes in flight (512: 3.9 TB/s, 2048: 4.4 TB/s backward at 65 664 x 768)
 #endif
 #ifndef XQ_FWD_BLOCKS_PER_CU
-#define XQ_FWD_BLOCKS_PER_CU 2
+#define XQ_FWD_BLOCKS_PER_CU 8
 #endif
 static constexpr int ROW_THREADS = 256;  // 4 waves = 4 rows in flight per block
 static constexpr int MAX_ROW_BLOCKS = XQ_MAX_ROW_BLOCKS;   // also the number of partial rows the finalize kernel reduces
