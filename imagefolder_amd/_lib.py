@@ -46,6 +46,8 @@ SIGNATURES = {
                                          ctypes.c_int, vp]),
     "xq_adamw_ema_step_dev": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_float, vp, ctypes.c_float, ctypes.c_float, ctypes.c_int, vp]),
+    "xq_vec_normalize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
+    "xq_sn_weight_grad": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp, vp]),
     "xq_row_partials_blocks": (ctypes.c_int, [ctypes.c_int64]),
     "xq_res_ln_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float,
                                          ctypes.c_int, vp, vp, vp, vp, vp]),

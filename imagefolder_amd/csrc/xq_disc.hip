@@ -288,3 +288,53 @@ extern "C" int xq_fold1d_circular(const void *dcols, int B, int L, int C, int K,
     else hipLaunchKernelGGL((fold1d_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, (const float *)dcols, B, L, C, K, (float *)dh);
     return xq_check_launch(fn);
 }
+
+// ---- spectral normalisation of the head convolutions (discriminator_dino.py:121-124 -> torch.nn.utils.spectral_norm, one power
+//      iteration per training forward).  The library formulation costs ~14 launches forward (two gemv, two F.normalize = norm + clamp
+//      + div each, two clones, a third gemv, a dot, W / sigma) and ~10 backward per convolution — 45 convolution calls per train step.
+//      Here: gemv -> vec_normalize -> gemv -> vec_normalize (its norm IS sigma: u^T W v = |W v| when u = W v / |W v|) -> W / sigma, and
+//      a two-launch backward (a dot, then sn_weight_grad).  All fp32. ------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vec_normalize_kernel(const float *__restrict__ x, int n, float eps, float *__restrict__ out,
+                                                            float *__restrict__ norm_out) {
+    __shared__ float red[4];
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) s = __builtin_fmaf(x[i], x[i], s);
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float nrm = __builtin_sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+    const float d = nrm > eps ? nrm : eps;                 // F.normalize: x / max(|x|, eps)
+    for (int i = threadIdx.x; i < n; i += 256) out[i] = x[i] / d;
+    if (norm_out && threadIdx.x == 0) norm_out[0] = nrm;
+}
+
+// g_W[i][j] = g[i][j] / sigma - (dot / sigma^2) * u[i] * v[j]   (d/dW of W / sigma with sigma = u^T W v, u and v constants; dot = <g, W>)
+__global__ __launch_bounds__(256) void sn_weight_grad_kernel(const float *__restrict__ g, const float *__restrict__ u, const float *__restrict__ v,
+                                                             const float *__restrict__ sigma, const float *__restrict__ dot, long rows, long cols,
+                                                             float *__restrict__ out) {
+    const float inv = 1.0f / sigma[0];
+    const float coef = dot[0] * inv * inv;
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cols, c = i - r * cols;
+        out[i] = g[i] * inv - coef * u[r] * v[c];
+    }
+}
+
+extern "C" int xq_vec_normalize(const float *x, int n, float eps, float *out, float *norm_out, xq_stream_t stream) {
+    if (n <= 0) return XQ_OK;
+    if (!x || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_vec_normalize");
+    hipLaunchKernelGGL(vec_normalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, n, eps, out, norm_out);
+    return xq_check_launch("xq_vec_normalize");
+}
+
+extern "C" int xq_sn_weight_grad(const float *g, const float *u, const float *v, const float *sigma, const float *dot, int64_t rows, int64_t cols,
+                                 float *out, xq_stream_t stream) {
+    if (rows <= 0 || cols <= 0) return XQ_OK;
+    if (!g || !u || !v || !sigma || !dot || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_sn_weight_grad");
+    long blocks = (rows * cols + 255) / 256;
+    const long cap = (long)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(sn_weight_grad_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g, u, v, sigma, dot, (long)rows, (long)cols, out);
+    return xq_check_launch("xq_sn_weight_grad");
+}

@@ -990,6 +990,42 @@ class SpatialAttentionFn(torch.autograd.Function):
 
 
 # ---- DinoDisc heads (csrc/xq_disc.hip) ------------------------------------------------------------------------------------
+class SpectralNormWeightFn(torch.autograd.Function):
+    """W / sigma for a spectrally normalised weight in TRAINING mode (torch.nn.utils.spectral_norm semantics, n_power_iterations = 1,
+    discriminator_dino.py:121-124): one power iteration updating the u / v buffers in place (no gradient through them), sigma = u^T W v,
+    gradient d(W / sigma)/dW with u, v constant.  5 launches forward, 2 backward (library formulation: ~14 + ~10), fp32."""
+
+    @staticmethod
+    def forward(ctx, W, u, v, eps):
+        Wm = W.detach().reshape(W.shape[0], -1)
+        if not Wm.is_contiguous():
+            Wm = Wm.contiguous()
+        lib, st = _lib.lib(), _stream(Wm)
+        sigma = torch.empty(1, dtype=torch.float32, device=Wm.device)
+        with torch.cuda.device(Wm.device):
+            t = torch.mv(Wm.t(), u)
+            check(lib.xq_vec_normalize(ptr(t), t.numel(), ctypes.c_float(eps), ptr(v), None, st), "xq_vec_normalize")      # v <- normalize(W^T u)
+            s = torch.mv(Wm, v)
+            check(lib.xq_vec_normalize(ptr(s), s.numel(), ctypes.c_float(eps), ptr(u), ptr(sigma), st), "xq_vec_normalize")  # u <- normalize(W v)
+        # u^T W v = |W v|^2 / max(|W v|, eps) = |W v| (the norm the kernel returned) unless W v underflows eps
+        out = W.detach() / sigma
+        ctx.save_for_backward(Wm, u.clone(), v.clone(), sigma)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        Wm, u, v, sigma = ctx.saved_tensors
+        gm = g.reshape(Wm.shape).float()
+        if not gm.is_contiguous():
+            gm = gm.contiguous()
+        dot = torch.dot(gm.reshape(-1), Wm.reshape(-1)).reshape(1)
+        out = torch.empty_like(gm)
+        with torch.cuda.device(gm.device):
+            rc = _lib.lib().xq_sn_weight_grad(ptr(gm), ptr(u), ptr(v), ptr(sigma), ptr(dot), Wm.shape[0], Wm.shape[1], ptr(out), _stream(gm))
+        check(rc, "xq_sn_weight_grad")
+        return out.view(g.shape), None, None, None
+
+
 class BNLocalLReLUFn(torch.autograd.Function):
     """out = LeakyReLU(BatchNormLocal(y)) [+ skip, * ratio] on token-major y (B, L, C): statistics per virtual batch of
     `virtual_bs` samples and channel over its virtual_bs * L tokens (discriminator_dino.py:127-154, :113-119, :157-166)."""

@@ -66,6 +66,7 @@ def lecam_reg(real_pred, fake_pred, lecam_ema):
 
 # ---- LPIPS (lpips.py) -------------------------------------------------------------------------------------------
 FUSED_VGG_BACKWARD = __import__("os").environ.get("XQ_FUSED_VGG", "1") == "1"
+FUSED_SPECTRAL_NORM = __import__("os").environ.get("XQ_FUSED_SN", "1") == "1"
 _VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]  # features[0:30]
 
 
@@ -360,6 +361,9 @@ class _SpectralConv1d(nn.Conv1d):
     def _normalised_weight(self):
         with torch.autocast(device_type=self.weight_orig.device.type, enabled=False):
             W = self.weight_orig
+            if self.training and W.is_cuda and W.dtype == torch.float32 and FUSED_SPECTRAL_NORM:
+                from .ops_dense import SpectralNormWeightFn
+                return SpectralNormWeightFn.apply(W, self.weight_u, self.weight_v, 1e-12)
             Wm = W.reshape(W.shape[0], -1)
             u, v = self.weight_u, self.weight_v
             if self.training:  # one power iteration per training forward, like SpectralNorm.compute_weight

@@ -273,6 +273,15 @@ int xq_row_softmax_backward(const float *P32, const void *dP, int64_t rows, int 
 int xq_maxpool2x2_nhwc_bf16_forward(const void *X, int B, int Ho, int Wo, int C, void *Y, xq_stream_t stream);
 int xq_maxpool2x2_nhwc_bf16_backward(const void *X, const void *G, int B, int Ho, int Wo, int C, void *GX, xq_stream_t stream);
 
+/* ---- spectral normalisation of the discriminator head convolutions (discriminator_dino.py:121-124: torch spectral_norm, one power
+ *      iteration per training forward), fp32 ------------------------------------------------------------------------------------ */
+/* out = x / max(|x|_2, eps) (F.normalize); norm_out (nullable) [1] = |x|_2.  One workgroup: n <= a few thousand elements. */
+int xq_vec_normalize(const float *x, int n, float eps, float *out, float *norm_out, xq_stream_t stream);
+/* out[rows][cols] = g / sigma - (dot / sigma^2) u v^T : the gradient of W / sigma w.r.t. W for sigma = u^T W v with u, v held constant;
+ * sigma [1], dot [1] = <g, W> on the device. */
+int xq_sn_weight_grad(const float *g, const float *u, const float *v, const float *sigma, const float *dot, int64_t rows, int64_t cols,
+                      float *out, xq_stream_t stream);
+
 /* ---- multi-head self-attention on the packed qkv projection (dino_enc/vision_transformer.py:175-195: qkv.reshape(B,N,3,H,hd)
  *      .permute(2,0,3,1,4) -> F.scaled_dot_product_attention -> transpose(1,2).reshape(B,N,C); discriminator_dino.py:28).
  *      bf16 MFMA, fp32 softmax statistics, head_dim 64 only, no mask, no dropout. ------------------------------------------ */

@@ -500,3 +500,25 @@ def test_linear_with_widths_outside_the_gemm_contract_is_zero_padded_onto_it(M, 
     for a, r, name in ((y.float(), yr, "y"), (gx, gxr, "gx"), (gw, gwr, "gw"), (gb, gbr, "gb")):
         err = (a - r).abs().max().item()
         assert err <= 2e-2 * max(1.0, r.abs().max().item()), (name, err)
+
+
+@pytest.mark.parametrize("shape", [(384, 384, 9), (384, 384, 1), (1, 384, 1), (96, 40, 5)])
+def test_spectral_norm_weight_fn_equals_the_library_formulation(shape):
+    """ops_dense.SpectralNormWeightFn (5 + 2 launches) == vq_loss._SpectralConv1d's library path == torch.nn.utils.spectral_norm in
+    training mode: normalised weight, updated u / v buffers, gradient w.r.t. weight_orig."""
+    from imagefolder_amd import vq_loss as vl
+    torch.manual_seed(sum(shape))
+    Co, Ci, k = shape
+    res = {}
+    for fused in (True, False):
+        vl.FUSED_SPECTRAL_NORM = fused
+        torch.manual_seed(11)
+        conv = vl._SpectralConv1d(Ci, Co, k, padding=k // 2, padding_mode='circular').cuda().train()
+        g = torch.randn(Co, Ci, k, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+        for _ in range(3):                     # three forwards: the buffers evolve
+            W = conv._normalised_weight()
+        (gw,) = torch.autograd.grad(W, conv.weight_orig, g)
+        res[fused] = (W.detach().clone(), conv.weight_u.clone(), conv.weight_v.clone(), gw)
+    vl.FUSED_SPECTRAL_NORM = True
+    for a, b in zip(res[True], res[False]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
