@@ -1,0 +1,189 @@
+// xq_aug.hip — DiffAug (translation, colour, cut-out) on a planar fp32 image batch in two launches per direction (gfx950).
+//
+// Replaces the ~15 elementwise / gather / reduction launches per call of the reference's differentiable augmentation
+// (tokenizer/tokenizer_image/diffaug.py:64-118; called three times per train step on (B, 3, 256, 256) images: vq_loss.py:169,209-210)
+// and their ~20 autograd launches in the generator pass.  Per sample b, with the seven uniform draws r0..r6 of the call
+// (rand01[k][b], drawn by torch exactly as upstream, so the random stream is unchanged):
+//   translation : x0[c][i][j] = x[c][i + th][j + tw] inside the image, 0 outside;  th = floor(r0 (2 dh + 1)) - dh,  tw likewise (r1)
+//   brightness  : x1 = x0 + (r2 - 0.5)
+//   saturation  : x2 = (x1 - m1) (2 r3) + m1,      m1 = mean over the 3 channels of the pixel
+//   contrast    : x3 = (x2 - m2) (r4 + 0.5) + m2,  m2 = mean over (c, i, j) of x2  = mean(x0) + (r2 - 0.5)  (saturation keeps pixel means)
+//   cut-out     : x4 = x3 * [ (i, j) outside the ch x cw box centred at (floor(r5 (H + 1 - ch % 2)), floor(r6 (W + 1 - cw % 2))) ]
+// Pass 1 reduces the per-sample sum (of x over the translated window forward, of g * mask backward) into per-block partials
+// (summed in a fixed order by pass 2: deterministic); pass 2 is one thread per pixel, three planes, coalesced rows.
+// The backward is the exact transpose: g3 = g mask; g2 = con g3 + (1 - con) sum(g3) / (3 H W); g1 = sat g2 + (1 - sat) mean_c(g2);
+// g_x[c][i'][j'] = g1[c][i' - th][j' - tw] inside the image.
+#include "xq_common.hpp"
+#include "xq_internal.hpp"
+#include "../../include/xq_ops.h"
+
+using namespace xq;
+
+namespace {
+
+constexpr int AUG_SLABS = 64;     // partial sums per sample
+
+struct AugArgs {
+    const float *rand01;   // [7][B]
+    int B, H, W, dh, dw, ch, cw;
+    int trans, color, cut;
+};
+
+struct AugSample {
+    int th, tw, oh, ow;
+    float br, sat, con;
+};
+
+__device__ __forceinline__ AugSample aug_sample(const AugArgs &a, int b) {
+    AugSample s;
+    const float *r = a.rand01;
+    s.th = a.trans ? (int)floorf(r[0 * a.B + b] * (float)(2 * a.dh + 1)) - a.dh : 0;
+    s.tw = a.trans ? (int)floorf(r[1 * a.B + b] * (float)(2 * a.dw + 1)) - a.dw : 0;
+    s.br = r[2 * a.B + b] - 0.5f;
+    s.sat = r[3 * a.B + b] * 2.0f;
+    s.con = r[4 * a.B + b] + 0.5f;
+    s.oh = (int)floorf(r[5 * a.B + b] * (float)(a.H + (1 - a.ch % 2)));
+    s.ow = (int)floorf(r[6 * a.B + b] * (float)(a.W + (1 - a.cw % 2)));
+    return s;
+}
+
+__device__ __forceinline__ float aug_mask(const AugArgs &a, const AugSample &s, int i, int j) {
+    if (!a.cut) return 1.0f;
+    const int sh = s.oh - a.ch / 2, sw = s.ow - a.cw / 2;
+    const bool in = i >= sh && i <= sh + a.ch - 1 && j >= sw && j <= sw + a.cw - 1;
+    return in ? 0.0f : 1.0f;
+}
+
+__device__ __forceinline__ float block_sum_256(float v, float *red) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// forward pass 1: partial[b][slab] = sum over the slab's DESTINATION pixels of x0 (3 channels); backward: of g * mask
+template <bool BWD>
+__global__ __launch_bounds__(256) void aug_sum_kernel(const float *__restrict__ x, AugArgs a, float *__restrict__ partial) {
+    __shared__ float red[4];
+    const int b = blockIdx.y, slab = blockIdx.x;
+    const AugSample s = aug_sample(a, b);
+    const long HW = (long)a.H * a.W;
+    const long per = (HW + AUG_SLABS - 1) / AUG_SLABS;
+    const long p0 = slab * per, p1 = p0 + per < HW ? p0 + per : HW;
+    const float *xb = x + (long)b * 3 * HW;
+    float acc = 0.0f;
+    for (long p = p0 + threadIdx.x; p < p1; p += 256) {
+        const int i = (int)(p / a.W), j = (int)(p - (long)i * a.W);
+        if (BWD) {
+            const float m = aug_mask(a, s, i, j);
+            acc += m * ((xb[p] + xb[HW + p]) + xb[2 * HW + p]);
+        } else {
+            const int si = i + s.th, sj = j + s.tw;
+            if (si >= 0 && si < a.H && sj >= 0 && sj < a.W) {
+                const long q = (long)si * a.W + sj;
+                acc += (xb[q] + xb[HW + q]) + xb[2 * HW + q];
+            }
+        }
+    }
+    const float t = block_sum_256(acc, red);
+    if (threadIdx.x == 0) partial[b * AUG_SLABS + slab] = t;
+}
+
+__device__ __forceinline__ float aug_total(const float *partial, int b) {
+    float t = 0.0f;
+    for (int k = 0; k < AUG_SLABS; ++k) t += partial[b * AUG_SLABS + k];
+    return t;
+}
+
+__global__ __launch_bounds__(256) void aug_apply_fwd_kernel(const float *__restrict__ x, AugArgs a, const float *__restrict__ partial,
+                                                            float *__restrict__ y) {
+    const int b = blockIdx.y;
+    const AugSample s = aug_sample(a, b);
+    const long HW = (long)a.H * a.W;
+    const float m2 = aug_total(partial, b) / (float)(3 * HW) + s.br;
+    const float *xb = x + (long)b * 3 * HW;
+    float *yb = y + (long)b * 3 * HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        const int i = (int)(p / a.W), j = (int)(p - (long)i * a.W);
+        const int si = i + s.th, sj = j + s.tw;
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+        if (si >= 0 && si < a.H && sj >= 0 && sj < a.W) {
+            const long q = (long)si * a.W + sj;
+            v0 = xb[q]; v1 = xb[HW + q]; v2 = xb[2 * HW + q];
+        }
+        if (a.color) {
+            v0 += s.br; v1 += s.br; v2 += s.br;
+            const float m1 = ((v0 + v1) + v2) / 3.0f;
+            v0 = (v0 - m1) * s.sat + m1; v1 = (v1 - m1) * s.sat + m1; v2 = (v2 - m1) * s.sat + m1;
+            v0 = (v0 - m2) * s.con + m2; v1 = (v1 - m2) * s.con + m2; v2 = (v2 - m2) * s.con + m2;
+        }
+        const float m = aug_mask(a, s, i, j);
+        yb[p] = v0 * m; yb[HW + p] = v1 * m; yb[2 * HW + p] = v2 * m;
+    }
+}
+
+__global__ __launch_bounds__(256) void aug_apply_bwd_kernel(const float *__restrict__ g, AugArgs a, const float *__restrict__ partial,
+                                                            float *__restrict__ gx) {
+    const int b = blockIdx.y;
+    const AugSample s = aug_sample(a, b);
+    const long HW = (long)a.H * a.W;
+    const float gmean = aug_total(partial, b) / (float)(3 * HW);       // mean over (c, i, j) of g * mask
+    const float *gb = g + (long)b * 3 * HW;
+    float *ob = gx + (long)b * 3 * HW;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+        const int si = (int)(p / a.W), sj = (int)(p - (long)si * a.W);     // SOURCE pixel of the forward
+        const int i = si - s.th, j = sj - s.tw;                             // its destination
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f;
+        if (i >= 0 && i < a.H && j >= 0 && j < a.W) {
+            const long q = (long)i * a.W + j;
+            const float m = aug_mask(a, s, i, j);
+            v0 = gb[q] * m; v1 = gb[HW + q] * m; v2 = gb[2 * HW + q] * m;
+            if (a.color) {
+                const float k = (1.0f - s.con) * gmean;
+                v0 = s.con * v0 + k; v1 = s.con * v1 + k; v2 = s.con * v2 + k;
+                const float mc = (1.0f - s.sat) * (((v0 + v1) + v2) / 3.0f);
+                v0 = s.sat * v0 + mc; v1 = s.sat * v1 + mc; v2 = s.sat * v2 + mc;
+            }
+        }
+        ob[p] = v0; ob[HW + p] = v1; ob[2 * HW + p] = v2;
+    }
+}
+
+int aug_check(const char *fn, const void *x, const float *rand01, const void *y, const float *ws, int B, int H, int W) {
+    if (B < 0 || H < 1 || W < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (B > 0 && (!x || !rand01 || !y || !ws)) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (B > 65535) return xq_set_error(XQ_EINVAL, "%s: batch > 65535", fn);
+    return XQ_OK;
+}
+
+}  // namespace
+
+extern "C" size_t xq_diffaug_workspace_floats(int B) { return (size_t)(B > 0 ? B : 0) * AUG_SLABS; }
+
+extern "C" int xq_diffaug_forward(const float *x, const float *rand01, int B, int H, int W, int dh, int dw, int ch, int cw, int trans, int color,
+                                  int cut, float *y, float *workspace, xq_stream_t stream) {
+    const char *fn = "xq_diffaug_forward";
+    if (int rc = aug_check(fn, x, rand01, y, workspace, B, H, W)) return rc;
+    if (B == 0) return XQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const AugArgs a{rand01, B, H, W, dh, dw, ch, cw, trans, color, cut};
+    if (color) hipLaunchKernelGGL((aug_sum_kernel<false>), dim3(AUG_SLABS, B), dim3(256), 0, s, x, a, workspace);
+    long bx = ((long)H * W + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(aug_apply_fwd_kernel, dim3((unsigned)bx, B), dim3(256), 0, s, x, a, workspace, y);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_diffaug_backward(const float *g, const float *rand01, int B, int H, int W, int dh, int dw, int ch, int cw, int trans, int color,
+                                   int cut, float *gx, float *workspace, xq_stream_t stream) {
+    const char *fn = "xq_diffaug_backward";
+    if (int rc = aug_check(fn, g, rand01, gx, workspace, B, H, W)) return rc;
+    if (B == 0) return XQ_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const AugArgs a{rand01, B, H, W, dh, dw, ch, cw, trans, color, cut};
+    if (color) hipLaunchKernelGGL((aug_sum_kernel<true>), dim3(AUG_SLABS, B), dim3(256), 0, s, g, a, workspace);
+    long bx = ((long)H * W + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(aug_apply_bwd_kernel, dim3((unsigned)bx, B), dim3(256), 0, s, g, a, workspace, gx);
+    return xq_check_launch(fn);
+}

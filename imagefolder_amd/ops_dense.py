@@ -990,6 +990,38 @@ class SpatialAttentionFn(torch.autograd.Function):
 
 
 # ---- DinoDisc heads (csrc/xq_disc.hip) ------------------------------------------------------------------------------------
+class DiffAugFn(torch.autograd.Function):
+    """DiffAug's translation + colour + cut-out (diffaug.py:64-118) for one call's draws `rand01` (7, B): xq_diffaug_forward / backward
+    (csrc/xq_aug.hip) — two launches each way instead of ~15 + ~20 library launches on (B, 3, 256, 256) fp32 images."""
+
+    @staticmethod
+    def forward(ctx, x, rand01, geom, flags):
+        xc = x.detach().float().contiguous()
+        B, C, H, W = xc.shape
+        r = rand01.detach().float().reshape(7, B).contiguous()
+        y = torch.empty_like(xc)
+        ws = torch.empty(_lib.lib().xq_diffaug_workspace_floats(B), dtype=torch.float32, device=xc.device)
+        with torch.cuda.device(xc.device):
+            rc = _lib.lib().xq_diffaug_forward(ptr(xc), ptr(r), B, H, W, *geom, *flags, ptr(y), ptr(ws), _stream(xc))
+        check(rc, "xq_diffaug_forward")
+        ctx.save_for_backward(r)
+        ctx.cfg = (geom, flags, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (r,) = ctx.saved_tensors
+        geom, flags, in_dtype = ctx.cfg
+        gc = g.detach().float().contiguous()
+        B, C, H, W = gc.shape
+        gx = torch.empty_like(gc)
+        ws = torch.empty(_lib.lib().xq_diffaug_workspace_floats(B), dtype=torch.float32, device=gc.device)
+        with torch.cuda.device(gc.device):
+            rc = _lib.lib().xq_diffaug_backward(ptr(gc), ptr(r), B, H, W, *geom, *flags, ptr(gx), ptr(ws), _stream(gc))
+        check(rc, "xq_diffaug_backward")
+        return gx.to(in_dtype), None, None, None
+
+
 class SpectralNormWeightFn(torch.autograd.Function):
     """W / sigma for a spectrally normalised weight in TRAINING mode (torch.nn.utils.spectral_norm semantics, n_power_iterations = 1,
     discriminator_dino.py:121-124): one power iteration updating the u / v buffers in place (no gradient through them), sigma = u^T W v,

@@ -66,6 +66,7 @@ def lecam_reg(real_pred, fake_pred, lecam_ema):
 
 # ---- LPIPS (lpips.py) -------------------------------------------------------------------------------------------
 FUSED_VGG_BACKWARD = __import__("os").environ.get("XQ_FUSED_VGG", "1") == "1"
+FUSED_DIFFAUG = __import__("os").environ.get("XQ_FUSED_DIFFAUG", "1") == "1"
 FUSED_SPECTRAL_NORM = __import__("os").environ.get("XQ_FUSED_SN", "1") == "1"
 _VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]  # features[0:30]
 
@@ -232,6 +233,10 @@ class DiffAug(object):
         B, dev = BCHW.shape[0], BCHW.device
         rand01 = torch.rand(7, B, 1, 1, device=dev) if (trans or color or cut) else None
         H, W = BCHW.shape[-2:]
+        if FUSED_DIFFAUG and BCHW.is_cuda and BCHW.shape[1] == 3 and rand01 is not None:
+            from .ops_dense import DiffAugFn       # the three transformations below as one op (csrc/xq_aug.hip), same draws
+            geom = (round(H * 0.125), round(W * 0.125), round(H * self.cutout), round(W * self.cutout))
+            return DiffAugFn.apply(BCHW, rand01, geom, (int(trans), int(color), int(self.using_cutout and cut)))
         if trans:
             dh, dw = round(H * 0.125), round(W * 0.125)
             th = rand01[0].mul(2 * dh + 1).floor().long() - dh

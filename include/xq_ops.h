@@ -273,6 +273,16 @@ int xq_row_softmax_backward(const float *P32, const void *dP, int64_t rows, int 
 int xq_maxpool2x2_nhwc_bf16_forward(const void *X, int B, int Ho, int Wo, int C, void *Y, xq_stream_t stream);
 int xq_maxpool2x2_nhwc_bf16_backward(const void *X, const void *G, int B, int Ho, int Wo, int C, void *GX, xq_stream_t stream);
 
+/* ---- DiffAug (diffaug.py:64-118: translation, colour, cut-out) on planar fp32 images [B][3][H][W], two launches per direction ------
+ * rand01 [7][B]: the call's uniform draws (translation h / w, brightness, saturation, contrast, cut-out h / w) exactly as upstream draws
+ * them; dh, dw = round(H / 8), round(W / 8); ch, cw = round(H * cutout), round(W * cutout); trans / color / cut: the three host-side
+ * branch decisions.  workspace: xq_diffaug_workspace_floats(B) floats.  backward: gx = (d y / d x)^T g for the same draws. */
+size_t xq_diffaug_workspace_floats(int B);
+int xq_diffaug_forward(const float *x, const float *rand01, int B, int H, int W, int dh, int dw, int ch, int cw, int trans, int color, int cut,
+                       float *y, float *workspace, xq_stream_t stream);
+int xq_diffaug_backward(const float *g, const float *rand01, int B, int H, int W, int dh, int dw, int ch, int cw, int trans, int color, int cut,
+                        float *gx, float *workspace, xq_stream_t stream);
+
 /* ---- spectral normalisation of the discriminator head convolutions (discriminator_dino.py:121-124: torch spectral_norm, one power
  *      iteration per training forward), fp32 ------------------------------------------------------------------------------------ */
 /* out = x / max(|x|_2, eps) (F.normalize); norm_out (nullable) [1] = |x|_2.  One workgroup: n <= a few thousand elements. */

@@ -522,3 +522,34 @@ def test_spectral_norm_weight_fn_equals_the_library_formulation(shape):
     vl.FUSED_SPECTRAL_NORM = True
     for a, b in zip(res[True], res[False]):
         assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("flags", [(1, 1, 1), (1, 0, 0), (0, 1, 0), (0, 0, 1), (1, 1, 0)])
+def test_fused_diffaug_equals_the_library_formulation(flags, monkeypatch):
+    """ops_dense.DiffAugFn (csrc/xq_aug.hip) == the tensor-op chain of vq_loss.DiffAug.aug (itself pinned to upstream's diffaug.py on CPU)
+    for the same draws: values and the gradient w.r.t. the image, for every combination of the three branch decisions."""
+    from imagefolder_amd import vq_loss as vl
+    B, H, W = 6, 40, 56
+    x = (torch.rand(B, 3, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(1)) * 2 - 1)
+    g = torch.randn(B, 3, H, W, device="cuda", generator=torch.Generator("cuda").manual_seed(2))
+    monkeypatch.setattr(torch, "rand", _rand_with_fixed_host_draws(torch.rand, flags))
+    res = {}
+    for fused in (True, False):
+        vl.FUSED_DIFFAUG = fused
+        torch.manual_seed(9); torch.cuda.manual_seed(9)
+        xi = x.clone().requires_grad_(True)
+        y = vl.DiffAug(prob=0.5, cutout=0.2).aug(xi)
+        (gx,) = torch.autograd.grad(y, xi, g)
+        res[fused] = (y.detach(), gx)
+    vl.FUSED_DIFFAUG = True
+    assert (res[True][0] - res[False][0]).abs().max().item() <= 2e-6
+    assert (res[True][1] - res[False][1]).abs().max().item() <= 2e-6 * max(1.0, res[False][1].abs().max().item())
+
+
+def _rand_with_fixed_host_draws(orig, flags):
+    """torch.rand stand-in: the 3-element HOST draw of DiffAug.aug (branch decisions at prob = 0.5) returns values that select `flags`"""
+    def rand(*size, **kw):
+        if size == (3,) and "device" not in kw:
+            return torch.tensor([0.1 if f else 0.9 for f in flags])
+        return orig(*size, **kw)
+    return rand
