@@ -413,16 +413,17 @@ class CapturedStep:
     DiffAug draws, perturbation draws differ from step to step as in eager mode), the optimizer's step counter lives on the device.
     What is FROZEN at capture time: every host-side decision — DiffAug's three branch draws (constant anyway at the reference's
     aug_prob = 1.0), the quantizer-dropout depths of codebook_drop > 0 configs (numpy draws upstream), epoch / alpha / beta / delta,
-    learning rates.  capture() refuses models with codebook_drop > 0 unless allow_frozen_host_rng=True.
+    learning rates.  capture() refuses multi-scale models with codebook_drop > 0 unless allow_frozen_host_rng=True.
     Single process only (collectives are not recorded): with world > 1 use the eager step."""
 
     def __init__(self, ts: "TokenizerTrainStep", imgs: torch.Tensor, epoch=0, alpha=0.0, beta=0.0, delta=100, warmup: int = 2,
                  allow_frozen_host_rng: bool = False):
         if ts.reducer.active:
             raise RuntimeError("CapturedStep: the gradient all-reduce is not recorded; use TokenizerTrainStep.step with world > 1")
-        if not allow_frozen_host_rng and float(getattr(ts.model, "codebook_drop", 0.0) or 0.0) > 0:
-            raise RuntimeError("CapturedStep: codebook_drop > 0 draws the dropout depths on the host every step; a replay would "
-                               "freeze them (allow_frozen_host_rng=True to accept that)")
+        multi_scale = len(getattr(ts.model, "v_patch_nums", [0])) > 1
+        if not allow_frozen_host_rng and multi_scale and float(getattr(ts.model, "codebook_drop", 0.0) or 0.0) > 0:
+            raise RuntimeError("CapturedStep: a multi-scale quantizer with codebook_drop > 0 draws its dropout depths on the host every "
+                               "step (xqgan_model.py:274 upstream); a replay would freeze them (allow_frozen_host_rng=True to accept that)")
         self.ts = ts
         self.static_imgs = imgs.clone()
         side = torch.cuda.Stream(device=imgs.device)

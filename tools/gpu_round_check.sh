@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: GPU test suite, default bench line, rocprofv3 kernel trace of the same command, PMC traffic passes.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_check.sh <tag> [parts]'
-# parts: any of  tests bench trace pmc shapes gemmtests gemmab configs   (default: the first five)
+# parts: any of  tests bench trace pmc shapes sections configs cnntrace gemmtests gemmab   (default: the first five)
 TAG=${1:-check}; export XQ_TAG=$TAG
 PARTS=${2:-"tests bench trace pmc shapes"}
 export TMPDIR=/tmp
