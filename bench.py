@@ -293,16 +293,22 @@ def main():
     if args.workload == "train_step" and args.graph != "off":
         if use_dist:
             graph_note = "off (collectives are not recorded: eager step with world > 1)"
+        elif args.graph == "auto" and (CFG["P"] > 1 or len(CFG["pns"]) > 1):
+            graph_note = "off (auto: only the single-quantizer, single-scale configs have a validated capture; --graph on to try)"
         else:
             try:
                 captured = ts.capture(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"], warmup=1)
                 for _ in range(2):
                     captured.replay()
                 graph_note = "on (torch.cuda.CUDAGraph over the whole step: train.CapturedStep)"
-            except Exception as e:  # noqa: BLE001 - fall back to the eager step, say why
+            except Exception as e:  # noqa: BLE001
                 if args.graph == "on":
                     raise
-                captured, graph_note = None, f"off (capture failed: {type(e).__name__}: {str(e)[:200]})"
+                # a capture that fails half way leaves the HIP stream-capture state invalidated for the whole process (measured:
+                # the eager step that follows dies with hipErrorStreamCaptureInvalidated) — start over in a fresh process, eagerly
+                sys.stderr.write(f"bench.py: hipGraph capture failed ({type(e).__name__}: {str(e)[:300]}); re-running with --graph off\n")
+                sys.stderr.flush()
+                os.execv(sys.executable, [sys.executable] + sys.argv + ["--graph", "off"])
     run = captured.replay if captured is not None else step
     torch.cuda.synchronize()
     if use_dist:

@@ -49,6 +49,9 @@ SIGNATURES = {
     "xq_diffaug_workspace_floats": (ctypes.c_size_t, [ctypes.c_int]),
     "xq_diffaug_forward": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp, vp]),
     "xq_diffaug_backward": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp, vp]),
+    "xq_rowdot_forward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_rowdot_backward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
+    "xq_colsum_partials": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_vec_normalize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
     "xq_sn_weight_grad": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp, vp]),
     "xq_row_partials_blocks": (ctypes.c_int, [ctypes.c_int64]),

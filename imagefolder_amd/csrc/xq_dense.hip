@@ -267,6 +267,57 @@ __global__ __launch_bounds__(1024) void colsum_kernel(const T *__restrict__ g, l
     }
 }
 
+// logit[r] = sum_c h[r][c] * w[c]: the 1-channel logit convolution of a discriminator head (discriminator_dino.py:215) as a row dot —
+// one wave per row, 16-byte lane loads (the library route: an fp32 copy of h + a gemv; its backward: two broadcast products + a cast)
+template <typename T>
+__global__ __launch_bounds__(256) void rowdot_fwd_kernel(const T *__restrict__ h, const float *__restrict__ w, long rows, int C,
+                                                         float *__restrict__ out) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        float s = 0.0f;
+        for (int c0 = lane * VEC; c0 < C; c0 += 64 * VEC) {
+            float v[VEC];
+            load_vec<T, VEC>(h + r * C + c0, v);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) s = __builtin_fmaf(v[j], w[c0 + j], s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[r] = s;
+    }
+}
+
+// g_h[r][c] = g[r] * w[c] (T);  partials[block][c] = sum over the block's rows of g[r] * h[r][c]  (-> g_w by colsum_finalize_kernel)
+template <typename T>
+__global__ __launch_bounds__(1024) void rowdot_bwd_kernel(const T *__restrict__ h, const float *__restrict__ w, const float *__restrict__ g,
+                                                          long rows, int C, T *__restrict__ g_h, float *__restrict__ partials) {
+    constexpr int VEC = 16 / sizeof(T);
+    for (int c0 = threadIdx.x * VEC; c0 < C; c0 += blockDim.x * VEC) {
+        float acc[VEC], ww[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) { acc[j] = 0.0f; ww[j] = w[c0 + j]; }
+        for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+            const float gr = g[r];
+            if (partials) {
+                float v[VEC];
+                load_vec<T, VEC>(h + r * C + c0, v);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) acc[j] = __builtin_fmaf(gr, v[j], acc[j]);
+            }
+            if (g_h) {
+                float o[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) o[j] = gr * ww[j];
+                store_vec<T, VEC>(g_h + r * C + c0, o);
+            }
+        }
+        if (partials) {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) partials[(size_t)blockIdx.x * C + c0 + j] = acc[j];
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
@@ -535,4 +586,47 @@ extern "C" int xq_lpips_level_backward_fused(const void *f0, const void *f1, con
     if (act_bf16)
         return lpips_dispatch<bf16>(true, (const bf16 *)f0, (const bf16 *)f1, w, gout, B, HW, C, nullptr, (bf16 *)g1, s, (const bf16 *)g_add, relu_mask);
     return lpips_dispatch<float>(true, (const float *)f0, (const float *)f1, w, gout, B, HW, C, nullptr, (float *)g1, s, (const float *)g_add, relu_mask);
+}
+
+extern "C" int xq_rowdot_forward(const void *h, const float *w, int64_t rows, int C, int act_bf16, float *out, xq_stream_t stream) {
+    const char *fn = "xq_rowdot_forward";
+    if (rows == 0) return XQ_OK;
+    if (!h || !w || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const int vec = act_bf16 ? 8 : 4;
+    if (C % vec) return xq_set_error(XQ_EINVAL, "%s: C=%ld must be a multiple of the 16-byte vector", fn, (long)C);
+    const int blocks = row_blocks_fwd(rows);
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) hipLaunchKernelGGL((rowdot_fwd_kernel<bf16>), dim3(blocks), dim3(256), 0, s, (const bf16 *)h, w, (long)rows, C, out);
+    else hipLaunchKernelGGL((rowdot_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float *)h, w, (long)rows, C, out);
+    return xq_check_launch(fn);
+}
+
+/* g_h (nullable) [rows][C] = g[r] w[c]; g_w (nullable) [C] = sum_r g[r] h[r][c] (partials: xq_row_partials_blocks(rows * 4) x C floats) */
+extern "C" int xq_rowdot_backward(const void *h, const float *w, const float *g, int64_t rows, int C, int act_bf16, void *g_h, float *g_w,
+                                  float *partials, xq_stream_t stream) {
+    const char *fn = "xq_rowdot_backward";
+    if (rows == 0) return XQ_OK;
+    if (!h || !w || !g) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (g_w && !partials) return xq_set_error(XQ_EINVAL, "%s: partials workspace required for g_w", fn);
+    const int vec = act_bf16 ? 8 : 4;
+    if (C % vec) return xq_set_error(XQ_EINVAL, "%s: C=%ld must be a multiple of the 16-byte vector", fn, (long)C);
+    const int blocks = row_blocks(rows * 4);
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = col_threads(C / vec);
+    float *part = g_w ? partials : nullptr;
+    if (act_bf16) hipLaunchKernelGGL((rowdot_bwd_kernel<bf16>), dim3(blocks), dim3(threads), 0, s, (const bf16 *)h, w, g, (long)rows, C, (bf16 *)g_h, part);
+    else hipLaunchKernelGGL((rowdot_bwd_kernel<float>), dim3(blocks), dim3(threads), 0, s, (const float *)h, w, g, (long)rows, C, (float *)g_h, part);
+    if (g_w)
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, s, partials, blocks, 1, C, g_w, nullptr, nullptr, nullptr, 0);
+    return xq_check_launch(fn);
+}
+
+/* out[c] = sum over r < nrows of partials[r][c] in a fixed order (the per-tile column partials the fused-GELU data-gradient GEMM leaves for
+ * the fc1 bias gradient: xq_gemm_bf16_nn_gelu_bwd) */
+extern "C" int xq_colsum_partials(const float *partials, int nrows, int D, float *out, xq_stream_t stream) {
+    if (D <= 0) return XQ_OK;
+    if (!partials || !out || nrows < 0) return xq_set_error(XQ_EINVAL, "%s: bad arguments", "xq_colsum_partials");
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((D + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, (hipStream_t)stream, partials, nrows, 1, D, out,
+                       nullptr, nullptr, nullptr, 0);
+    return xq_check_launch("xq_colsum_partials");
 }

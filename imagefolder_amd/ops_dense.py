@@ -402,7 +402,11 @@ class MlpFn(torch.autograd.Function):
             rc = _lib.lib().xq_gemm_bf16_nn_gelu_bwd(ptr(g2), ptr(W2), ptr(h), M, Hd, W2.shape[0], ptr(g_h), ptr(colpart), int(tanh), _stream(h))
         check(rc, "xq_gemm_bf16_nn_gelu_bwd")
         g_w2 = gemm_tn(g2, hg).to(wdtype) if ctx.needs_input_grad[3] else None
-        g_b1 = colpart.sum(0) if ctx.needs_input_grad[2] else None
+        g_b1 = None
+        if ctx.needs_input_grad[2]:
+            g_b1 = torch.empty(Hd, dtype=torch.float32, device=h.device)
+            with torch.cuda.device(h.device):
+                check(_lib.lib().xq_colsum_partials(ptr(colpart), rows, Hd, ptr(g_b1), _stream(h)), "xq_colsum_partials")
         g_w1 = gemm_tn(g_h, a2).to(wdtype) if ctx.needs_input_grad[1] else None
         g_a = gemm_nn(g_h, W1).view(shp) if ctx.needs_input_grad[0] else None
         return g_a, g_w1, g_b1, g_w2, None, None
@@ -1164,24 +1168,36 @@ class RowDotFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h, w):
-        ctx.save_for_backward(h, w)
-        return torch.mv(h.float(), w)
+        hc = h.detach().contiguous()
+        wc = w.detach().float().contiguous()
+        ctx.save_for_backward(hc, wc)
+        rows, C = hc.shape
+        if hc.is_cuda and hc.dtype in (torch.bfloat16, torch.float32) and C % (8 if hc.dtype == torch.bfloat16 else 4) == 0:
+            out = torch.empty(rows, dtype=torch.float32, device=hc.device)
+            with torch.cuda.device(hc.device):
+                rc = _lib.lib().xq_rowdot_forward(ptr(hc), ptr(wc), rows, C, _act_flag(hc.dtype), ptr(out), _stream(hc))
+            check(rc, "xq_rowdot_forward")
+            ctx.hip = True
+            return out
+        ctx.hip = False
+        return torch.mv(hc.float(), wc)
 
     @staticmethod
     def backward(ctx, g):
         h, w = ctx.saved_tensors
-        g = g.float()
-        g_h = (g.unsqueeze(1) * w.unsqueeze(0)).to(h.dtype) if ctx.needs_input_grad[0] else None
-        g_w = None
-        if ctx.needs_input_grad[1]:
-            prod = (h.float() * g.unsqueeze(1)).contiguous()
-            rows, C = prod.shape
-            g_w = torch.empty(C, dtype=torch.float32, device=h.device)
-            nb = _lib.lib().xq_row_partials_blocks(rows * 4)
-            part = torch.empty(nb * C, dtype=torch.float32, device=h.device)
+        g = g.float().contiguous()
+        rows, C = h.shape
+        if ctx.hip:
+            need_h, need_w = ctx.needs_input_grad
+            g_h = torch.empty_like(h) if need_h else None
+            g_w = torch.empty(C, dtype=torch.float32, device=h.device) if need_w else None
+            part = torch.empty(_lib.lib().xq_row_partials_blocks(rows * 4) * C, dtype=torch.float32, device=h.device) if need_w else None
             with torch.cuda.device(h.device):
-                rc = _lib.lib().xq_colsum(ptr(prod), rows, C, 0, ptr(g_w), 0, ptr(part), _stream(prod))
-            check(rc, "xq_colsum")
+                rc = _lib.lib().xq_rowdot_backward(ptr(h), ptr(w), ptr(g), rows, C, _act_flag(h.dtype), ptr(g_h), ptr(g_w), ptr(part), _stream(h))
+            check(rc, "xq_rowdot_backward")
+            return g_h, g_w
+        g_h = (g.unsqueeze(1) * w.unsqueeze(0)).to(h.dtype) if ctx.needs_input_grad[0] else None
+        g_w = (h.float() * g.unsqueeze(1)).sum(0) if ctx.needs_input_grad[1] else None
         return g_h, g_w
 
 

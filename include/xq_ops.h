@@ -283,6 +283,16 @@ int xq_diffaug_forward(const float *x, const float *rand01, int B, int H, int W,
 int xq_diffaug_backward(const float *g, const float *rand01, int B, int H, int W, int dh, int dw, int ch, int cw, int trans, int color, int cut,
                         float *gx, float *workspace, xq_stream_t stream);
 
+/* out [D] = sum over the nrows rows of partials [nrows][D] (fp32), fixed order: finishes the fc1 bias gradient from the column partials of
+ * xq_gemm_bf16_nn_gelu_bwd */
+int xq_colsum_partials(const float *partials, int nrows, int D, float *out, xq_stream_t stream);
+
+/* ---- the 1-channel logit convolution of a DinoDisc head as a row dot (discriminator_dino.py:215): out[r] = sum_c h[r][c] w[c];
+ *      backward: g_h[r][c] = g[r] w[c] (nullable), g_w[c] = sum_r g[r] h[r][c] (nullable; partials: xq_row_partials_blocks(rows * 4) * C floats) */
+int xq_rowdot_forward(const void *h, const float *w, int64_t rows, int C, int act_bf16, float *out, xq_stream_t stream);
+int xq_rowdot_backward(const void *h, const float *w, const float *g, int64_t rows, int C, int act_bf16, void *g_h, float *g_w,
+                       float *partials, xq_stream_t stream);
+
 /* ---- spectral normalisation of the discriminator head convolutions (discriminator_dino.py:121-124: torch spectral_norm, one power
  *      iteration per training forward), fp32 ------------------------------------------------------------------------------------ */
 /* out = x / max(|x|_2, eps) (F.normalize); norm_out (nullable) [1] = |x|_2.  One workgroup: n <= a few thousand elements. */

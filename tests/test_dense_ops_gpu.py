@@ -553,3 +553,21 @@ def _rand_with_fixed_host_draws(orig, flags):
             return torch.tensor([0.1 if f else 0.9 for f in flags])
         return orig(*size, **kw)
     return rand
+
+
+@pytest.mark.parametrize("rows,C,dt", [(25088, 384, torch.bfloat16), (1000, 64, torch.bfloat16), (777, 384, torch.float32)])
+def test_rowdot_kernels_vs_reference(rows, C, dt):
+    from imagefolder_amd.ops_dense import RowDotFn
+    torch.manual_seed(rows)
+    h = torch.randn(rows, C, device="cuda").to(dt).requires_grad_(True)
+    w = torch.randn(C, device="cuda").requires_grad_(True)
+    g = torch.randn(rows, device="cuda")
+    out = RowDotFn.apply(h, w)
+    gh, gw = torch.autograd.grad(out, (h, w), g)
+    hr, wr = h.detach().float().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    ref = hr @ wr
+    ghr, gwr = torch.autograd.grad(ref, (hr, wr), g)
+    assert (out - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    tol = 1e-5 if dt == torch.float32 else 1e-2
+    assert (gh.float() - ghr).abs().max().item() <= tol * ghr.abs().max().item()
+    assert (gw - gwr).abs().max().item() <= 1e-4 * gwr.abs().max().item()

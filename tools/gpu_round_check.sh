@@ -27,7 +27,7 @@ if has trace; then
 fi
 if has pmc; then
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 500 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-mfu > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
+    timeout 500 rocprofv3 --pmc $C --output-format csv -d /tmp/pmc_${TAG}_$C -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-mfu --graph off > $OUT/pmc_$C.json 2> $OUT/pmc_$C.err
     echo "pmc $C rc=$?"
   done
   python tools/pmc_traffic.py /tmp/pmc_${TAG}_FETCH_SIZE /tmp/pmc_${TAG}_WRITE_SIZE > $OUT/kernel_hbm_traffic.json 2> $OUT/pmc_traffic.err

@@ -28,5 +28,5 @@ for key, name in groups.items():
                  "write_bytes_per_launch": 1024.0 * sum(wr) / max(1, len(wr)),
                  "raw_fetch_size_kb_avg": sum(fr) / max(1, len(fr)), "raw_write_size_kb_avg": sum(wr) / max(1, len(wr))}
     out[name]["hbm_bytes_per_launch"] = out[name]["read_bytes_per_launch"] + out[name]["write_bytes_per_launch"]
-print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-mfu",
+print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-mfu --graph off (counter collection does not survive hipGraph replays: the FETCH pass hung, the WRITE pass crashed)",
                   "corrections": "FETCH_SIZE KB x 1024 x 2 (gfx950 wide-read under-count); WRITE_SIZE KB x 1024", "kernels": out}, indent=1))
