@@ -15,6 +15,7 @@ EMA, optional discriminator step) with an MI355X-first data path instead of torc
   * on CPU (gloo) the same class runs with a plain tensor AdamW so the N > 1 logic is testable without GPUs.
 """
 import ctypes
+import os
 from typing import Callable, Iterable, List, Optional
 
 import torch
@@ -440,6 +441,8 @@ class CapturedStep:
         c0 = (ts.arena.step_count, ts.arena.epoch)
         with torch.cuda.graph(self.graph):
             self.loss = ts.step(self.static_imgs, epoch, alpha, beta, delta)
+            if os.environ.get("XQ_TEST_CAPTURE_FAIL") == "1":      # tests: a capture that dies half way (bench.py must recover)
+                raise RuntimeError("XQ_TEST_CAPTURE_FAIL: simulated failure inside the hipGraph capture")
         # the capture pass ran the host bookkeeping once without executing anything: take it back; replay() redoes it per step
         ts.arena.step_count, ts.arena.epoch = c0
         if disc is not None:

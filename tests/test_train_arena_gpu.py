@@ -73,3 +73,23 @@ def test_bench_runs_its_rccl_branch_at_world_size_1():
     assert res["allreduce"]["exposed_ms_per_step"] is not None
     assert res["allreduce"]["chunks"] >= 2
     assert res["value"] > 0
+
+
+def test_bench_recovers_from_a_failed_hipgraph_capture():
+    """bench.py --graph auto: when the capture of the train step fails half way, the process re-executes itself with --graph off
+    (the invalidated capture state would otherwise kill the eager step that follows) and still prints its JSON line."""
+    env = dict(os.environ, XQ_TEST_CAPTURE_FAIL="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--no-mfu"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "re-running with --graph off" in out.stderr
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["config"]["hip_graph"].startswith("off") and res["value"] > 0
+
+
+def test_bench_replays_the_step_from_a_hipgraph_by_default():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--no-mfu"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["config"]["hip_graph"].startswith("on") and res["value"] > 0 and res["roofline"]["launches"] > 0
