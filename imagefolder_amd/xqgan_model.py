@@ -421,6 +421,26 @@ class VQModel(nn.Module):
                     for i, fi in enumerate(f.chunk(chunks=self.product_quant, dim=2))]
         return [self.quantize.f_to_idxBl_or_fhat(f, to_fhat=False, v_patch_nums=vp)]
 
+    def img_to_sem_feat(self, x):
+        """quantised latent of the LAST product branch at the last scale (xqgan_model.py:405-426 upstream; the feature map the
+        semantic probes read).  Upstream indexes `self.quantizes` unconditionally, which only exists for product_quant > 1; the
+        single-quantizer model is served through `self.quantize` here instead of failing."""
+        f = nn_ops.conv1x1(self._tokens_to_map(self.encoder(x)), self.quant_conv.weight, self.quant_conv.bias)
+        multi = len(self.v_patch_nums) > 1
+        vp = self.v_patch_nums if multi else None
+        if self.product_quant > 1:
+            b, c, l, _ = f.shape
+            side = int(sqrt(l // self.product_quant))
+            fi = f.chunk(chunks=self.product_quant, dim=2)[-1].reshape(b, -1, side, side)
+            return self.quantizes[-1].f_to_idxBl_or_fhat(fi, to_fhat=True, v_patch_nums=vp)[-1]
+        return self.quantize.f_to_idxBl_or_fhat(f, to_fhat=True, v_patch_nums=vp)[-1]
+
+    def decode_code(self, code_b):
+        """xqgan_model.py:263-266 upstream, statement for statement: written for a quantizer whose forward returns three values
+        (models/quant.py); with the XQ-GAN quantizers (five values) the unpacking raises ValueError there and here."""
+        quant_b, usages, mean_vq_loss = self.quantize(code_b, ret_usages=True)
+        return self.decode(quant_b)
+
     def fhat_to_img(self, f_hat: torch.Tensor):
         f_hat = nn_ops.conv1x1(f_hat, self.post_quant_conv.weight, self.post_quant_conv.bias)
         if self.dec_type == 'dinov2':

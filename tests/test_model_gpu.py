@@ -34,8 +34,11 @@ def test_vqmodel_forward_backward_and_inference(cfg):
     with torch.no_grad():
         rec = m.img_to_reconstructed_img(x)
         ids = m.img_to_idx(x)
+        sem = m.img_to_sem_feat(x)
     assert rec.shape == x.shape and rec.abs().max() <= 1.0
     assert len(ids) == cfg["P"] and all(i.dtype == torch.int64 for br in ids for i in br)
+    side = int(round((cfg["L"]) ** 0.5))
+    assert sem.shape == (4, 16, side, side) and torch.isfinite(sem).all()       # (B, C, sqrt(L), sqrt(L)) of the last branch
 
 
 def test_adamw_ema_kernel_matches_torch_adamw():
