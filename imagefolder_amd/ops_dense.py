@@ -625,8 +625,7 @@ class LpipsVggFn(torch.autograd.Function):
                 if li > 0 and layers[li - 1][0] == "conv":        # conv -> conv inside a slice: mask by the ReLU output below
                     y_prev = layers[li - 1][2].saved_tensors[2]
                     g = torch.ops.aten.threshold_backward(g.to(y_prev.dtype), y_prev, 0)
-        ctx.layers = None
-        return g.to(ctx.in_dtype), None, None, None
+        return g.to(ctx.in_dtype), None, None, None      # (ctx.layers stays: a retain_graph backward may come again)
 
 
 def _packed_conv_weight(weight, for_data_grad: bool):
