@@ -689,7 +689,7 @@ def conv3x3_gemm(x_cl, wp, bias, Cout, relu=False, stride=1, pad=1, upsample=Fal
 
 def _use_gemm_engine(n_pixels, Cout):
     """the tile engine wins once its 256-row tiles fill the chip and the output is at least 128 channels wide
-    (profiles/r02_conv_gemm_v1.txt); narrow / small layers stay on the round-1 kernel (64- and 128-channel tiles, 128-pixel tiles)"""
+    (profiles/r02_conv_modes_b32.txt); narrow / small layers stay on the round-1 kernel (64- and 128-channel tiles, 128-pixel tiles)"""
     if CONV_ENGINE != "gemm" or Cout < 128:
         return False
     bn = 256 if Cout >= 256 else 128
