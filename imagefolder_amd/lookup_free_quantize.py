@@ -23,12 +23,12 @@ from torch import distributed as tdist, nn as nn
 from torch.nn import functional as F
 
 from . import ops
-from .quant import Phi, PhiNonShared, PhiPartiallyShared, PhiShared, _dist_ready
+from .quant import Phi, PhiNonShared, PhiPartiallyShared, PhiShared, VarHelpersMixin, _dist_ready
 
 _CPAD = 16  # channel count of the ladder kernels the bit channels are padded to
 
 
-class LFQ(nn.Module):
+class LFQ(VarHelpersMixin, nn.Module):
     def __init__(self, codebook_size, Cvae, using_znorm=False, beta: float = 0.25, default_qresi_counts=0, v_patch_nums=None,
                  quant_resi=0.5, share_quant_resi=4, num_latent_tokens=256, codebook_drop=0.0, scale=1,
                  sample_minimization_weight=1.0, batch_maximization_weight=1.0, entropy_weight=0.1, soft_entropy=True):

@@ -96,7 +96,59 @@ class PhiNonShared(nn.ModuleList):
         return f'ticks={self.ticks}'
 
 
-class VectorQuantizer2(nn.Module):
+class VarHelpersMixin:
+    """VAR-side helpers shared by VectorQuantizer2 (quant.py:148-180,226-258 upstream) and LFQ (lookup_free_quantize.py:311-343,
+    383-415): the running reconstruction f_hat built from per-scale code maps with the ladder's own kernels (ops.ms_upsample /
+    ms_phi_accumulate / ms_area_pool).  Needs self.v_patch_nums, self.Cvae, self.quant_resi, self.prog_si (+ self.embedding for
+    idxBl_to_var_input — LFQ has none, upstream and here: AttributeError)."""
+
+    def _phi_at(self, si: int, SN: int):
+        return self.quant_resi[si / (SN - 1)] if SN > 1 else self.quant_resi[0]
+
+    def embed_to_fhat(self, ms_h_BChw: List[torch.Tensor], all_to_max_scale=True, last_one=False):
+        """cumulative reconstructions from per-scale code embeddings (quant.py:148-180, all_to_max_scale branch)"""
+        if not all_to_max_scale:
+            raise NotImplementedError("experimental upstream branch (quant.py:165-178) is not mirrored")
+        SN = len(self.v_patch_nums)
+        HW = self.v_patch_nums[-1]
+        B = ms_h_BChw[0].shape[0]
+        f_hat = torch.zeros(B, self.Cvae, HW, HW, dtype=torch.float32, device=ms_h_BChw[0].device)
+        outs = []
+        for si in range(SN):
+            u = ops.ms_upsample(ms_h_BChw[si], HW, HW, bicubic=si < SN - 1)
+            ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
+            if not last_one:
+                outs.append(f_hat.clone())
+        return f_hat if last_one else outs
+
+    def idxBl_to_var_input(self, gt_ms_idx_Bl: List[torch.Tensor]) -> torch.Tensor:
+        """teacher-forcing input of VAR: the area-pooled running reconstruction before every scale but the first
+        (quant.py:226-245) -> (B, sum_{s >= 1} pn_s^2, C)"""
+        SN = len(self.v_patch_nums)
+        HW = self.v_patch_nums[-1]
+        B = gt_ms_idx_Bl[0].shape[0]
+        f_hat = torch.zeros(B, self.Cvae, HW, HW, dtype=torch.float32, device=gt_ms_idx_Bl[0].device)
+        nxt = []
+        for si in range(SN - 1):
+            if self.prog_si == 0 or (0 <= self.prog_si - 1 < si):
+                break
+            u = ops.ms_upsample(gt_ms_idx_Bl[si], HW, HW, codebook=self.embedding.weight, bicubic=True)
+            ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
+            pn = self.v_patch_nums[si + 1]
+            nxt.append(ops.ms_area_pool(f_hat, pn).view(B, self.Cvae, pn * pn).transpose(1, 2))
+        return torch.cat(nxt, dim=1) if nxt else None
+
+    def get_next_autoregressive_input(self, si: int, SN: int, f_hat: torch.Tensor, h_BChw: torch.Tensor):
+        """one step of VAR sampling (quant.py:248-258): folds scale si into f_hat IN PLACE, returns (f_hat, next input map)"""
+        HW = self.v_patch_nums[-1]
+        u = ops.ms_upsample(h_BChw, HW, HW, bicubic=si != SN - 1)
+        ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
+        if si != SN - 1:
+            return f_hat, ops.ms_area_pool(f_hat, self.v_patch_nums[si + 1])
+        return f_hat, f_hat
+
+
+class VectorQuantizer2(VarHelpersMixin, nn.Module):
     """Drop-in for reference VectorQuantizer2 (tokenizer_image/quant.py:13-258)."""
 
     def __init__(self, vocab_size, Cvae, using_znorm=True, beta: float = 0.25, default_qresi_counts=0, v_patch_nums=None,
@@ -229,50 +281,6 @@ class VectorQuantizer2(nn.Module):
     # Inference-time plumbing between the tokenizer and the VAR generator.  Each is a short sequence of the three kernels the
     # fused ladder is made of — ops.ms_upsample (code gather + bicubic), ops.ms_phi_accumulate (f_hat += Phi_k(.)) and
     # ops.ms_area_pool — so they share its arithmetic (bit-identical to oracle/xq_oracle.c); no autograd, as upstream uses them.
-    def _phi_at(self, si: int, SN: int):
-        return self.quant_resi[si / (SN - 1)] if SN > 1 else self.quant_resi[0]
-
-    def embed_to_fhat(self, ms_h_BChw: List[torch.Tensor], all_to_max_scale=True, last_one=False):
-        """cumulative reconstructions from per-scale code embeddings (quant.py:148-180, all_to_max_scale branch)"""
-        if not all_to_max_scale:
-            raise NotImplementedError("experimental upstream branch (quant.py:165-178) is not mirrored")
-        SN = len(self.v_patch_nums)
-        HW = self.v_patch_nums[-1]
-        B = ms_h_BChw[0].shape[0]
-        f_hat = torch.zeros(B, self.Cvae, HW, HW, dtype=torch.float32, device=ms_h_BChw[0].device)
-        outs = []
-        for si in range(SN):
-            u = ops.ms_upsample(ms_h_BChw[si], HW, HW, bicubic=si < SN - 1)
-            ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
-            if not last_one:
-                outs.append(f_hat.clone())
-        return f_hat if last_one else outs
-
-    def idxBl_to_var_input(self, gt_ms_idx_Bl: List[torch.Tensor]) -> torch.Tensor:
-        """teacher-forcing input of VAR: the area-pooled running reconstruction before every scale but the first
-        (quant.py:226-245) -> (B, sum_{s >= 1} pn_s^2, C)"""
-        SN = len(self.v_patch_nums)
-        HW = self.v_patch_nums[-1]
-        B = gt_ms_idx_Bl[0].shape[0]
-        f_hat = torch.zeros(B, self.Cvae, HW, HW, dtype=torch.float32, device=gt_ms_idx_Bl[0].device)
-        nxt = []
-        for si in range(SN - 1):
-            if self.prog_si == 0 or (0 <= self.prog_si - 1 < si):
-                break
-            u = ops.ms_upsample(gt_ms_idx_Bl[si], HW, HW, codebook=self.embedding.weight, bicubic=True)
-            ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
-            pn = self.v_patch_nums[si + 1]
-            nxt.append(ops.ms_area_pool(f_hat, pn).view(B, self.Cvae, pn * pn).transpose(1, 2))
-        return torch.cat(nxt, dim=1) if nxt else None
-
-    def get_next_autoregressive_input(self, si: int, SN: int, f_hat: torch.Tensor, h_BChw: torch.Tensor):
-        """one step of VAR sampling (quant.py:248-258): folds scale si into f_hat IN PLACE, returns (f_hat, next input map)"""
-        HW = self.v_patch_nums[-1]
-        u = ops.ms_upsample(h_BChw, HW, HW, bicubic=si != SN - 1)
-        ops.ms_phi_accumulate(f_hat, u, self._phi_at(si, SN))
-        if si != SN - 1:
-            return f_hat, ops.ms_area_pool(f_hat, self.v_patch_nums[si + 1])
-        return f_hat, f_hat
 
 
 class VectorQuantizer2Var(VectorQuantizer2):

@@ -194,6 +194,45 @@ def gen_lfq(name, Cbits, B, pns, seed, codebook_drop=0.1, start_drop=3, using_zn
     print("wrote", name, "vq", vq.item(), "commit", float(commit), "entropy", float(ent), "usages", [round(u, 2) for u in usages][:4])
 
 
+def gen_lfq_var_helpers(name, Cbits, B, pns, seed, using_znorm=True, share=4):
+    """VAR-side helpers of LFQ (lookup_free_quantize.py:311-343 embed_to_fhat, :404-415 get_next_autoregressive_input) on the
+    sign codes of a random latent.  (idxBl_to_var_input :383-401 dereferences `self.embedding`, which LFQ does not define:
+    it raises AttributeError upstream, nothing to record.)"""
+    R = load_reference()
+    torch.manual_seed(seed)
+    H = W = pns[-1]
+    SN = len(pns)
+    import contextlib, io
+    with contextlib.redirect_stdout(io.StringIO()):
+        q = R["LFQ"](2 ** Cbits, Cbits, using_znorm=using_znorm, v_patch_nums=list(pns), num_latent_tokens=H * W, share_quant_resi=share,
+                     codebook_drop=0.0, scale=1.0, entropy_weight=0.0, soft_entropy=True).eval()
+    for c in list(q.quant_resi.qresi_ls):
+        torch.nn.init.normal_(c.weight, std=0.2)
+        torch.nn.init.normal_(c.bias, std=0.1)
+    f = torch.randn(B, Cbits, H, W) * 0.6
+    with torch.no_grad():
+        idx_list = q.f_to_idxBl_or_fhat(f, to_fhat=False, v_patch_nums=None)
+        ms_h = [q.indices_to_bits(idx, si).transpose(1, 2).reshape(B, Cbits, pn, pn).float().contiguous()
+                for si, (idx, pn) in enumerate(zip(idx_list, pns))]
+        fhats = q.embed_to_fhat(ms_h, all_to_max_scale=True, last_one=False)
+        fhat_last = q.embed_to_fhat(ms_h, all_to_max_scale=True, last_one=True)
+        f_hat = torch.zeros(B, Cbits, H, W)
+        nexts = []
+        for si in range(SN):
+            f_hat, nxt = q.get_next_autoregressive_input(si, SN, f_hat, ms_h[si])
+            nexts.append(nxt.clone())
+    convs = list(q.quant_resi.qresi_ls)
+    phi_sel = [int(np.argmin(np.abs(q.quant_resi.ticks - si / (SN - 1)))) for si in range(SN)]
+    np.savez(os.path.join(OUT, name + ".npz"), Cbits=np.int32(Cbits), pns=np.array(pns, np.int32), share=np.int32(share),
+             using_znorm=np.int32(using_znorm),
+             phi_w=np.stack([c.weight.detach().numpy() for c in convs]), phi_b=np.stack([c.bias.detach().numpy() for c in convs]),
+             phi_sel=np.array(phi_sel, np.int32), phi_ratio=np.float32(abs(q.quant_resi_ratio)),
+             ms_h=np.concatenate([t.reshape(-1).numpy() for t in ms_h]),
+             fhat_scales=np.stack([t.numpy() for t in fhats]), fhat_last=fhat_last.numpy(),
+             next_maps=np.concatenate([t.reshape(-1).numpy() for t in nexts]), f_hat_final=f_hat.numpy(), meta=np.array(str(meta())))
+    print("wrote", name, "|f_hat|", float(f_hat.abs().mean()))
+
+
 def gen_model(name, kw, seed):
     """VQModel.img_to_reconstructed_img + code indices (xqgan_model.py:367-403) with deterministic weights
     (oracle/det_init.py); eval mode (no DropPath), fp32 CPU = the reference CPU path of BASELINE config 1/2."""
@@ -352,6 +391,11 @@ def main():
                                                       encoder_model="vit_base_patch14_dinov2.lvd142m",
                                                       decoder_model="vit_base_patch14_dinov2.lvd142m"), seed=32)
         return
+    if only in ("lfqvar", ""):
+        gen_lfq_var_helpers("vh_lfq_c12_11grid_b3", 12, 3, [1, 1, 2, 3, 3, 4, 5, 6, 8, 11], seed=53)
+        gen_lfq_var_helpers("vh_lfq_raw_c14_16grid_b2", 14, 2, [1, 2, 3, 4, 6, 8, 11, 16], seed=54, using_znorm=False)
+        if only:
+            return
     if only in ("var", ""):
         # VAR-d16 geometry (1x1 -> 16x16, 10 scales, 4 partially shared Phi) and the MSVR10P2 ladder; models/quant.py twin
         gen_var_helpers("var_helpers_16grid_v512_c16_b3", 512, 16, 3, [1, 2, 3, 4, 5, 6, 8, 10, 13, 16], seed=50)
