@@ -453,6 +453,10 @@ class CapturedStep:
     def replay(self, imgs: Optional[torch.Tensor] = None):
         if imgs is not None and imgs.data_ptr() != self.static_imgs.data_ptr():
             self.static_imgs.copy_(imgs, non_blocking=True)
+        # the device step counters follow the host ones (eager steps taken between replays, a loaded checkpoint): the graph adds 1
+        self.ts.opt._step_dev.fill_(float(self.ts.arena.step_count))
+        if self._disc is not None:
+            self._disc.opt._step_dev.fill_(float(self._disc.opt.arena.step_count))
         self.graph.replay()
         self.ts.arena.step_count += 1
         self.ts.arena.epoch += 1
