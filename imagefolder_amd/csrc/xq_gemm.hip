@@ -73,6 +73,7 @@ struct GemmArgs {
     int nt_store;           // non-temporal bf16 output stores (default; XQ_GEMM_PLAIN_STORE turns them off): the 128 KiB a CU
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
+    int two_phase;          // XQ_GEMM_TWO_PHASE: experimental 2-phase-per-K-tile schedule of the persistent kernel (opt-in, untested on hardware)
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
@@ -558,7 +559,7 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int AK, int BK, int ACT>
+template <int AK, int BK, int ACT, int PH = 4>
 __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int WTN = 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 8 ring slots + 8 x 4 KiB epilogue staging
@@ -676,6 +677,45 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         GR_BARRIER();                                                         \
         r_par ^= 1;                                                           \
     } while (0)
+    // EXPERIMENTAL (PH = 2, impl bit XQ_GEMM_TWO_PHASE; never selected by XQ_GEMM_AUTO, not yet run on hardware): the same stream
+    // regrouped into two phases of 16 MFMAs per K tile — half the barriers, and the 16 + 8 fragment reads of a phase get 512 instead
+    // of 256 matrix-pipe cycles of the other wave row to land under.  Hazards re-derived for two pieces per phase:
+    //   RAW  phase A reads pieces (t,1) (t,2) (t,0): in flight after phase B(t-1) staged (t+1,0) (t+1,1) are, oldest first,
+    //        (t,0..3) (t+1,0) (t+1,1) = 12 instructions -> vmcnt(6) there retires (t,0) (t,1) (t,2);  phase B reads (t,3): in flight
+    //        after phase A(t) staged (t+1,2) (t+1,3) are (t,3) (t+1,0..3) = 10 -> vmcnt(8) retires (t,3);  prologue: vmcnt(6)
+    //   WAR  slot of (t+1,3) = slot of (t-1,3), last read at the head of phase B(t-1) by wave row 0 and one barrier later by row 1:
+    //        the explicit lgkmcnt(0) in front of every phase's first barrier retires a wave's reads before it signals, so a piece
+    //        is restaged at least two barriers after its last read has RETURNED (cdna_hip_programming.md, 8-phase template rule)
+#define GR_LGKM0()                                                            \
+    do {                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+    } while (0)
+#define PR_TILE2()                                                            \
+    do {                                                                      \
+        PR_READ_B(bl, 1)                                                      \
+        PR_READ_B(br, 2)                                                      \
+        PR_READ_A(0)                                                          \
+        PR_STAGE(2);                                                          \
+        PR_STAGE(3);                                                          \
+        GR_LGKM0();                                                           \
+        GR_VMCNT(8);                                                          \
+        GR_BARRIER();                                                         \
+        PR_MFMA(0, 0, bl);                                                    \
+        PR_MFMA(0, 1, br);                                                    \
+        GR_BARRIER();                                                         \
+        PR_READ_A(3)                                                          \
+        PR_ADVANCE();                                                         \
+        PR_STAGE(0);                                                          \
+        PR_STAGE(1);                                                          \
+        GR_LGKM0();                                                           \
+        GR_VMCNT(6);                                                          \
+        GR_BARRIER();                                                         \
+        PR_MFMA(2, 1, br);                                                    \
+        PR_MFMA(2, 0, bl);                                                    \
+        GR_BARRIER();                                                         \
+        r_par ^= 1;                                                           \
+    } while (0)
 
     // prologue: K tile 0 of the first item completely, A-top + B-left of its K tile 1
     PR_STAGE(0);
@@ -685,14 +725,15 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     PR_ADVANCE();
     PR_STAGE(0);
     PR_STAGE(1);
-    GR_VMCNT(8);
+    if (PH == 2) GR_VMCNT(6); else GR_VMCNT(8);
     GR_BARRIER();
 
     const int h = lane >> 5;
     for (;;) {
         const bool has_next = cp + G < items;
         if (wr == 1) GR_BARRIER();
-        for (int kt = 0; kt < cit.KT; ++kt) PR_TILE();
+        if (PH == 2) { for (int kt = 0; kt < cit.KT; ++kt) PR_TILE2(); }
+        else { for (int kt = 0; kt < cit.KT; ++kt) PR_TILE(); }
         if (wr == 0) GR_BARRIER();
         if (!has_next) GR_VMCNT(0);      // the dummy pieces target `region`
 
@@ -810,6 +851,8 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         decode_item(g, cp, cit);
     }
 #undef PR_TILE
+#undef PR_TILE2
+#undef GR_LGKM0
 #undef PR_MFMA
 #undef PR_PIN
 #undef PR_READ_A
@@ -966,8 +1009,13 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
         const long grid = items < num_cus() ? items : num_cus();
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
-        if (set_lds<gemm_pring_kernel<AK, BK, ACT>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-        hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+        if (g.two_phase && ACT == ACT_NONE) {      // experimental schedule, explicit opt-in only
+            if (set_lds<gemm_pring_kernel<AK, BK, ACT_NONE, 2>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT_NONE, 2>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+        } else {
+            if (set_lds<gemm_pring_kernel<AK, BK, ACT>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+        }
         if (EPI == EPI_BF16 && pl.tail_tiles)
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
                                pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
@@ -1030,6 +1078,7 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     GemmArgs g{};
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
+    g.two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1047,6 +1096,7 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
+    g.two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1065,6 +1115,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     hipStream_t s = (hipStream_t)stream;
     const int BN = pick_bn(Q, impl);
     const int tile_major_debug = (impl & XQ_GEMM_TILE_MAJOR) ? 1 : 0;
+    const int two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
     impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
@@ -1080,6 +1131,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
         if (impl == XQ_GEMM_AUTO) impl = BN == 256 ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
         compact = impl == XQ_GEMM_PERSISTENT;
         g.tile_major_debug = tile_major_debug;
+        g.two_phase = two_phase;
         if (!compact && (ws_bytes < (size_t)splits * P * Q * 4 || !ws)) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
         const int rc = launch_gemm<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, ws, ws_bytes, s, fn, 2.0 * P * Q * (double)(kt_all * 64));
         if (rc) return rc;

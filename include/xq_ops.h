@@ -393,6 +393,8 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_DEBUG_NO_STORE 0x200 /* OR-ed into impl (NT, persistent schedule): skip the output stores — timing experiments, result unusable */
 #define XQ_GEMM_TILE_MAJOR 0x400 /* OR-ed into impl (TN, persistent schedule): execute the K-split items tile-major instead of split-major (A/B timing) */
 #define XQ_GEMM_PLAIN_STORE 0x800 /* OR-ed into impl (persistent schedule): plain instead of non-temporal output stores (A/B timing) */
+#define XQ_GEMM_TWO_PHASE 0x1000 /* OR-ed into impl (persistent schedule, no fused activation): EXPERIMENTAL two-phase-per-K-tile schedule; never
+                                    chosen by XQ_GEMM_AUTO; derived on paper (hazard table in csrc/xq_gemm.hip), not yet run on hardware */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2
