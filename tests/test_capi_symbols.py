@@ -76,3 +76,40 @@ def test_argument_validation_returns_errors_without_a_gpu():
     assert l.xq_unfold1d_circular(one, 1, 4, 64, 9, 1, one, None) != 0               # kernel longer than the sequence
     assert l.xq_gelu_forward(one, 7, 1, 0, one, None) != 0                          # not a multiple of the 16-byte vector
     assert l.xq_prof_marker(0, None) != 0
+
+
+def test_round2_entry_points_validate_their_arguments_without_a_gpu():
+    """the entry points added in round 2 (GEMMs, fused glue ops, the device-step optimizer variant): error codes and messages before any
+    device access; empty problems are no-ops"""
+    from imagefolder_amd import _lib
+    l = _lib.lib()
+    one = ctypes.c_void_p(16)
+    f = ctypes.c_float
+
+    def err():
+        return l.xq_last_error().decode()
+
+    # GEMMs: reduction depth must be a multiple of 64, at least 32 output columns
+    assert l.xq_gemm_bf16_nt(one, one, None, 128, 256, 96, one, None, 0, 0, None) != 0 and "K" in err()
+    assert l.xq_gemm_bf16_nt(one, one, None, 128, 16, 128, one, None, 0, 0, None) != 0
+    assert l.xq_gemm_bf16_nt(None, None, None, 0, 256, 128, None, None, 0, 0, None) == 0          # no rows: nothing to do
+    assert l.xq_gemm_bf16_tn(one, one, 4096, 20, 256, one, one, 1 << 20, 0, None) != 0 and "P" in err()
+    assert l.xq_gemm_bf16_nt(one, one, None, 4096, 128, 128, one, None, 0, 2, None) != 0 and "ring" in err()   # ring needs 256-column tiles
+    # fused glue ops
+    assert l.xq_vec_normalize(None, 8, f(1e-12), one, None, None) != 0 and "null" in err()
+    assert l.xq_vec_normalize(None, 0, f(1e-12), None, None, None) == 0
+    assert l.xq_sn_weight_grad(one, one, one, None, one, 4, 4, one, None) != 0 and "null" in err()
+    assert l.xq_rowdot_forward(one, one, 10, 12, 1, one, None) != 0 and "16-byte" in err()
+    assert l.xq_rowdot_backward(one, one, one, 10, 384, 1, one, one, None, None) != 0 and "partials" in err()
+    assert l.xq_rowdot_forward(None, None, 0, 384, 1, None, None) == 0
+    assert l.xq_diffaug_forward(one, None, 2, 8, 8, 1, 1, 2, 2, 1, 1, 1, one, one, None) != 0 and "null" in err()
+    assert l.xq_diffaug_forward(one, one, 2, 0, 8, 1, 1, 2, 2, 1, 1, 1, one, one, None) != 0 and "shape" in err()
+    assert l.xq_diffaug_backward(None, None, 0, 8, 8, 1, 1, 2, 2, 1, 1, 1, None, None, None) == 0
+    assert l.xq_diffaug_workspace_floats(3) == 3 * 64
+    assert l.xq_lpips_level_backward_fused(one, one, one, None, None, 1, 2, 16, 64, 1, one, None) != 0 and "null" in err()
+    assert l.xq_colsum_partials(None, 4, 64, one, None) != 0
+    assert l.xq_conv3x3_from3_forward(one, 0, one, None, 2, 8, 8, 96, 1, one, None) != 0 and "Cout" in err()
+    # optimizer: the device-step variant needs its coefficient buffer; the host-step variant a step >= 1
+    assert l.xq_adamw_ema_step_dev(one, one, one, one, None, None, 64, f(1e-3), f(0.9), f(0.95), f(1e-8), f(0.0), None, f(0.999), f(1.0), 1,
+                                   None) != 0 and "coefficient" in err()
+    assert l.xq_adamw_ema_step(one, one, one, one, None, None, 64, f(1e-3), f(0.9), f(0.95), f(1e-8), f(0.0), 0, f(0.999), f(1.0), 1, None) != 0
