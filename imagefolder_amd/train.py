@@ -414,7 +414,9 @@ class CapturedStep:
     DiffAug draws, perturbation draws differ from step to step as in eager mode), the optimizer's step counter lives on the device.
     What is FROZEN at capture time: every host-side decision — DiffAug's three branch draws (constant anyway at the reference's
     aug_prob = 1.0), the quantizer-dropout depths of codebook_drop > 0 configs (numpy draws upstream), epoch / alpha / beta / delta,
-    learning rates.  capture() refuses multi-scale models with codebook_drop > 0 unless allow_frozen_host_rng=True.
+    learning rates, and the quantizers' `record_hit` counters, i.e. which coefficient (0.9 during the first 100 updates, then 0.99:
+    xqgan_model.py:779-785) the codebook-usage EMA uses — a statistic only, but capture after the first 100 steps if it is logged.
+    capture() refuses multi-scale models with codebook_drop > 0 unless allow_frozen_host_rng=True.
     Single process only (collectives are not recorded): with world > 1 use the eager step."""
 
     def __init__(self, ts: "TokenizerTrainStep", imgs: torch.Tensor, epoch=0, alpha=0.0, beta=0.0, delta=100, warmup: int = 2,
