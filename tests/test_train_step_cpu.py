@@ -44,6 +44,42 @@ def test_flat_arena_keeps_module_semantics():
             assert p.grad.data_ptr() >= ar.g.data_ptr()  # grads landed in the arena
 
 
+def test_released_gradients_are_adopted_then_collected_into_the_arena():
+    """FlatArena.release_grads / collect (the train step's path): with p.grad = None autograd adopts the gradient tensors of the backward
+    nodes (no add into the arena view); collect() copies them into their slots — partial ranges too, as the all-reduce chunks do —
+    re-points p.grad at the slots and leaves the slots of parameters without a gradient at zero; two backward passes still accumulate."""
+    from imagefolder_amd.train import FlatArena
+    m, ref = Tiny(), Tiny()
+    ar = FlatArena(m.parameters())
+    x = torch.randn(4, 5)
+    _loss(ref(x, 0, 0, 0, 0), x).backward()
+    ar.release_grads()
+    assert all(p.grad is None for p in ar.params)
+    _loss(m(x, 0, 0, 0, 0), x).backward()
+    outside = [p for p, o in zip(ar.params, ar.offsets) if p.grad is not None and p.grad.data_ptr() != ar.g.data_ptr() + 4 * o]
+    assert outside, "autograd should have adopted fresh gradient tensors"
+    assert float(ar.g.abs().max()) == 0.0                      # nothing reached the arena yet
+    half = len(ar.params) // 2
+    ar.collect(0, half)                                         # one all-reduce chunk's worth
+    for i, (p, q) in enumerate(zip(ar.params, [q for q in ref.parameters() if q.requires_grad])):
+        o, n = ar.offsets[i], p.numel()
+        if i < half:
+            assert p.grad.data_ptr() == ar.g.data_ptr() + 4 * o and torch.allclose(ar.g[o:o + n].view(p.shape), q.grad)
+        else:
+            assert float(ar.g[o:o + n].abs().max()) == 0.0
+    ar.collect()
+    for p, q in zip(ar.params, [q for q in ref.parameters() if q.requires_grad]):
+        assert torch.allclose(p.grad, q.grad) and p.grad.data_ptr() >= ar.g.data_ptr()
+    # gradient accumulation over two backward passes before one collect
+    ar.g.zero_()
+    ar.release_grads()
+    _loss(m(x, 0, 0, 0, 0), x).backward()
+    _loss(m(x, 0, 0, 0, 0), x).backward()
+    ar.collect()
+    for p, q in zip(ar.params, [q for q in ref.parameters() if q.requires_grad]):
+        assert torch.allclose(p.grad, 2 * q.grad, atol=1e-6)
+
+
 def test_host_optimizer_matches_torch_adamw_and_reference_ema():
     from imagefolder_amd.train import TokenizerTrainStep
     m, ref = Tiny(), Tiny()
