@@ -1,7 +1,9 @@
 #!/usr/bin/env python
 """bench.py — tokenizer train-step throughput on MI355X (contract: ONE JSON line on rank 0).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without WORLD_SIZE in the environment: re-executes itself under
+                                                            torch.distributed.run --nproc-per-node N, one rank per GPU — the
+                                                            reference's launch line, README.md:195 `torchrun --nproc_per_node=8 ...`)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workload (BASELINE.json configs[1]): VQ-8192.yaml — VQ-16 tokenizer, DINOv2 ViT-B encoder + decoder (random init: no
@@ -112,7 +114,7 @@ def quantizer_stage(dev, B_sample=16, iters=3):
     return (time.perf_counter() - t0) / iters * 1e3
 
 
-def cpu_baseline(args, dev, B_sample=2, budget_s=25.0):
+def cpu_baseline(args, dev, B_sample=2):
     """The complete train step of this config on the host cores (fp32), bounded sample; + the quantizer stage GPU vs CPU."""
     cpu = torch.device("cpu")
     a2 = argparse.Namespace(**vars(args))
@@ -125,7 +127,7 @@ def cpu_baseline(args, dev, B_sample=2, budget_s=25.0):
         t0 = time.perf_counter()
         ts.step(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"])  # warm-up (allocations, oneDNN primitives)
         warm = time.perf_counter() - t0
-        iters = 2 if warm < budget_s / 3 else 1
+        iters = 3      # SURVEY §8d asks for a warm-up + several timed iterations; B_sample is what bounds the leg, not the count
         t0 = time.perf_counter()
         for _ in range(iters):
             ts.step(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"])
@@ -221,8 +223,27 @@ def build_train_step(args, dev, world, amp_dtype=torch.bfloat16, disc_group=None
     return model, ts
 
 
+def _respawn_one_rank_per_gpu(args):
+    """`python bench.py --gpus N` (N > 1) without a launcher: become `python -m torch.distributed.run --nproc-per-node N bench.py ...`
+    (one process per GPU over RCCL, rendezvous on 127.0.0.1 — the container hostname may not resolve).  Rank 0 of the spawned job
+    prints the JSON line; this process is replaced (execv), so stdout / the exit code are the job's."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool's host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stderr.write("bench.py: no WORLD_SIZE in the environment, spawning " + " ".join(cmd[1:8]) + " ...\n")
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_one_rank_per_gpu(args)
     CFG.update(CONFIGS[args.config])
     if args.batch == CONFIGS["VQ-8192"]["B"] and args.config != "VQ-8192":
         args.batch = CFG["B"]
@@ -238,14 +259,10 @@ def main():
     force_dist = os.environ.get("XQ_FORCE_DIST", "0") == "1"
     use_dist = world > 1 or force_dist
     disc_group = None
-    # flops of one step per image (for "mfu"): counted on rank 0 BEFORE the process group exists — the counting pass builds its own
-    # train step, which would otherwise see world > 1 and issue collectives that no other rank joins
+    # flops of one step per image (for "mfu") are counted on rank 0 at the very END, after the process group is gone: the counting
+    # pass builds its own train step, which must not issue collectives that no other rank joins — and no rank waits in the
+    # rendezvous while rank 0 counts
     flops_img, mfu_error = None, None
-    if rank == 0 and args.workload == "train_step" and not args.no_mfu:
-        try:
-            flops_img = count_flops_per_image(args, dev)
-        except Exception as e:  # noqa: BLE001 - the bench line must still print
-            mfu_error = f"{type(e).__name__}: {e}"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -326,6 +343,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # like-with-like for the scaling curve: world > 1 always runs the eager step, so at N = 1 the eager step is timed next to the
+    # replayed one (config.hip_graph_eager_ms_per_step); `value` stays the replayed number the graph note declares
+    eager_ms = None
+    if captured is not None:
+        n_eager = min(args.steps, 10)
+        step()
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(n_eager):
+            step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - te) / n_eager * 1e3
     PROF_STEPS = 3
     prof_steps = args.steps
     if captured is not None:
@@ -352,6 +381,9 @@ def main():
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = tmax.item()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()      # from here on rank 0 works alone (flop count, CPU baseline); the other ranks are done
 
     if rank == 0:
         # algorithmic flops of the assign kernel: 2*N*V*C per launch; a step launches it once per
@@ -385,6 +417,7 @@ def main():
                                 grad_allreduce="rccl" if world > 1 or os.environ.get("XQ_FORCE_DIST") else "not run (single process)"),
                 "loss": args.loss,
                 "hip_graph": graph_note,
+                "hip_graph_eager_ms_per_step": eager_ms,
                 "roofline_timing": ("HIP events around every instrumented launch over the timed region" if captured is None else
                                     f"HIP events around every instrumented launch over {PROF_STEPS} eager steps of the same workload run "
                                     "right after the timed replays (the graph holds the same kernels without the event records)"),
@@ -435,6 +468,13 @@ def main():
                                 "comm_dtype": args.grad_comm, "chunks": len(ts.reducer.chunks),
                                 "launch": "per-chunk from backward hooks, generator and discriminator on separate communicators",
                                 "exposed_ms_per_step": (sum(exposed) / len(exposed)) if exposed else None}
+            if not args.no_mfu:
+                captured = ts = model = step = run = None      # release the timed step's arenas before the counting pass
+                torch.cuda.empty_cache()
+                try:
+                    flops_img = count_flops_per_image(args, dev)
+                except Exception as e:  # noqa: BLE001 - the bench line must still print
+                    mfu_error = f"{type(e).__name__}: {e}"
             if mfu_error:
                 out["mfu_error"] = mfu_error
             out["mfu"] = None if flops_img is None else {
@@ -449,9 +489,7 @@ def main():
                 out["cpu_baseline"] = dict(value=16 / (q_cpu * 1e-3), unit="images/sec", cores=torch.get_num_threads(), kind="port",
                                            sample="VectorQuantizer fwd+bwd on B=16 images, ATen CPU fp32 restatement of xqgan_model.py:745-801",
                                            quantizer_stage={"quantizer_stage_gpu_ms": q_gpu, "quantizer_stage_cpu_ms": q_cpu})
-        print(json.dumps(out))
-    if use_dist:
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

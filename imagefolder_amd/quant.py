@@ -15,7 +15,7 @@ import torch
 from torch import distributed as tdist, nn as nn
 from torch.nn import functional as F
 
-from .lazy import lazy_list
+from .lazy import lazy_list, materialise
 from . import ops
 
 
@@ -171,6 +171,7 @@ class VectorQuantizer2(VarHelpersMixin, nn.Module):
 
         self.register_buffer('ema_vocab_hit_SV', torch.full((len(self.v_patch_nums), self.vocab_size), fill_value=0.0))
         self.record_hit = 0
+        self.lazy_usages = False     # as VectorQuantizer.lazy_usages: Python floats at the API seam unless the train step opts in
 
         self.beta: float = beta
         self.embedding = nn.Embedding(self.vocab_size, self.Cvae)
@@ -250,7 +251,7 @@ class VectorQuantizer2(VarHelpersMixin, nn.Module):
         margin = world * (f.numel() / f.shape[1]) / self.vocab_size * 0.08
         if ret_usages:
             # one ASYNCHRONOUS device->host copy for all scales, waited for when read (the reference does SN .item() syncs, quant.py:140)
-            usages = lazy_list((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100)
+            usages = materialise(lazy_list((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100), self.lazy_usages)
         else:
             usages = None
         self._last_indices = idx_all
@@ -317,6 +318,6 @@ class VectorQuantizer2Var(VectorQuantizer2):
         B, C, H, W = f.shape
         world = tdist.get_world_size() if _dist_ready() else 1
         margin = world * (B * H * W) / self.vocab_size * 0.08
-        usages = lazy_list((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100) if ret_usages else None
+        usages = materialise(lazy_list((self.ema_vocab_hit_SV >= margin).float().mean(dim=1) * 100), self.lazy_usages) if ret_usages else None
         self._last_indices = idx_all
         return f_hat, usages, mean_vq_loss

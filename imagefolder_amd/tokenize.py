@@ -64,6 +64,7 @@ class BulkTokenizer:
         self.augment = augment
         self.class_ids: List[np.ndarray] = []
         self.tokens: List[np.ndarray] = []
+        self.batch_sizes: List[int] = []          # SOURCE images per batch (before augmentation): the grouping key of write_code_npy
         self._pending = None
         self._side = None
         self._pinned = [None, None]
@@ -111,6 +112,7 @@ class BulkTokenizer:
             if device is not None:
                 samples = samples.to(device, non_blocking=True)
             target = torch.as_tensor(target)
+            self.batch_sizes.append(int(target.shape[0]))
             if self.augment == "ten_crop":
                 samples, target = augment_ten_crop(samples, target)
             elif self.augment == "flip":
@@ -136,18 +138,40 @@ class BulkTokenizer:
         return path
 
     # -- VAR / LlamaGen format (dataset/imagenet.py:8-50) ------------------------------------------------------------
-    def write_code_npy(self, code_dir: str, label_dir: str, n_aug: int, first_index: int = 0) -> int:
-        """consecutive groups of n_aug records are the augmentations of one source image (flip: the batch halves are
-        re-paired by `pair_flip=True` records order: see regroup_flip)"""
+    @property
+    def n_aug(self) -> int:
+        """augmented views per source image in `records`"""
+        if self.augment == "flip":
+            return 2
+        if self.augment == "none":
+            return 1
+        cls, _ = self.records
+        return len(cls) // max(1, sum(self.batch_sizes))      # ten_crop: whatever the crop count of the input was
+
+    def write_code_npy(self, code_dir: str, label_dir: str, n_aug: Optional[int] = None, first_index: int = 0) -> int:
+        """one `{i}.npy` pair per SOURCE image: codes (1, n_aug, L) = its augmented views, label (1,).
+        The record stream is ordered per batch as the augmentation emitted it — flip: [batch, flipped batch]
+        (pretokenization.py:227-228), so the two views of an image are B records apart and are brought together here
+        (regroup_flip over the recorded batch sizes); ten_crop: the crops of an image are already adjacent.  `n_aug`, if given,
+        must be the augmentation's own count (2 / crops / 1)."""
         os.makedirs(code_dir, exist_ok=True)
         os.makedirs(label_dir, exist_ok=True)
         cls, tok = self.records
-        assert len(cls) % n_aug == 0, "record count is not a multiple of the augmentation count"
-        n = len(cls) // n_aug
+        own = self.n_aug
+        if n_aug is not None and n_aug != own:
+            raise ValueError(f"n_aug={n_aug}, but augment='{self.augment}' produced {own} views per image")
+        n_aug = own
+        n = sum(self.batch_sizes)
+        if len(cls) != n * n_aug:
+            raise ValueError(f"{len(cls)} records for {n} source images x {n_aug} views: records were edited behind run()")
+        if self.augment == "flip":
+            cls, tok = regroup_flip(cls, tok, self.batch_sizes)
         for i in range(n):
-            codes = tok[i * n_aug:(i + 1) * n_aug]
-            np.save(os.path.join(code_dir, f"{first_index + i}.npy"), codes.reshape(1, n_aug, -1))
-            np.save(os.path.join(label_dir, f"{first_index + i}.npy"), cls[i * n_aug:i * n_aug + 1].reshape(1))
+            views = cls[i * n_aug:(i + 1) * n_aug]
+            if not (views == views[0]).all():
+                raise ValueError(f"source image {i}: its {n_aug} views carry different labels {views.tolist()}")
+            np.save(os.path.join(code_dir, f"{first_index + i}.npy"), tok[i * n_aug:(i + 1) * n_aug].reshape(1, n_aug, -1))
+            np.save(os.path.join(label_dir, f"{first_index + i}.npy"), views[:1].reshape(1))
         return n
 
 

@@ -250,6 +250,12 @@ class ArenaOptimizer:
                  always_reduce: bool = False):
         self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
         self.ema_decay = ema_decay
+        params = list(params)
+        # torch.optim.AdamW(model.parameters()) — what the reference builds (xqgan_train.py:344-347) — numbers its state by position
+        # in the FULL parameter list, frozen ones included (the frozen semantic_model sits between the decoder and sem_linear):
+        # the checkpoint layout below uses those positions, not positions among the trainable parameters
+        self._n_all = len(params)
+        self._torch_index = [i for i, p in enumerate(params) if p.requires_grad]
         self.arena = FlatArena(params, with_ema=use_ema)
         self.reducer = GradAllReducer(self.arena.g, group=group, chunk_bytes=chunk_bytes,
                                       params=self.arena.params if hooks else None, offsets=self.arena.offsets if hooks else None,
@@ -257,16 +263,17 @@ class ArenaOptimizer:
         self.world = self.reducer.world
 
     # -- checkpointing: the layout of torch.optim.AdamW.state_dict() (what the reference saves as "optimizer" /
-    #    "optimizer_disc", xqgan_train.py:580-600), one entry per parameter in arena order, plus the EMA copy ------------------
+    #    "optimizer_disc", xqgan_train.py:580-600): state keyed by the parameter's position in model.parameters() (frozen
+    #    parameters count and have no entry), one param group listing every position; plus the EMA copy ----------------------------
     def state_dict(self):
         a = self.arena
         state = {}
-        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
+        for ti, p, o in zip(self._torch_index, a.params, a.offsets):
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(a.step_count)), "exp_avg": a.m[o:o + n].view(p.shape).clone(),
-                        "exp_avg_sq": a.v[o:o + n].view(p.shape).clone()}
+            state[ti] = {"step": torch.tensor(float(a.step_count)), "exp_avg": a.m[o:o + n].view(p.shape).clone(),
+                         "exp_avg_sq": a.v[o:o + n].view(p.shape).clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
-                 "amsgrad": False, "maximize": False, "params": list(range(len(a.params)))}
+                 "amsgrad": False, "maximize": False, "params": list(range(self._n_all))}
         out = {"state": state, "param_groups": [group]}
         if a.ema is not None:
             out["ema"] = [a.ema[o:o + p.numel()].view(p.shape).clone() for p, o in zip(a.params, a.offsets)]
@@ -275,20 +282,36 @@ class ArenaOptimizer:
     @torch.no_grad()
     def load_state_dict(self, sd):
         a = self.arena
-        st = sd["state"]
-        assert len(st) in (0, len(a.params)), "optimizer state does not match the parameter list"
+        st = {int(k): v for k, v in sd["state"].items()}
+        groups = sd["param_groups"]
+        n_listed = sum(len(g["params"]) for g in groups)
+        if n_listed != self._n_all:
+            raise ValueError(f"optimizer state lists {n_listed} parameters, the model has {self._n_all} (frozen ones included): "
+                             "not a checkpoint of this parameter list")
+        unknown = sorted(set(st) - set(self._torch_index))
+        if unknown:
+            raise ValueError(f"optimizer state for parameter positions {unknown[:8]}... that are not trainable here")
+        missing = [ti for ti in self._torch_index if ti not in st]
+        if st and missing:
+            raise ValueError(f"optimizer state has no entry for trainable parameter positions {missing[:8]}...")
         steps = set()
-        for i, (p, o) in enumerate(zip(a.params, a.offsets)):
-            e = st.get(i, st.get(str(i))) if st else None
+        for ti, p, o in zip(self._torch_index, a.params, a.offsets):
+            e = st.get(ti)
             if e is None:
                 continue
             n = p.numel()
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of parameter {ti}: shape {tuple(e['exp_avg'].shape)} vs {tuple(p.shape)}")
             a.m[o:o + n].copy_(e["exp_avg"].reshape(-1))
             a.v[o:o + n].copy_(e["exp_avg_sq"].reshape(-1))
             steps.add(int(float(e["step"])))
-        assert len(steps) <= 1, "per-parameter step counts differ: not an AdamW state this optimizer can hold"
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ: not an AdamW state this optimizer can hold")
         a.step_count = steps.pop() if steps else 0
-        g = sd["param_groups"][0]
+        if not st:
+            a.m.zero_()
+            a.v.zero_()
+        g = groups[0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
         if "ema" in sd and a.ema is not None:
             for t, p, o in zip(sd["ema"], a.params, a.offsets):
@@ -376,6 +399,11 @@ class TokenizerTrainStep:
         self.reducer = self.opt.reducer
         self.world = self.opt.world
         self.device = self.arena.p.device
+        # codebook-usage statistics: no host read inside the step (lazy.py) — upstream's .item() per forward (xqgan_model.py:788,
+        # quant.py:140) would stall the stream every step and cannot be recorded into a hipGraph
+        for m in model.modules():
+            if hasattr(m, "lazy_usages"):
+                m.lazy_usages = True
 
     # -- one train step -----------------------------------------------------------------------------------------
     def step(self, imgs, epoch=0, alpha=0.0, beta=0.0, delta=100):
@@ -440,16 +468,21 @@ class CapturedStep:
         if disc is not None:
             disc.opt.prepare_capture()
         self.graph = torch.cuda.CUDAGraph()
-        c0 = (ts.arena.step_count, ts.arena.epoch)
-        with torch.cuda.graph(self.graph):
-            self.loss = ts.step(self.static_imgs, epoch, alpha, beta, delta)
-            if os.environ.get("XQ_TEST_CAPTURE_FAIL") == "1":      # tests: a capture that dies half way (bench.py must recover)
-                raise RuntimeError("XQ_TEST_CAPTURE_FAIL: simulated failure inside the hipGraph capture")
-        # the capture pass ran the host bookkeeping once without executing anything: take it back; replay() redoes it per step
-        ts.arena.step_count, ts.arena.epoch = c0
-        if disc is not None:
-            disc.opt.arena.step_count -= 1
-            disc.global_step -= 1
+        c0 = ts.arena.step_count
+        d0 = (disc.opt.arena.step_count, disc.global_step) if disc is not None else None
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = ts.step(self.static_imgs, epoch, alpha, beta, delta)
+        finally:
+            # the capture pass ran the host bookkeeping once without executing anything (also when it raised half way): the step
+            # counters go back, replay() advances them per step.  The arena EPOCHS stay advanced (and move once more): every cache
+            # filled during the capture (packed conv weights, ...) is stamped with the capture-time epoch but its producer kernels
+            # were only recorded — eager code that runs before the first replay must not hit those entries
+            ts.arena.step_count = c0
+            ts.arena.epoch += 1
+            if disc is not None:
+                disc.opt.arena.step_count, disc.global_step = d0
+                disc.opt.arena.epoch += 1
         self._disc = disc
 
     def replay(self, imgs: Optional[torch.Tensor] = None):

@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.distributed as tdist
 
-from .lazy import LazyFloat
+from .lazy import LazyFloat, materialise, mean_lazy
 from . import nn_ops, ops
 from .cliploss import ClipLoss
 from .cnn import Encoder, Decoder
@@ -54,6 +54,9 @@ class VectorQuantizer(nn.Module):
 
         self.register_buffer("ema_vocab_hit_SV", torch.full((self.vocab_size,), fill_value=0.0))
         self.record_hit = 0
+        # False: `usages` are Python floats, read with one synchronisation like upstream's .item() (:788); True (set by
+        # train.TokenizerTrainStep): LazyFloat objects that are only waited for when somebody reads them (lazy.py)
+        self.lazy_usages = False
 
     def no_weight_decay(self):
         return ['embedding.weight', ]
@@ -77,7 +80,7 @@ class VectorQuantizer(nn.Module):
             self.record_hit += 1
             margin = world * (z.numel() / self.z_channels) / self.vocab_size * 0.08
             # read lazily: no device synchronisation inside the forward (the reference calls .item() here, :788)
-            codebook_usage = LazyFloat((self.ema_vocab_hit_SV >= margin).float().mean() * 100)
+            codebook_usage = materialise([LazyFloat((self.ema_vocab_hit_SV >= margin).float().mean() * 100)], self.lazy_usages)[0]
         else:
             # the reference leaves `codebook_usage` unbound here and dies with UnboundLocalError
             # (xqgan_model.py:773-788,801); same error type, clearer message.
@@ -333,7 +336,7 @@ class VQModel(nn.Module):
                 commit_list.append(commit_loss); ent_list.append(entropy_loss)
             dependency_loss = self.dependency_loss_weight * orthogonal_cosine_loss(
                 torch.mean(quant_list[0], dim=(2, 3)).contiguous(), torch.mean(quant_list[-1], dim=(2, 3)).contiguous())
-            usages = [sum(us) / self.product_quant for us in zip(*usages_list)]
+            usages = mean_lazy(usages_list)     # :287 sum(us) / product_quant, without reading the statistics on the host
             mean_vq_loss = sum(vq_list) / self.product_quant
             mean_commit_loss = sum(commit_list) / self.product_quant
             mean_entropy = sum(ent_list) / self.product_quant

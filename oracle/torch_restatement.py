@@ -58,3 +58,45 @@ def perturb(z, z_q, weight, codebook_norm, alpha, beta, delta, random_prob, rand
     pz = (zt + (pz - zt).detach()).permute(0, 3, 1, 2)  # :29-30
     mask = (torch.arange(z.shape[0]) < int(z.shape[0] * beta))[:, None, None, None]  # :32-33
     return torch.where(mask, pz, z_q), pick
+
+
+def msvq_ladder(f, weight, phi_w, phi_b, n_quant, patch_nums, phi_sel, phi_ratio, using_znorm, skip_last_pool):
+    """VectorQuantizer2.forward's ladder (tokenizer_image/quant.py:64-135) on ATen CPU ops, returned in the shape of
+    imagefolder_amd.ops.MSVQLadder: (f_hat straight-through, sq_vq (SN,), sq_commit (SN,), idx_all, hist (SN,V)).
+    sq_vq[s] = sum(mask_s (f_hat_s - sg f)^2) carries the gradient into the codebook / Phi convs (:131), sq_commit[s] =
+    sum(mask_s (sg f_hat_s - f)^2) the one into f (:132); the caller divides by ratio_s, numel and SN as the reference does.
+    phi_w (K,C,C,3,3) / phi_b (K,C): the stacked Phi convs, phi_sel[s] the one scale s uses (quant.py:110-113,280-288)."""
+    B, C, H, W = f.shape
+    SN = len(patch_nums)
+    V = weight.shape[0]
+    f_no_grad = f.detach()
+    f_rest = f_no_grad.clone()                                           # :68-70
+    f_hat = torch.zeros_like(f_rest)
+    nq = torch.full((B,), float(SN + 1)) if n_quant is None else n_quant.float()
+    sq_vq, sq_commit, idxs, hists = [], [], [], []
+    E = weight.detach()
+    for si, pn in enumerate(patch_nums):
+        pooled = not (si == SN - 1 and skip_last_pool)                   # :91-92
+        rest = (F.interpolate(f_rest, size=(pn, pn), mode='area') if pooled else f_rest).permute(0, 2, 3, 1).reshape(-1, C)
+        if using_znorm:                                                  # :93-94
+            idx = torch.argmax(F.normalize(rest, dim=-1) @ F.normalize(E.T, dim=0), dim=1)
+        else:                                                            # :96-101
+            d = rest.square().sum(1, keepdim=True) + E.square().sum(1)
+            d = d.addmm(rest, E.T, alpha=-2, beta=1)
+            idx = torch.argmin(d, dim=1)
+        hists.append(idx.bincount(minlength=V).float())                  # :102
+        idxs.append(idx)
+        h = weight[idx.view(B, pn, pn)].permute(0, 3, 1, 2)              # :106-109 (gradient reaches the codebook rows)
+        if si != SN - 1:
+            h = F.interpolate(h, size=(H, W), mode='bicubic')
+        h = h.contiguous()
+        if phi_w is not None:                                            # :110-113, Phi.forward :266-268
+            k = phi_sel[si]
+            h = h * (1 - phi_ratio) + F.conv2d(h, phi_w[k], phi_b[k], padding=1) * phi_ratio
+        mask = (torch.full((B,), float(si)) < nq)[:, None, None, None].to(h.dtype)     # :115
+        f_hat = f_hat + h * mask                                         # :116
+        f_rest = f_rest - h.detach()                                     # :118
+        sq_vq.append(((f_hat - f_no_grad).square() * mask).sum())        # :131 (numerator)
+        sq_commit.append(((f_hat.detach() - f).square() * mask).sum())   # :132 (numerator)
+    f_hat_ste = (f_hat.detach() - f_no_grad) + f                         # :135
+    return f_hat_ste, torch.stack(sq_vq), torch.stack(sq_commit), torch.cat(idxs), torch.stack(hists)

@@ -56,16 +56,20 @@ def test_records_flip_jsonl_and_npy_formats(tmp_path):
     c, t = tk.read_jsonl_record(os.path.join(tmp_path, "pretokenized.jsonl"), 4)
     assert c.item() == 6 and t.dtype == torch.int64 and np.array_equal(t.numpy(), tok[4])
 
-    # VAR / LlamaGen: the two views of one image adjacent, (1, n_aug, L) codes + (1,) label per source image
+    # VAR / LlamaGen through the public path: the two views of one image in one file, (1, n_aug, L) codes + (1,) label per source image
     c2, t2 = tk.regroup_flip(cls, tok, [3, 2])
     assert c2.tolist() == [5, 5, 6, 6, 7, 7, 8, 8, 9, 9]
-    bt.class_ids, bt.tokens = [c2], [t2]
-    n_img = bt.write_code_npy(os.path.join(tmp_path, "codes"), os.path.join(tmp_path, "labels"), n_aug=2)
+    assert bt.batch_sizes == [3, 2] and bt.n_aug == 2
+    n_img = bt.write_code_npy(os.path.join(tmp_path, "codes"), os.path.join(tmp_path, "labels"))
     assert n_img == 5
-    feats = np.load(os.path.join(tmp_path, "codes", "2.npy"))
-    labels = np.load(os.path.join(tmp_path, "labels", "2.npy"))
-    assert feats.shape == (1, 2, L) and labels.shape == (1,) and labels[0] == 7
-    assert np.array_equal(feats[:, 1], tok[5:6])                                  # CustomDataset: features[:, aug_idx]
+    for i, (label, orig, flipped) in enumerate([(5, 0, 3), (6, 1, 4), (7, 2, 5), (8, 6, 8), (9, 7, 9)]):
+        feats = np.load(os.path.join(tmp_path, "codes", f"{i}.npy"))
+        labels = np.load(os.path.join(tmp_path, "labels", f"{i}.npy"))
+        assert feats.shape == (1, 2, L) and labels.shape == (1,) and labels[0] == label
+        assert np.array_equal(feats[0, 0], tok[orig]) and np.array_equal(feats[0, 1], tok[flipped])   # CustomDataset: features[:, aug_idx]
+    assert not np.array_equal(tok[0], tok[3])                      # the fake tokenizer is not flip-invariant: a mix-up would show
+    with pytest.raises(ValueError, match="views per image"):
+        bt.write_code_npy(os.path.join(tmp_path, "codes"), os.path.join(tmp_path, "labels"), n_aug=1)
 
 
 def test_ten_crop_layout():
@@ -74,6 +78,7 @@ def test_ten_crop_layout():
     bt = tk.BulkTokenizer(model, augment="ten_crop").run([(x, torch.tensor([1, 2]))])
     cls, tok = bt.records
     assert cls.tolist() == [1] * 10 + [2] * 10 and tok.shape == (20, 16)
+    assert bt.n_aug == 10
 
 
 @pytest.mark.gpu

@@ -77,14 +77,44 @@ def test_bench_runs_its_rccl_branch_at_world_size_1():
 
 def test_bench_recovers_from_a_failed_hipgraph_capture():
     """bench.py --graph auto: when the capture of the train step fails half way, the process re-executes itself with --graph off
-    (the invalidated capture state would otherwise kill the eager step that follows) and still prints its JSON line."""
-    env = dict(os.environ, XQ_TEST_CAPTURE_FAIL="1")
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--no-cpu-baseline", "--no-mfu"], env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    (the invalidated capture state would otherwise kill the eager step that follows) and still prints its JSON line.
+    The failure is injected from here: the step function is wrapped so that it raises while the stream is capturing."""
+    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-mfu"]
+    prog = (
+        "import sys, torch\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        f"sys.argv = [{os.path.join(ROOT, 'bench.py')!r}] + {argv!r}\n"
+        "import imagefolder_amd.train as t\n"
+        "orig = t.TokenizerTrainStep.step\n"
+        "def step(self, *a, **k):\n"
+        "    out = orig(self, *a, **k)\n"
+        "    if torch.cuda.is_current_stream_capturing():\n"
+        "        raise RuntimeError('injected failure inside the hipGraph capture')\n"
+        "    return out\n"
+        "t.TokenizerTrainStep.step = step\n"
+        "import bench\n"
+        "bench.main()\n")
+    out = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "re-running with --graph off" in out.stderr
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert res["config"]["hip_graph"].startswith("off") and res["value"] > 0
+
+
+def test_bench_spawns_its_ranks_under_torch_distributed_run():
+    """the driver's multi-GPU command line, on the one GPU of this box: `python -m torch.distributed.run --nproc-per-node 1 bench.py
+    --gpus 1` (WORLD_SIZE / RANK / LOCAL_RANK / MASTER_* from the launcher; XQ_FORCE_DIST makes the world-1 job create its RCCL
+    groups and run every collective) — and bench.py's own spawn path (_respawn_one_rank_per_gpu builds exactly this command for
+    --gpus N > 1 when no launcher set WORLD_SIZE)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["XQ_FORCE_DIST"] = "1"
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+                          "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--batch", "8", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["allreduce"]["backend"] == "rccl" and res["allreduce"]["exposed_ms_per_step"] is not None
+    assert res["mfu"] is not None and res["mfu"]["flops_per_image"] > 0      # counted after the process group was torn down
 
 
 def test_bench_replays_the_step_from_a_hipgraph_by_default():
