@@ -74,7 +74,18 @@ struct GemmArgs {
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
     int two_phase;          // XQ_GEMM_TWO_PHASE: experimental 2-phase-per-K-tile schedule of the persistent kernel (opt-in, untested on hardware)
+    int row_major_debug;    // XQ_GEMM_ROW_MAJOR: plain row-major whole-tile items (A/B timing of the XCD-banded order below)
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
+    // XCD-banded tile order of the persistent schedule's whole-tile items (NT / NN / implicit-GEMM conv).  The tile grid is cut
+    // into column GROUPS of grp_c column tiles; the tile sequence runs group by group, row-major inside a group; XCD x (workgroups
+    // x, x + 8, ...) owns the contiguous eighth [x, x + 1) * band_full / 8 of that sequence and walks it round by round.  So the B
+    // panels an XCD needs (grp_c x 256 x K x 2 bytes, sized by plan_band() to stay resident in its 4 MiB L2) are fetched once per
+    // XCD instead of once per round, and successive rounds move DOWN the rows of one group instead of jumping 256 tiles ahead
+    // (row-major order made every XCD stream the whole weight matrix every round: 4 - 6x re-fetch of it through the fabric,
+    // profiles/r02_kernel_hbm_traffic_shapes.json).  band_full = the items under this mapping (a multiple of the grid size; the
+    // last partial round and the K-split tail keep sequence position = item index); grp_c = 0: plain row-major (XQ_GEMM_ROW_MAJOR).
+    int grp_c;
+    long band_full;
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
                             // ONE range of g / x rows through its L2 for all of that range's output tiles; tile-major order (0, the
@@ -549,8 +560,10 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
         it.slab = 1;
         it.slab_idx = tl * nsplit + split;       // slab layout [tile][split] whatever the execution order (slab_reduce_kernel)
     }
-    it.m0 = (tile / g.tiles_n) * gm::BM;
-    it.n0 = (tile % g.tiles_n) * 256;
+    long tm, tn;
+    gm::band_tile(gm::band_seq(p < g.main_items ? p : tile, g.band_full, (long)gridDim.x), g.tiles_m, g.tiles_n, g.grp_c, &tm, &tn);
+    it.m0 = tm * gm::BM;
+    it.n0 = tn * 256;
     const long base = g.kt_full / nsplit, rem = g.kt_full % nsplit;
     it.k0 = (split * base + (split < rem ? split : rem)) * gm::BKT;
     it.KT = (int)(base + (split < rem ? 1 : 0));
@@ -867,14 +880,16 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 
 // slabs [item = tail tile * nsplit + split][256][256] fp32 -> output: the sum over the splits of every tail tile,
 //   bf16 (+ bias) into C (NT / NN tail tiles), or fp32 into out (TN; + the < 64 remainder rows of the reduction, folded in here)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_n,
-                                                          long M, long N, long ldc, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_m, int tiles_n,
+                                                          int grp_c, long M, long N, long ldc, const float *__restrict__ bias,
                                                           __hip_bfloat16 *__restrict__ out16, float *__restrict__ out32,
                                                           const __hip_bfloat16 *__restrict__ G, const __hip_bfloat16 *__restrict__ X,
                                                           long r_begin, long r_end) {
     const long t = blockIdx.x;
     const long tile = first_tile + t;
-    const long m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+    long tm, tn;
+    gm::band_tile(tile, tiles_m, tiles_n, grp_c, &tm, &tn);     // tail tiles: sequence position = tile index (decode_item)
+    const long m0 = tm * 256, n0 = tn * 256;
     const int rl = blockIdx.y * 8 + (threadIdx.x >> 5), cl = (threadIdx.x & 31) * 8;
     const long gr = m0 + rl, gc = n0 + cl;
     if (gr >= M || gc + 8 > N) return;
@@ -984,6 +999,29 @@ PPlan plan_persistent(long tiles, int kt_full, bool weight_grad) {
     return p;
 }
 
+// column-group width of the banded order (GemmArgs::grp_c): the c that minimises the bytes the eight L2s pull through the fabric,
+//   A panels: every row panel is fetched once per column group                      -> A_bytes * ceil(tiles_n / c)
+//   B panels: a group that fits the L2 budget stays resident, fetched once per XCD   -> 8 * c * panel_B
+//             one that does not is streamed again by every XCD in every round        -> rounds * 8 * c * panel_B
+// (panel_B = 256 x K x 2 bytes; budget 2.5 MiB of the 4 MiB L2: the A panels of the round in flight and the output stream need the rest)
+int plan_band(long tiles_m, long tiles_n, long K) {
+    const double panel_b = 256.0 * (double)K * 2.0, a_bytes = (double)tiles_m * 256.0 * (double)K * 2.0;
+    const double rounds = (double)(tiles_m * tiles_n) / (double)num_cus();
+    const double budget = 2.5 * 1048576.0;
+    double best = -1.0;
+    int best_c = (int)tiles_n;
+    for (long c = 1; c <= tiles_n; ++c) {
+        const long groups = (tiles_n + c - 1) / c;
+        if ((groups - 1) * c >= tiles_n) continue;
+        const long cw = (tiles_n + groups - 1) / groups;          // balanced widths: ceil(tiles_n / groups)
+        if (cw != c) continue;
+        const double fb = (c * panel_b <= budget ? 1.0 : (rounds > 1.0 ? rounds : 1.0)) * 8.0 * (double)c * panel_b;
+        const double cost = a_bytes * (double)groups + fb;
+        if (best < 0.0 || cost < best) { best = cost; best_c = (int)c; }
+    }
+    return best_c;
+}
+
 template <int AK, int BK, int EPI, int ACT = ACT_NONE>
 int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStream_t s, const char *fn, double flops, int prof_kind = XQ_PROF_GEMM) {
     const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -1008,6 +1046,13 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         g.slabs = (float *)ws;
         const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
         const long grid = items < num_cus() ? items : num_cus();
+        if (EPI == EPI_BF16 && !g.row_major_debug && grid % 8 == 0 && pl.main_items >= grid) {
+            g.grp_c = plan_band(g.tiles_m, g.tiles_n, (long)g.kt_full * gm::BKT);
+            g.band_full = (pl.main_items / grid) * grid;
+        } else {
+            g.grp_c = 0;
+            g.band_full = 0;
+        }
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
         if (g.two_phase && ACT == ACT_NONE) {      // experimental schedule, explicit opt-in only
             if (set_lds<gemm_pring_kernel<AK, BK, ACT_NONE, 2>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
@@ -1018,7 +1063,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         }
         if (EPI == EPI_BF16 && pl.tail_tiles)
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
-                               pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
+                               pl.main_items, g.tiles_m, g.tiles_n, g.grp_c, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
                                (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L);
     } else {
         if (ACT != ACT_NONE) return xq_set_error(XQ_EINVAL, "%s: the fused activation needs the persistent schedule", fn);
@@ -1079,6 +1124,7 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
+    g.row_major_debug = (impl & XQ_GEMM_ROW_MAJOR) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1097,6 +1143,7 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
+    g.row_major_debug = (impl & XQ_GEMM_ROW_MAJOR) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1138,7 +1185,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     }
     const long done = splits ? kt_all * 64 : 0;   // rows covered by whole K tiles
     if (compact) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)tiles, 32), dim3(256), 0, s, (const float *)ws, splits, 0L, g.tiles_n, (long)P,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)tiles, 32), dim3(256), 0, s, (const float *)ws, splits, 0L, g.tiles_m, g.tiles_n, 0, (long)P,
                            (long)Q, (long)Q, (const float *)nullptr, (__hip_bfloat16 *)nullptr, g_w, (const __hip_bfloat16 *)g_y,
                            (const __hip_bfloat16 *)x, done, (long)R);
     } else {
@@ -1198,8 +1245,10 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     if ((long)B * Hi * Wi >= 0x7fffffffL || Ho > 32767 || Wo > 32767) return xq_set_error(XQ_EINVAL, "%s: image too large for 32-bit pixel indices", fn);
     const long M = (long)B * Ho * Wo, K = 9L * Cin;
     const int BN = pick_bn(Cout, impl);
+    const int row_major_debug = (impl & XQ_GEMM_ROW_MAJOR) ? 1 : 0;
     impl &= 0xff;
     GemmArgs g{};
+    g.row_major_debug = row_major_debug;
     g.nt_store = 1;
     g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;
     g.M = M; g.N = Cout; g.lda = K; g.ldb = K; g.ldc = Cout;

@@ -215,14 +215,23 @@ class VectorQuantizer2(VarHelpersMixin, nn.Module):
         B, C, H, W = f.shape
         SN = len(self.v_patch_nums)
         # quantizer dropout: per-sample number of active scales, built on the host exactly like quant.py:79-86
-        if self.training and dropout is not None:
+        inv_ratio = None
+        if self.training and dropout is not None and dropout.is_cuda:
+            # depths drawn on the device (VQModel.device_dropout_rng): everything stays there — no host read, replay-safe
+            n_quantizers = torch.full((B,), float(SN + 1), device=dropout.device)
+            n_dropout = int(B * self.codebook_drop)
+            n_quantizers[:n_dropout] = dropout[:n_dropout].to(n_quantizers.dtype)
+            active = torch.arange(SN, device=dropout.device, dtype=torch.float32)[:, None] < n_quantizers[None, :]
+            inv_ratio = float(B) / active.float().sum(dim=1)            # 1 / ratio_s, ratio_s = mask.sum() / B (quant.py:128)
+        elif self.training and dropout is not None:
             n_quantizers = torch.ones((B,)) * (SN + 1)
             n_dropout = int(B * self.codebook_drop)
             n_quantizers[:n_dropout] = dropout[:n_dropout].to(n_quantizers.dtype)
         else:
             n_quantizers = torch.ones((B,)) * (SN + 1)
-        # ratio_s = mask.sum()/B (quant.py:128) — known on the host, no device sync
-        ratio = [float((torch.full((B,), float(si)) < n_quantizers).sum().item()) / B for si in range(SN)]
+        if inv_ratio is None:
+            # ratio_s = mask.sum()/B (quant.py:128) — known on the host, no device sync
+            ratio = [float((torch.full((B,), float(si)) < n_quantizers).sum().item()) / B for si in range(SN)]
         last_pn = self.v_patch_nums[-1]
         skip_last_pool = (last_pn == int(sqrt(self.num_latent_tokens)))  # quant.py:91-92
         sel, phi_w, phi_b = self._phi_pack()
@@ -231,7 +240,8 @@ class VectorQuantizer2(VarHelpersMixin, nn.Module):
         f_hat, sq_vq, sq_commit, idx_all, hit_SV = ops.MSVQLadder.apply(f, self.embedding.weight, phi_w, phi_b,
                                                                         n_quantizers.to(f.device), cfg)
         numel = float(f.numel())
-        inv_ratio = torch.tensor([1.0 / r for r in ratio], dtype=torch.float32, device=f.device)
+        if inv_ratio is None:
+            inv_ratio = torch.tensor([1.0 / r for r in ratio], dtype=torch.float32, device=f.device)
         mean_vq_loss = (sq_vq * inv_ratio).sum() * (1.0 / numel / SN)          # :131,:134
         mean_commit_loss = (sq_commit * inv_ratio).sum() * (self.beta / numel)  # :132
         if self.training:

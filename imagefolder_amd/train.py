@@ -441,10 +441,10 @@ class CapturedStep:
     `static_imgs` first (replay(imgs) does it), torch's CUDA generator advances its Philox offset per replay (DropPath masks,
     DiffAug draws, perturbation draws differ from step to step as in eager mode), the optimizer's step counter lives on the device.
     What is FROZEN at capture time: every host-side decision — DiffAug's three branch draws (constant anyway at the reference's
-    aug_prob = 1.0), the quantizer-dropout depths of codebook_drop > 0 configs (numpy draws upstream), epoch / alpha / beta / delta,
+    aug_prob = 1.0), epoch / alpha / beta / delta (the quantizer-dropout depths of codebook_drop > 0 configs, host draws upstream,
+    move to the device generator for a captured model: VQModel.device_dropout_rng),
     learning rates, and the quantizers' `record_hit` counters, i.e. which coefficient (0.9 during the first 100 updates, then 0.99:
     xqgan_model.py:779-785) the codebook-usage EMA uses — a statistic only, but capture after the first 100 steps if it is logged.
-    capture() refuses multi-scale models with codebook_drop > 0 unless allow_frozen_host_rng=True.
     Single process only (collectives are not recorded): with world > 1 use the eager step."""
 
     def __init__(self, ts: "TokenizerTrainStep", imgs: torch.Tensor, epoch=0, alpha=0.0, beta=0.0, delta=100, warmup: int = 2,
@@ -452,9 +452,14 @@ class CapturedStep:
         if ts.reducer.active:
             raise RuntimeError("CapturedStep: the gradient all-reduce is not recorded; use TokenizerTrainStep.step with world > 1")
         multi_scale = len(getattr(ts.model, "v_patch_nums", [0])) > 1
-        if not allow_frozen_host_rng and multi_scale and float(getattr(ts.model, "codebook_drop", 0.0) or 0.0) > 0:
-            raise RuntimeError("CapturedStep: a multi-scale quantizer with codebook_drop > 0 draws its dropout depths on the host every "
-                               "step (xqgan_model.py:274 upstream); a replay would freeze them (allow_frozen_host_rng=True to accept that)")
+        if multi_scale and float(getattr(ts.model, "codebook_drop", 0.0) or 0.0) > 0:
+            # upstream draws the quantizer-dropout depths on the host every step (xqgan_model.py:274): a replay would freeze them.
+            # The model draws them from the DEVICE generator instead (same distribution, advances per replay like DropPath's masks)
+            if hasattr(ts.model, "device_dropout_rng"):
+                ts.model.device_dropout_rng = True
+            elif not allow_frozen_host_rng:
+                raise RuntimeError("CapturedStep: this multi-scale model draws its dropout depths on the host every step; a replay "
+                                   "would freeze them (allow_frozen_host_rng=True to accept that)")
         self.ts = ts
         self.static_imgs = imgs.clone()
         side = torch.cuda.Stream(device=imgs.device)

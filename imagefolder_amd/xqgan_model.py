@@ -241,6 +241,7 @@ class VQModel(nn.Module):
                 self.quantize = make_lfq(config.num_latent_tokens)
 
         self.codebook_embed_dim = config.codebook_embed_dim
+        self.device_dropout_rng = False     # True: quantizer-dropout depths from the device RNG (replay-safe), see forward()
         self.v_patch_nums = config.v_patch_nums
         self.codebook_drop = config.codebook_drop
         self.semantic_guide = config.semantic_guide
@@ -322,6 +323,10 @@ class VQModel(nn.Module):
         b, c, l, _ = h.shape
         if len(self.v_patch_nums) == 1:
             dropout_rand = None
+        elif self.device_dropout_rng and input.is_cuda:
+            # same distribution, drawn by the device generator: no host decision inside the step, so a hipGraph replay draws new
+            # depths every step (train.CapturedStep switches this on; the host draw below would be frozen at capture time)
+            dropout_rand = torch.randint(self.start_drop, len(self.v_patch_nums) + 1, (b,), device=input.device)
         else:  # host RNG like upstream (:274): fixes the dropout depth across the product quantizers
             dropout_rand = torch.randint(self.start_drop, len(self.v_patch_nums) + 1, (b,))
 

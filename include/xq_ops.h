@@ -395,6 +395,7 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_PLAIN_STORE 0x800 /* OR-ed into impl (persistent schedule): plain instead of non-temporal output stores (A/B timing) */
 #define XQ_GEMM_TWO_PHASE 0x1000 /* OR-ed into impl (persistent schedule, no fused activation): EXPERIMENTAL two-phase-per-K-tile schedule; never
                                     chosen by XQ_GEMM_AUTO; derived on paper (hazard table in csrc/xq_gemm.hip), not yet run on hardware */
+#define XQ_GEMM_ROW_MAJOR 0x2000 /* OR-ed into impl (persistent schedule): plain row-major tile order instead of the XCD-banded one (A/B timing) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2

@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--dims", type=int, nargs="*", default=[768])
     ap.add_argument("--scheds", type=str, nargs="*", default=["3"], help="impl values: 1 simple, 2 ring, 3 persistent, 0x103 = persistent with forced 256-column tiles")
     ap.add_argument("--only", default=None, choices=[None, "nt", "nn", "tn"], help="time one pass only (library + hip)")
+    ap.add_argument("--layers", nargs="*", default=None, help="subset of qkv proj fc1 fc2")
+    ap.add_argument("--no-library", action="store_true", help="skip the hipBLASLt rows (counter-collection runs)")
+    ap.add_argument("--iters", type=int, default=20)
     a = ap.parse_args()
     lines = []
 
@@ -42,18 +45,20 @@ def main():
         layers = {"qkv": (3 * D, D), "proj": (D, D), "fc1": (4 * D, D), "fc2": (D, 4 * D)}
         for M in a.rows:
             for name, (N, K) in layers.items():
+                if a.layers and name not in a.layers:
+                    continue
                 x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
                 w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
                 g = torch.randn(M, N, device="cuda").to(torch.bfloat16)
                 bias = torch.randn(N, device="cuda")
                 b16 = bias.to(torch.bfloat16)
                 fl = 2.0 * M * N * K
-                cases = [
+                cases = [] if a.no_library else [
                     ("fwd  library addmm", lambda: torch.addmm(b16, x, w.t())),
                     ("gx   library mm", lambda: torch.mm(g, w)),
                     ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
                 ]
-                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)", 0x1003: "persistent TWO-PHASE (experimental)"}.get(int(x, 0), x)) for x in a.scheds]:
+                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)", 0x1003: "persistent TWO-PHASE (experimental)", 0x2003: "persistent row-major items (old order)", 0x3003: "persistent TWO-PHASE row-major"}.get(int(x, 0), x)) for x in a.scheds]:
                     def mk(f, sched=sched):
                         def run():
                             od.GEMM_SCHEDULE = sched
@@ -72,7 +77,7 @@ def main():
                     cases = [c for c in cases if c[0].startswith(key)]
                 for label, fn in cases:
                     try:
-                        ms = timeit(fn)
+                        ms = timeit(fn, iters=a.iters)
                         emit(f"D{D} M{M} {name:5s} N{N:5d} K{K:5d} {label:44s} {ms:8.3f} ms {fl / ms / 1e9:8.1f} TF/s")
                     except Exception as e:  # noqa: BLE001
                         emit(f"D{D} M{M} {name:5s} {label:44s} FAILED: {e}")
