@@ -324,6 +324,69 @@ def gen_train_forward(name, kw, B, alpha, beta, delta, seed):
     print("wrote", name, "masks", len(masks), "vq", float(vq), "commit", float(commit), "sem", float(sem), "dep", float(dep), "usages", [round(float(u), 2) for u in usages][:3])
 
 
+# parameters whose reference gradients are recorded (sub-sampled to <= ~16k entries each): the decoder's last layer (the tensor the
+# adaptive GAN weight differentiates, xqgan_train.py:452), the 1x1 convs around the quantizer, the codebook(s), first / last
+# transformer block of encoder and decoder (qkv weight, fc1 bias, LayerScale), position / token tables, the Phi convs
+GRAD_TAPS = ["decoder.to_pixel.model.weight", "decoder.to_pixel.model.bias", "quant_conv.weight", "quant_conv.bias", "post_quant_conv.weight",
+             "quantize.embedding.weight", "quantizes.0.embedding.weight", "quantizes.1.embedding.weight",
+             "quantizes.0.quant_resi.qresi_ls.0.weight", "quantizes.1.quant_resi.qresi_ls.3.weight",
+             "encoder.model.blocks.0.attn.qkv.weight", "encoder.model.blocks.11.attn.qkv.weight", "encoder.model.blocks.0.mlp.fc1.bias",
+             "encoder.model.blocks.11.mlp.fc2.weight", "encoder.model.blocks.5.ls1.gamma", "encoder.model.pos_embed", "encoder.latent_tokens",
+             "encoder.model.patch_embed.proj.weight", "encoder.model.norm.weight",
+             "decoder.model.blocks.0.attn.qkv.weight", "decoder.model.blocks.11.attn.proj.weight", "decoder.model.blocks.11.mlp.fc1.bias",
+             "decoder.model.blocks.6.mlp.fc1.weight", "decoder.model.pos_embed", "decoder.mask_token", "decoder.lvl_embed.weight"]
+
+
+def grad_subsample(t):
+    """deterministic sub-sample of a gradient tensor: every k-th entry of the flattened tensor, k chosen for <= 16384 entries"""
+    f = t.reshape(-1)
+    k = max(1, (f.numel() + 16383) // 16384)
+    return f[::k]
+
+
+def gen_train_backward(name, fwd_name, kw, B, alpha, beta, delta, seed):
+    """One reference training backward at model level (xqgan_train.py:439-462 without the GAN / LPIPS terms, which need downloaded
+    checkpoints): loss = mse(recons, imgs) + vq + commit + entropy + semantic + dependency of VQModel.forward in train() mode,
+    .backward() through the reference's own autograd.  Same weights, images and random draws as the forward golden `fwd_name`
+    (asserted).  Recorded twice: fp32, and under torch.autocast('cpu', bfloat16) — the reference's own reduced-precision
+    backward, the yardstick for the MI355X bf16 training kernels (tests/test_train_backward_parity.py)."""
+    from oracle.det_init import det_state_dict
+    from oracle import timm_shim
+    import contextlib, io
+    R = load_reference()
+    fwd = np.load(os.path.join(OUT, fwd_name + ".npz"), allow_pickle=True)
+    out = {}
+    for tag, amp in (("f32", False), ("bf16", True)):
+        torch.manual_seed(seed)
+        m = R["VQ_models"]["VQ-16"](**dict(TRAIN_COMMON, **kw)).train()
+        m.load_state_dict(det_state_dict(m.state_dict(), seed))
+        x = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(4321 + seed)) * 2 - 1
+        timm_shim.DropPath.RECORD = []
+        torch.manual_seed(seed + 17)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), torch.autocast("cpu", dtype=torch.bfloat16, enabled=amp):
+                dec, (vq, commit, ent, usages), sem, detail, dep = m(x, 0, alpha, beta, delta)
+                loss = torch.nn.functional.mse_loss(dec.float(), x) + vq + commit + ent + sem + dep
+        finally:
+            masks = timm_shim.DropPath.RECORD
+            timm_shim.DropPath.RECORD = None
+        if not amp:      # same pass as the forward golden: identical draws -> identical output
+            assert np.array_equal(torch.stack(masks).numpy(), fwd["droppath"]), "DropPath draws differ from the forward golden"
+            assert np.abs(dec.detach()[:, :, ::4, ::4].numpy() - fwd["dec_sub"]).max() <= 1e-6
+        loss.backward()
+        params = dict(m.named_parameters())
+        out[f"loss_{tag}"] = np.float64(loss.item())
+        for n in GRAD_TAPS:
+            if n in params and params[n].grad is not None:
+                g = params[n].grad.detach().float()
+                out[f"{tag}:{n}"] = grad_subsample(g).numpy().copy()
+                out[f"{tag}:{n}:l2"] = np.float64(g.double().square().sum().sqrt())
+        print(name, tag, "loss", loss.item(), "taps", sum(1 for k in out if k.startswith(tag + ":") and not k.endswith(":l2")))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), fwd_name=np.array(fwd_name), taps=np.array([n for n in GRAD_TAPS if f"f32:{n}" in out]),
+                        meta=np.array(str(meta())), **out)
+    print("wrote", name)
+
+
 def gen_model_bf16(name, kw, seed):
     """the same image through the reference under torch.autocast('cpu', bfloat16): what the reference's own reduced-precision
     path does to reconstructions and indices — the yardstick for the MI355X bf16 kernels (tests/test_model_parity.py)."""
@@ -380,6 +443,10 @@ def main():
     if only == "train":
         for i, (nm, (kw, B, al, be, de)) in enumerate(TRAIN_CASES.items()):
             gen_train_forward(nm, kw, B, al, be, de, seed=60 + i)
+        return
+    if only == "trainbwd":
+        for i, (nm, (kw, B, al, be, de)) in enumerate(TRAIN_CASES.items()):
+            gen_train_backward(nm.replace("train_fwd_", "train_bwd_"), nm, kw, B, al, be, de, seed=60 + i)
         return
     if only == "bf16":
         gen_model_bf16("model_cfg1_cnn_vq4096", dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], enc_type="cnn",

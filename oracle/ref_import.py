@@ -77,3 +77,21 @@ def load_reference():
     if saved_datasets is not None:
         sys.modules["datasets"] = saved_datasets
     return _loaded
+
+
+def load_reference_evaluator():
+    """The reference's evaluator.py (ADM FID evaluator) imported unmodified with its absent heavy dependencies stubbed
+    (tensorflow, requests, tqdm are only touched by the Inception-graph code paths): gives the real `FIDStatistics.frechet_distance`
+    (evaluator.py:72-115) and `Evaluator.compute_statistics` (:186-189) to pin imagefolder_amd.rfid against."""
+    if "evaluator" in _loaded:
+        return _loaded["evaluator"]
+    if not reference_available():
+        raise RuntimeError("reference tree not present at %s" % REF_ROOT)
+    for m in ["tensorflow", "tensorflow.compat", "tensorflow.compat.v1", "requests"]:
+        if m not in sys.modules:
+            sys.modules[m] = MagicMock()
+    spec = importlib.util.spec_from_file_location("ref_evaluator", os.path.join(REF_ROOT, "evaluator.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    _loaded["evaluator"] = mod
+    return mod

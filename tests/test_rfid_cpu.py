@@ -74,3 +74,35 @@ def test_rfid_two_ranks_equal_single_process():
     mp.spawn(_worker, args=(2, 29577, out), nprocs=2, join=True)
     assert abs(out[0] - out[1]) <= 1e-12
     assert abs(out[0] - out["single"]) <= 1e-9 * max(1.0, abs(out["single"]))
+
+
+def test_frechet_distance_and_statistics_against_the_reference_functions_themselves():
+    """evaluator.py imported unmodified (tensorflow / requests stubbed: only its Inception-graph code touches them):
+    rfid.frechet_distance == FIDStatistics.frechet_distance (evaluator.py:72-115) and FeatureStats.finalize == Evaluator.compute_statistics
+    (:186-189), including the singular-product branch (fewer samples than dimensions -> the eps fallback / real part)."""
+    import pytest
+    from oracle.ref_import import reference_available, load_reference_evaluator
+    if not reference_available():
+        pytest.skip("reference tree not present (GPU box)")
+    ev = load_reference_evaluator()
+    rng = np.random.default_rng(7)
+    for n1, n2, d in [(500, 450, 32), (64, 64, 48), (20, 24, 40)]:          # the last: rank-deficient covariances
+        a, b = rng.normal(size=(n1, d)) * 2.0 + 0.5, rng.normal(size=(n2, d)) * 1.7
+        compute_statistics = ev.Evaluator.compute_statistics                  # uses no instance state
+        sa, sb = compute_statistics(None, a), compute_statistics(None, b)
+        want = sa.frechet_distance(sb)
+        fa, fb = rfid.FeatureStats(d), rfid.FeatureStats(d)
+        for chunk in np.array_split(a, 5):
+            fa.update(torch.from_numpy(chunk))
+        for chunk in np.array_split(b, 3):
+            fb.update(torch.from_numpy(chunk))
+        (m1, s1), (m2, s2) = fa.finalize(), fb.finalize()
+        np.testing.assert_allclose(m1.numpy(), sa.mu, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(s1.numpy(), sa.sigma, rtol=1e-9, atol=1e-10)
+        got = rfid.frechet_distance(m1.numpy(), s1.numpy(), m2.numpy(), s2.numpy())
+        assert abs(got - want) <= 1e-7 * max(1.0, abs(want)), (got, want)
+        # the statement itself on the reference's own statistics: bit-for-bit the same arithmetic
+        assert rfid.frechet_distance(sa.mu, sa.sigma, sb.mu, sb.sigma) == want
+        if n1 > d:
+            dev = rfid.frechet_distance_device(m1, s1, m2, s2).item()
+            assert abs(dev - want) <= 1e-6 * max(1.0, abs(want))

@@ -76,3 +76,62 @@ def test_rfid_of_gpu_reconstructions_equals_reference_cpu_path():
     assert abs(fid_gpu_dev - fid_gpu) <= 1e-6 * max(1.0, fid_gpu)
     if flips == 0:
         assert worst <= 1e-4
+
+
+KW_VITB = dict(codebook_size=8192, codebook_embed_dim=32, v_patch_nums=[16], enc_type="dinov2", dec_type="dinov2", semantic_guide="none",
+               detail_guide="none", num_latent_tokens=256, product_quant=1, abs_pos_embed=True,
+               encoder_model="vit_base_patch14_dinov2.lvd142m", decoder_model="vit_base_patch14_dinov2.lvd142m")
+
+
+def test_rfid_parity_at_the_named_geometry_vitb_256():
+    """The geometry north_star names: the ViT-B tokenizer (VQ-8192.yaml: DINOv2 ViT-B encoder + decoder, V = 8192, C = 32) on
+    256 x 256 images (xqgan_train.py:516-567 evaluates exactly img_to_reconstructed_img on the validation images).
+    Reference CPU path = the host mirror in fp32 (the reference's classes on the host, tests/test_model_parity.py) + the C oracle's
+    nearest code; MI355X = img_to_reconstructed_img (i) in fp32 on the hand-written exact-fp32 kernels, (ii) under bf16 autocast on
+    the training kernels (how the in-loop evaluation runs inside the bf16 train job).  |rFID - rFID_reference| <= 0.02 for both."""
+    from imagefolder_amd import rfid
+    from imagefolder_amd.xqgan_model import VQ_models
+    torch.manual_seed(0)
+    m_cpu = VQ_models["VQ-16"](**KW_VITB).eval()
+    m_cpu.load_state_dict(det_state_dict(m_cpu.state_dict(), 32))
+    m_gpu = VQ_models["VQ-16"](**KW_VITB).eval()
+    m_gpu.load_state_dict(m_cpu.state_dict())
+    m_gpu = m_gpu.cuda()
+    D = 24
+    feat_cpu, feat_gpu = StandInFeatures(D), StandInFeatures(D).cuda()
+    E = m_cpu.quantize.embedding.weight.detach().numpy()
+    g = torch.Generator().manual_seed(8765)
+    N, bs = 48, 8
+    ev_cpu = rfid.ReconstructionFID(feat_cpu, D)
+    ev_f32 = rfid.ReconstructionFID(feat_gpu, D, device="cuda")
+    ev_b16 = rfid.ReconstructionFID(feat_gpu, D, device="cuda")
+    worst32 = worst16 = 0.0
+    flips32 = flips16 = 0
+    with torch.no_grad():
+        for _ in range(N // bs):
+            # ImageNet-shaped synthetic batch: a smooth low-frequency field plus texture, in [-1, 1]
+            low = torch.nn.functional.interpolate(torch.rand(bs, 3, 8, 8, generator=g) * 2 - 1, size=(256, 256), mode="bicubic")
+            x = (0.8 * low + 0.2 * (torch.rand(bs, 3, 256, 256, generator=g) * 2 - 1)).clamp(-1, 1)
+            f = m_cpu.encode(x)
+            idx, _ = xq_oracle.assign(f.numpy(), E, xq_oracle.MODE_L2_NORMED)
+            zq, _, _ = xq_oracle.vq_finish(f.numpy(), E, idx, normed=True, ste=False, want_hist=False)
+            rec_cpu = m_cpu.decode(torch.from_numpy(zq)).clamp_(-1, 1)
+            xg = x.cuda()
+            rec32 = m_gpu.img_to_reconstructed_img(xg)
+            flips32 += int((m_gpu.img_to_idx(xg)[0][0].cpu().numpy().reshape(-1) != idx).sum())
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                rec16 = m_gpu.img_to_reconstructed_img(xg).float()
+                flips16 += int((m_gpu.img_to_idx(xg)[0][0].cpu().numpy().reshape(-1) != idx).sum())
+            worst32 = max(worst32, (rec32.cpu() - rec_cpu).abs().max().item())
+            worst16 = max(worst16, (rec16.cpu() - rec_cpu).abs().max().item())
+            ev_cpu.update(x, rec_cpu)
+            ev_f32.update(xg, rec32)
+            ev_b16.update(xg, rec16)
+    fid_cpu, fid32, fid16 = ev_cpu.compute(), ev_f32.compute(), ev_b16.compute()
+    print(f"ViT-B 256x256, {N} images: rFID reference-CPU path {fid_cpu:.6f} | MI355X fp32 {fid32:.6f} (max |pixel diff| {worst32:.2e}, "
+          f"code flips {flips32} of {N * 256}) | MI355X bf16 autocast {fid16:.6f} (max |pixel diff| {worst16:.2e}, flips {flips16})")
+    assert fid_cpu > 1e-3
+    assert abs(fid32 - fid_cpu) <= 0.02
+    assert abs(fid16 - fid_cpu) <= 0.02
+    if flips32 == 0:
+        assert worst32 <= 1e-4

@@ -1,0 +1,144 @@
+"""M1 / T1 backward: one training backward of VQModel at model level against the REFERENCE's autograd (xqgan_train.py:439-462,
+xqgan_model.py:268-365), BASELINE configs 2-5 (ViT-B, P = 1 / 2, single scale / 10-scale ladder, quantizer dropout, latent
+perturbation, semantic branch).
+
+Goldens (oracle/make_golden.py gen_train_backward, tests/golden/train_bwd_*.npz): the unmodified reference model on the host,
+deterministic weights, every random draw recorded; loss = mse(recons, imgs) + vq + commit + entropy + semantic + dependency (the
+LPIPS / GAN terms need downloaded checkpoints); gradients of ~25 parameter tensors spread over the whole model (decoder last layer,
+1x1 convs around the quantizer, codebooks, Phi convs, first / last transformer blocks, position / token tables), sub-sampled, each
+recorded twice — fp32, and under torch.autocast('cpu', bfloat16): the reference's own reduced-precision backward.
+
+Checked here on the MI355X:
+  (a) fp32 step (HIP quantizers + perturbation with their hand-written backward, fp32 dense path): every tapped gradient within
+      REL_F32 of the reference's fp32 gradient (relative L2 over the sub-sample);
+  (b) the bf16 TRAINING path (hand-written bf16 MFMA GEMMs fwd / dgrad / wgrad, attention fwd / bwd, fused row kernels, quantizer
+      backward): its distance to the reference's fp32 gradient is bounded by the distance of the reference's OWN bf16-autocast
+      backward to it (x SLACK + FLOOR) — tensor by tensor;
+  (c) cfg 2: the parameters after ONE fused AdamW step (xq_adamw_ema_step) equal torch.optim.AdamW applied to the reference's
+      gradient (first Adam step: p - lr g / (|g| + eps)), which closes the train step T1 end to end.
+A token on an fp32 near-tie may pick another code than the reference's ATen build (the forward test allows 3 % of the pixels for
+that); such a flip changes the gradient of a few codebook rows — the bounds below are on whole-tensor relative L2 and absorb it."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle.det_init import det_state_dict
+from test_train_forward_parity import CASES, COMMON
+
+pytestmark = pytest.mark.gpu
+
+REL_F32 = 2e-3          # (a): fp32 path vs reference fp32 (ATen CPU sums in another order; near-tie flips)
+SLACK, FLOOR = 1.5, 3e-3   # (b): err_ours <= SLACK * err_reference_bf16 + FLOOR
+
+
+def _sub(t):
+    f = t.reshape(-1)
+    k = max(1, (f.numel() + 16383) // 16384)
+    return f[::k]
+
+
+def _rel(a, b):
+    return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
+
+
+def _run(name, amp_dtype, monkeypatch, lr=1e-4):
+    """one TokenizerTrainStep.step of the mirror with the reference's draws replayed; returns ({param: grad}, {param: value after the step})"""
+    from imagefolder_amd import latent_perturbation, xqgan_model
+    from imagefolder_amd.dino_enc.vision_transformer import DropPath
+    from imagefolder_amd.train import TokenizerTrainStep
+    fwd_name = name.replace("train_bwd_", "train_fwd_")
+    g = load_golden(fwd_name)
+    seed, B = int(g["seed"]), int(g["B"])
+    torch.manual_seed(seed)
+    m = xqgan_model.VQ_models["VQ-16"](**dict(COMMON, **CASES[fwd_name])).train()
+    m.load_state_dict(det_state_dict(m.state_dict(), seed))
+    m = m.cuda()
+    x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(4321 + seed)) * 2 - 1).cuda()
+    DropPath.REPLAY = [torch.from_numpy(r) for r in g["droppath"]]
+    real_randint = torch.randint
+
+    def randint(*a, **k):
+        if len(g["dropout_rand"]) and len(a) >= 3 and tuple(a[2]) == (B,):
+            return torch.from_numpy(g["dropout_rand"]).clone()
+        return real_randint(*a, **k)
+    monkeypatch.setattr(torch, "randint", randint)
+    if len(g["lp_prob"]):
+        alpha = float(g["alpha"])
+        prob, ridx = torch.from_numpy(g["lp_prob"]), torch.from_numpy(g["lp_idx"])
+        rank = torch.where(prob > alpha, torch.zeros_like(ridx), ridx)
+
+        def draw(n_tokens, a_, delta_, device):
+            return rank.to(device)
+        monkeypatch.setattr(latent_perturbation, "draw_ranks", draw)
+
+    def gen_loss(out, imgs):
+        recons, (vq, commit, entropy, usages), sem, detail, dep = out
+        return torch.nn.functional.mse_loss(recons.float(), imgs) + vq + commit + entropy + sem + dep
+    ts = TokenizerTrainStep(m, gen_loss, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8, use_ema=False, amp_dtype=amp_dtype)
+    names = [n for n, p in m.named_parameters() if p.requires_grad]
+    grads = {}
+    opt_step = ts.opt.step
+
+    def recording_step():
+        for n, p, o in zip(names, ts.arena.params, ts.arena.offsets):
+            grads[n] = ts.arena.g[o:o + p.numel()].clone()
+        opt_step()
+    ts.opt.step = recording_step
+    try:
+        loss = ts.step(x, 0, float(g["alpha"]), float(g["beta"]), int(g["delta"]))
+        torch.cuda.synchronize()
+        assert DropPath.REPLAY == [], f"{len(DropPath.REPLAY)} recorded DropPath masks were not consumed"
+    finally:
+        DropPath.REPLAY = None
+    after = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    return float(loss), grads, after, seed
+
+
+@pytest.mark.parametrize("name", ["train_bwd_cfg2_vq8192", "train_bwd_cfg3_vp2_16384", "train_bwd_cfg4_msvr10p2_4096", "train_bwd_cfg5_robusttok"])
+def test_model_level_gradients_match_the_reference_autograd(name, monkeypatch):
+    gb = load_golden(name)
+    taps = [str(t) for t in gb["taps"]]
+    assert len(taps) >= 20
+    # ---- (a) fp32 ----
+    lr = 1e-4
+    loss32, g32, after32, seed = _run(name, None, monkeypatch, lr=lr)
+    np.testing.assert_allclose(loss32, float(gb["loss_f32"]), rtol=2e-4)
+    rows = []
+    for n in taps:
+        ref = gb[f"f32:{n}"]
+        got = _sub(g32[n]).float().cpu().numpy()
+        rows.append((n, _rel(got, ref), float(gb[f"f32:{n}:l2"])))
+    # ---- (b) bf16 training kernels ----
+    loss16, g16, _, _ = _run(name, torch.bfloat16, monkeypatch, lr=lr)
+    rows16 = []
+    for n in taps:
+        ref32, ref16 = gb[f"f32:{n}"], gb[f"bf16:{n}"]
+        got = _sub(g16[n]).float().cpu().numpy()
+        rows16.append((n, _rel(got, ref32), _rel(ref16, ref32)))
+    print(f"\n{name}: loss fp32 {loss32:.6f} (ref {float(gb['loss_f32']):.6f}), bf16 {loss16:.6f} (ref bf16 {float(gb['loss_bf16']):.6f})")
+    for (n, e32, l2), (_, e16, r16) in zip(rows, rows16):
+        print(f"  {n:48s} |g| {l2:9.3e}  fp32 rel {e32:8.2e}   bf16 rel {e16:8.2e}  (reference's own bf16: {r16:8.2e})")
+    bad32 = [(n, e) for n, e, _ in rows if e > REL_F32]
+    assert not bad32, f"fp32 gradients off the reference: {bad32}"
+    bad16 = [(n, e, r) for n, e, r in rows16 if e > SLACK * r + FLOOR]
+    assert not bad16, f"bf16 gradients further from the reference's fp32 gradient than its own bf16 backward allows: {bad16}"
+    assert abs(loss16 - float(gb["loss_f32"])) <= SLACK * abs(float(gb["loss_bf16"]) - float(gb["loss_f32"])) + 2e-3 * abs(float(gb["loss_f32"]))
+    # ---- (c) one AdamW step on the reference gradient (cfg 2 closes T1) ----
+    if name == "train_bwd_cfg2_vq8192":
+        from imagefolder_amd import xqgan_model
+        torch.manual_seed(seed)
+        p0 = det_state_dict(xqgan_model.VQ_models["VQ-16"](**dict(COMMON, **CASES["train_fwd_cfg2_vq8192"])).state_dict(), seed)
+        checked = 0
+        for n in taps:
+            ref = gb[f"f32:{n}"].astype(np.float64)
+            start = _sub(p0[n]).double().numpy()
+            want = start - lr * ref / (np.abs(ref) + 1e-8)             # first AdamW step, weight_decay 0: m_hat = g, v_hat = g^2
+            got = _sub(after32[n]).double().cpu().numpy()
+            solid = np.abs(ref) > 1e-3 * np.abs(ref).max()             # entries whose sign is not rounding noise
+            if solid.sum() < 16:
+                continue
+            ok = np.abs(got - want)[solid] <= 0.02 * lr
+            assert ok.mean() >= 0.995, (n, float(ok.mean()))
+            checked += 1
+        assert checked >= 15
