@@ -73,8 +73,11 @@ struct GemmArgs {
     int nt_store;           // non-temporal bf16 output stores (default; XQ_GEMM_PLAIN_STORE turns them off): the 128 KiB a CU
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
-    int two_phase;          // XQ_GEMM_TWO_PHASE: experimental 2-phase-per-K-tile schedule of the persistent kernel (opt-in, untested on hardware)
-    int row_major_debug;    // XQ_GEMM_ROW_MAJOR: plain row-major whole-tile items (A/B timing of the XCD-banded order below)
+    int four_phase;         // XQ_GEMM_FOUR_PHASE: the round-2 schedule of the persistent kernel (4 phases of 8 MFMAs per K tile) instead of
+                            // the default 2 phases of 16 (A/B timing; profiles/r03_gemm_schedules.txt: two phases +15..19 % on the weight
+                            // gradient, +3..6 % on the data gradient, +0..8 % forward)
+    int banded;             // XQ_GEMM_BANDED: XCD-banded whole-tile order (below) instead of row-major — opt-in: it cuts the fabric traffic
+                            // but measured 4 - 10 % SLOWER on the forward products (profiles/r03_gemm_schedules.txt), so it is not the default
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
     // XCD-banded tile order of the persistent schedule's whole-tile items (NT / NN / implicit-GEMM conv).  The tile grid is cut
     // into column GROUPS of grp_c column tiles; the tile sequence runs group by group, row-major inside a group; XCD x (workgroups
@@ -83,7 +86,7 @@ struct GemmArgs {
     // XCD instead of once per round, and successive rounds move DOWN the rows of one group instead of jumping 256 tiles ahead
     // (row-major order made every XCD stream the whole weight matrix every round: 4 - 6x re-fetch of it through the fabric,
     // profiles/r02_kernel_hbm_traffic_shapes.json).  band_full = the items under this mapping (a multiple of the grid size; the
-    // last partial round and the K-split tail keep sequence position = item index); grp_c = 0: plain row-major (XQ_GEMM_ROW_MAJOR).
+    // last partial round and the K-split tail keep sequence position = item index); grp_c = 0: plain row-major (the default).
     int grp_c;
     long band_full;
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
@@ -690,9 +693,10 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         GR_BARRIER();                                                         \
         r_par ^= 1;                                                           \
     } while (0)
-    // EXPERIMENTAL (PH = 2, impl bit XQ_GEMM_TWO_PHASE; never selected by XQ_GEMM_AUTO, not yet run on hardware): the same stream
-    // regrouped into two phases of 16 MFMAs per K tile — half the barriers, and the 16 + 8 fragment reads of a phase get 512 instead
-    // of 256 matrix-pipe cycles of the other wave row to land under.  Hazards re-derived for two pieces per phase:
+    // PH = 2 (the default since round 3; PH = 4 above stays behind XQ_GEMM_FOUR_PHASE): the same stream regrouped into two phases of
+    // 16 MFMAs per K tile — half the barriers, and the 16 + 8 fragment reads of a phase get 512 instead of 256 matrix-pipe cycles of
+    // the other wave row to land under.  Bit-identical results (same MFMA order per accumulator; tests/test_gemm_gpu.py race screen).
+    // Hazards for two pieces per phase (HW barrier numbering: wave row 1 runs one barrier interval behind row 0):
     //   RAW  phase A reads pieces (t,1) (t,2) (t,0): in flight after phase B(t-1) staged (t+1,0) (t+1,1) are, oldest first,
     //        (t,0..3) (t+1,0) (t+1,1) = 12 instructions -> vmcnt(6) there retires (t,0) (t,1) (t,2);  phase B reads (t,3): in flight
     //        after phase A(t) staged (t+1,2) (t+1,3) are (t,3) (t+1,0..3) = 10 -> vmcnt(8) retires (t,3);  prologue: vmcnt(6)
@@ -1046,7 +1050,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         g.slabs = (float *)ws;
         const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
         const long grid = items < num_cus() ? items : num_cus();
-        if (EPI == EPI_BF16 && !g.row_major_debug && grid % 8 == 0 && pl.main_items >= grid) {
+        if (EPI == EPI_BF16 && g.banded && grid % 8 == 0 && pl.main_items >= grid) {
             g.grp_c = plan_band(g.tiles_m, g.tiles_n, (long)g.kt_full * gm::BKT);
             g.band_full = (pl.main_items / grid) * grid;
         } else {
@@ -1054,12 +1058,12 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
             g.band_full = 0;
         }
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
-        if (g.two_phase && ACT == ACT_NONE) {      // experimental schedule, explicit opt-in only
-            if (set_lds<gemm_pring_kernel<AK, BK, ACT_NONE, 2>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT_NONE, 2>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+        if (!g.four_phase) {      // default: two phases of 16 MFMAs per K tile
+            if (set_lds<gemm_pring_kernel<AK, BK, ACT, 2>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 2>), dim3((unsigned)grid), dim3(GT), lds, s, g);
         } else {
-            if (set_lds<gemm_pring_kernel<AK, BK, ACT>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+            if (set_lds<gemm_pring_kernel<AK, BK, ACT, 4>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 4>), dim3((unsigned)grid), dim3(GT), lds, s, g);
         }
         if (EPI == EPI_BF16 && pl.tail_tiles)
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
@@ -1123,8 +1127,8 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     GemmArgs g{};
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
-    g.row_major_debug = (impl & XQ_GEMM_ROW_MAJOR) ? 1 : 0;
+    g.four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
+    g.banded = (impl & XQ_GEMM_BANDED) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1142,8 +1146,8 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
-    g.row_major_debug = (impl & XQ_GEMM_ROW_MAJOR) ? 1 : 0;
+    g.four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
+    g.banded = (impl & XQ_GEMM_BANDED) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1162,7 +1166,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     hipStream_t s = (hipStream_t)stream;
     const int BN = pick_bn(Q, impl);
     const int tile_major_debug = (impl & XQ_GEMM_TILE_MAJOR) ? 1 : 0;
-    const int two_phase = (impl & XQ_GEMM_TWO_PHASE) ? 1 : 0;
+    const int four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
     impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
@@ -1178,7 +1182,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
         if (impl == XQ_GEMM_AUTO) impl = BN == 256 ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
         compact = impl == XQ_GEMM_PERSISTENT;
         g.tile_major_debug = tile_major_debug;
-        g.two_phase = two_phase;
+        g.four_phase = four_phase;
         if (!compact && (ws_bytes < (size_t)splits * P * Q * 4 || !ws)) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
         const int rc = launch_gemm<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, ws, ws_bytes, s, fn, 2.0 * P * Q * (double)(kt_all * 64));
         if (rc) return rc;
@@ -1245,10 +1249,11 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     if ((long)B * Hi * Wi >= 0x7fffffffL || Ho > 32767 || Wo > 32767) return xq_set_error(XQ_EINVAL, "%s: image too large for 32-bit pixel indices", fn);
     const long M = (long)B * Ho * Wo, K = 9L * Cin;
     const int BN = pick_bn(Cout, impl);
-    const int row_major_debug = (impl & XQ_GEMM_ROW_MAJOR) ? 1 : 0;
+    const int banded = (impl & XQ_GEMM_BANDED) ? 1 : 0, four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
     impl &= 0xff;
     GemmArgs g{};
-    g.row_major_debug = row_major_debug;
+    g.banded = banded;
+    g.four_phase = four_phase;
     g.nt_store = 1;
     g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;
     g.M = M; g.N = Cout; g.lda = K; g.ldb = K; g.ldc = Cout;

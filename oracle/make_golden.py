@@ -255,6 +255,42 @@ def gen_model(name, kw, seed):
     print("wrote", name, "rec range", float(rec.min()), float(rec.max()), "distinct codes", len(set(idx.tolist())))
 
 
+def gen_tokens(name, kw, B, seed):
+    """Code indices of a product-quantizer / multi-scale tokenizer as the REFERENCE emits them at inference
+    (xqgan_model.py:386-394: f.chunk(P, dim=2) -> quantizes[i].f_to_idxBl_or_fhat(f_i, to_fhat=False, v_patch_nums)): per branch
+    the latent f_i and the list of per-scale index maps, plus the flat token rows in the layout of imagefolder_amd.tokenize
+    (branch p: its scales in order, ids offset by p * codebook_size — the shared vocabulary of P * V ids, configs/VP2-16384.yaml)."""
+    from oracle.det_init import det_state_dict
+    R = load_reference()
+    torch.manual_seed(seed)
+    m = R["VQ_models"]["VQ-16"](**kw).eval()
+    m.load_state_dict(det_state_dict(m.state_dict(), seed))
+    x = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(1234 + seed)) * 2 - 1
+    P, V = kw["product_quant"], kw["codebook_size"]
+    multi = len(kw["v_patch_nums"]) > 1
+    out = {}
+    with torch.no_grad():
+        h = m.encoder(x)
+        b, l, c = h.shape
+        h = h.view(b, l, 1, c).permute(0, 3, 1, 2)                       # xqgan_model.py:246-249 (product_quant > 1)
+        f = m.quant_conv(h)
+        side = int((f.shape[2] // P) ** 0.5)
+        rows = []
+        for i, fi in enumerate(f.chunk(chunks=P, dim=2)):
+            fi = fi.reshape(b, -1, side, side)
+            ids = m.quantizes[i].f_to_idxBl_or_fhat(fi, to_fhat=False, v_patch_nums=kw["v_patch_nums"] if multi else None)
+            out[f"f{i}"] = fi.numpy()
+            for si, t in enumerate(ids):
+                out[f"idx{i}_{si}"] = t.reshape(b, -1).numpy()
+                rows.append(t.reshape(b, -1).long() + i * V)
+        rec = m.img_to_reconstructed_img(x)
+    tokens = torch.cat(rows, dim=1).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x_seed=np.int32(1234 + seed), B=np.int32(B), seed=np.int32(seed), tokens=tokens,
+                        rec_sub=rec[:, :, ::4, ::4].contiguous().numpy(), n_scales=np.int32(len(kw["v_patch_nums"])),
+                        meta=np.array(str(meta())), **out)
+    print("wrote", name, "tokens", tokens.shape, "distinct", len(np.unique(tokens)))
+
+
 TRAIN_COMMON = dict(enc_type="dinov2", dec_type="dinov2", semantic_guide="dinov2", detail_guide="none", abs_pos_embed=True,
                     encoder_model="vit_base_patch14_dinov2.lvd142m", decoder_model="vit_base_patch14_dinov2.lvd142m",
                     share_quant_resi=4, start_drop=3, sem_loss_weight=0.1, guide_type_1="class")
@@ -443,6 +479,15 @@ def main():
     if only == "train":
         for i, (nm, (kw, B, al, be, de)) in enumerate(TRAIN_CASES.items()):
             gen_train_forward(nm, kw, B, al, be, de, seed=60 + i)
+        return
+    if only == "tokens":
+        base = dict(enc_type="dinov2", dec_type="dinov2", semantic_guide="none", detail_guide="none", abs_pos_embed=True,
+                    encoder_model="vit_base_patch14_dinov2.lvd142m", decoder_model="vit_base_patch14_dinov2.lvd142m", share_quant_resi=4)
+        # BASELINE config 3 (VP2-16384: two single-scale quantizers) and config 4 (MSVR10P2-4096: two 10-scale ladders)
+        gen_tokens("tokens_cfg3_vp2_16384", dict(base, codebook_size=16384, codebook_embed_dim=32, v_patch_nums=[16], num_latent_tokens=256,
+                                                 product_quant=2, half_sem=True), 2, seed=70)
+        gen_tokens("tokens_cfg4_msvr10p2_4096", dict(base, codebook_size=4096, codebook_embed_dim=32, v_patch_nums=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11],
+                                                     num_latent_tokens=121, product_quant=2, half_sem=True), 2, seed=71)
         return
     if only == "trainbwd":
         for i, (nm, (kw, B, al, be, de)) in enumerate(TRAIN_CASES.items()):

@@ -11,6 +11,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 SIMPLE, RING, PERSISTENT = 1, 2, 3
+FOUR_PHASE, BANDED = PERSISTENT | 0x4000, PERSISTENT | 0x2000      # include/xq_ops.h XQ_GEMM_FOUR_PHASE / XQ_GEMM_BANDED
 
 
 def _ops():
@@ -38,7 +39,7 @@ NT_SHAPES = [(256, 256, 128), (300, 256, 128), (1, 256, 64), (513, 768, 768), (2
              (22300, 768, 768), (22272, 768, 256), (51400, 768, 128)]
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT, FOUR_PHASE, BANDED])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_gemm_nt(M, N, K, impl):
     od = _ops()
@@ -58,7 +59,7 @@ def test_gemm_nt(M, N, K, impl):
     _check_bf16(y, ref + bias, absprod + bias.abs())
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT, FOUR_PHASE, BANDED])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_gemm_nn(M, N, K, impl):
     """g_x[M][N] = g[M][K] @ W[K][N] (W = forward weight [out = K][in = N])"""
@@ -79,7 +80,7 @@ TN_SHAPES = [(256, 256, 256), (2052, 2304, 768), (2052, 768, 768), (2056, 768, 3
              (788, 384, 1536), (788, 1152, 384), (4104, 768, 768), (640, 200, 192), (0, 64, 64)]
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT, FOUR_PHASE])
 @pytest.mark.parametrize("R,P,Q", TN_SHAPES)
 def test_gemm_tn(R, P, Q, impl):
     od = _ops()
@@ -132,6 +133,38 @@ def test_gemm_ring_equals_simple_and_is_repeatable(op):
         assert torch.equal(o, outs_p[0])
     scale = base.float().abs().max().item()
     assert (outs_p[0].float() - base.float()).abs().max().item() <= 2.0 ** -7 * scale
+
+
+@pytest.mark.parametrize("op", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K", [(22300, 768, 768), (65664, 2304, 768), (65664, 768, 3072)])
+def test_two_phase_schedule_is_bit_identical_to_the_four_phase_one(op, M, N, K):
+    """Race screen of the default (two phases of 16 MFMAs per K tile) persistent schedule: the same work items, the same MFMA order
+    per accumulator as the round-2 four-phase schedule -> every output BIT-identical, over 24 back-to-back launches on a busy chip
+    and on the bench shapes (an LDS piece read before its DMA landed, or restaged before its last read returned, shows up as a
+    wrong tile that comes and goes).  The XCD-banded order walks the same items in another order: bit-identical too."""
+    od = _ops()
+    if op == "tn":
+        a, b = _rand((M, N), 7), _rand((M, K), 8)
+        run = lambda: od.gemm_tn(a, b)
+    elif op == "nn":
+        a, b = _rand((M, K), 7), _rand((K, N), 8, 0.05)
+        run = lambda: od.gemm_nn(a, b)
+    else:
+        a, b = _rand((M, K), 7), _rand((N, K), 8, 0.05)
+        bias = torch.randn(N, device="cuda")
+        run = lambda: od.gemm_nt(a, b, bias)
+    try:
+        od.GEMM_SCHEDULE = FOUR_PHASE
+        base = run()
+        od.GEMM_SCHEDULE = PERSISTENT
+        outs = [run() for _ in range(24)]
+        od.GEMM_SCHEDULE = BANDED
+        outs_b = [run() for _ in range(4)] if op != "tn" else []
+    finally:
+        od.GEMM_SCHEDULE = 0
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs + outs_b):
+        assert torch.equal(o, base), f"launch {i} differs from the four-phase result in {(o != base).sum().item()} entries"
 
 
 def test_linear_fn_matches_library_autograd():

@@ -95,3 +95,61 @@ def test_tokens_equal_reference_indices_on_model_goldens(oracle, name, tmp_path)
     E = m.quantize.embedding.weight.detach().cpu().numpy()
     par = oracle.index_parity(g["f"], E, oracle.MODE_L2_NORMED, t0.numpy(), g["idx"], tol=2e-4)
     assert par["match_rate"] >= 0.98 and par["all_ties"], par                     # same contract as test_model_parity
+
+
+TOKEN_CASES = {
+    "tokens_cfg3_vp2_16384": dict(codebook_size=16384, codebook_embed_dim=32, v_patch_nums=[16], num_latent_tokens=256, product_quant=2, half_sem=True),
+    "tokens_cfg4_msvr10p2_4096": dict(codebook_size=4096, codebook_embed_dim=32, v_patch_nums=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11], num_latent_tokens=121,
+                                      product_quant=2, half_sem=True),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(TOKEN_CASES))
+def test_product_and_multiscale_tokens_equal_the_reference_indices(oracle, name):
+    """f2 depth: the token rows of BASELINE config 3 (VP2-16384: P = 2 single-scale quantizers) and config 4 (MSVR10P2-4096: P = 2
+    ten-scale ladders) against what the reference emits (xqgan_model.py:386-394 -> f_to_idxBl_or_fhat(to_fhat=False)), ViT-B
+    tokenizer with deterministic weights, 256 x 256 images (oracle/make_golden.py gen_tokens).
+      (i)  the HIP quantizers on the REFERENCE latents: every index of every branch and scale identical;
+      (ii) images -> tokens end to end on the MI355X fp32 path, in the row layout of tokenize.tokens_from_images (branch p offset by
+           p * V): rows agree except where the encoder's fp32 rounding flips a near-tie (a ladder flip re-routes the later scales of
+           that sample's branch, so the bound is per row)."""
+    from conftest import load_golden
+    from oracle.det_init import det_state_dict
+    from imagefolder_amd.xqgan_model import VQ_models
+    g = load_golden(name)
+    kw = dict(enc_type="dinov2", dec_type="dinov2", semantic_guide="none", detail_guide="none", abs_pos_embed=True,
+              encoder_model="vit_base_patch14_dinov2.lvd142m", decoder_model="vit_base_patch14_dinov2.lvd142m", share_quant_resi=4,
+              **TOKEN_CASES[name])
+    seed, B = int(g["seed"]), int(g["B"])
+    torch.manual_seed(seed)
+    m = VQ_models["VQ-16"](**kw).eval()
+    m.load_state_dict(det_state_dict(m.state_dict(), seed))
+    m = m.cuda()
+    P, V, SN = kw["product_quant"], kw["codebook_size"], int(g["n_scales"])
+    multi = SN > 1
+    # (i) quantizers alone, on the reference's latents
+    rows = []
+    with torch.no_grad():
+        for p in range(P):
+            f = torch.from_numpy(g[f"f{p}"]).cuda()
+            ids = m.quantizes[p].f_to_idxBl_or_fhat(f, to_fhat=False, v_patch_nums=kw["v_patch_nums"] if multi else None)
+            assert len(ids) == SN
+            for si, t in enumerate(ids):
+                got = t.reshape(B, -1).cpu().numpy()
+                want = g[f"idx{p}_{si}"]
+                if not np.array_equal(got, want):      # only an fp64-verified tie may differ (single-scale: checkable directly)
+                    assert not multi, f"branch {p} scale {si}: {(got != want).sum()} ladder indices differ from the reference"
+                    E = m.quantizes[p].embedding.weight.detach().cpu().numpy()
+                    par = oracle.index_parity(g[f"f{p}"], E, oracle.MODE_L2_NORMED, got.reshape(-1), want.reshape(-1))
+                    assert par["all_ties"], par
+                rows.append(t.reshape(B, -1).long().cpu() + p * V)
+    assert np.array_equal(torch.cat(rows, dim=1).numpy(), g["tokens"]) or not multi
+    # (ii) end to end
+    x = (torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(int(g["x_seed"]))) * 2 - 1).cuda()
+    tok = tk.tokens_from_images(m, x).cpu().numpy()
+    assert tok.shape == g["tokens"].shape and tok.dtype == np.int64
+    assert tok[:, :tok.shape[1] // 2].max() < V and tok[:, tok.shape[1] // 2:].min() >= V
+    agree = (tok == g["tokens"]).mean(axis=1)
+    print(f"{name}: end-to-end token agreement per image {agree.tolist()}")
+    assert agree.min() >= (0.9 if multi else 0.97)
