@@ -75,8 +75,9 @@ def parse():
     p.add_argument("--no-mfu", action="store_true", help="skip the FlopCounterMode pass (mfu = null)")
     p.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the links")
     p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                   help="replay the train step from a hipGraph (train.CapturedStep): auto = single process and a config without "
-                        "per-step host randomness, falling back to the eager step if the capture fails")
+                   help="replay the train step from a hipGraph (train.CapturedStep): auto = single process (every BASELINE config captures: "
+                        "quantizer-dropout depths are drawn on the device for a captured model), falling back to the eager step if the "
+                        "capture fails")
     return p.parse_args()
 
 
@@ -145,7 +146,6 @@ def count_flops_per_image(args, dev, B_count=2):
     """FlopCounterMode over one complete train step on the library formulation (fp32, per-op blocks) / B_count."""
     from torch.utils._python_dispatch import TorchDispatchMode
     from torch.utils.flop_counter import flop_registry
-    from imagefolder_amd import nn_ops, ops_dense
 
     class FlopMode(TorchDispatchMode):
         """FlopCounterMode's per-op formulas (torch.utils.flop_counter.flop_registry) without its module tracker, whose
@@ -161,10 +161,8 @@ def count_flops_per_image(args, dev, B_count=2):
             return out
     a2 = argparse.Namespace(**vars(args))
     a2.batch = B_count
-    saved = (nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL)
-    nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL = False, "library"
-    impl_saved = dict(nn_ops.IMPL)
-    try:
+    from tools.library_backend import library_dense_ops     # A/B harness: the library formulation the counter has formulas for
+    with library_dense_ops():
         torch.manual_seed(0)
         model, ts = build_train_step(a2, dev, 1, amp_dtype=None)
         imgs = torch.rand(B_count, 3, 256, 256, device=dev) * 2 - 1
@@ -172,10 +170,6 @@ def count_flops_per_image(args, dev, B_count=2):
             ts.step(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"])
         torch.cuda.synchronize()
         total = float(fc.total)
-    finally:
-        nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL = saved
-        nn_ops.IMPL.clear()
-        nn_ops.IMPL.update(impl_saved)
     tokens = CFG["P"] * (sum(p * p for p in CFG["pns"]) if len(CFG["pns"]) > 1 else CFG["L"])
     quant = 2.0 * tokens * CFG["V"] * CFG["C"]          # the assign kernel (custom op: invisible to the counter)
     del model, ts
@@ -310,8 +304,6 @@ def main():
     if args.workload == "train_step" and args.graph != "off":
         if use_dist:
             graph_note = "off (collectives are not recorded: eager step with world > 1)"
-        elif args.graph == "auto" and (CFG["P"] > 1 or len(CFG["pns"]) > 1):
-            graph_note = "off (auto: only the single-quantizer, single-scale configs have a validated capture; --graph on to try)"
         else:
             try:
                 captured = ts.capture(imgs, epoch=0, alpha=CFG["alpha"], beta=CFG["beta_lp"], delta=CFG["delta"], warmup=1)

@@ -27,6 +27,11 @@
 
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+
 using namespace xq;
 
 namespace {
@@ -73,9 +78,11 @@ struct GemmArgs {
     int nt_store;           // non-temporal bf16 output stores (default; XQ_GEMM_PLAIN_STORE turns them off): the 128 KiB a CU
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
-    int four_phase;         // XQ_GEMM_FOUR_PHASE: the round-2 schedule of the persistent kernel (4 phases of 8 MFMAs per K tile) instead of
-                            // the default 2 phases of 16 (A/B timing; profiles/r03_gemm_schedules.txt: two phases +15..19 % on the weight
-                            // gradient, +3..6 % on the data gradient, +0..8 % forward)
+    int phases;             // phases per K tile of the persistent kernel: 2 (16 MFMAs each), 4 (8 MFMAs each: the round-2 schedule) or
+                            // 0 = pick per shape by timing both once (pick_phases below).  The two schedules give bit-identical results;
+                            // which one is faster depends on the product (profiles/r03_gemm_schedules_v2.txt: two phases +7..17 % on the
+                            // weight gradient, -11..+4 % forward).  XQ_GEMM_TWO_PHASE / XQ_GEMM_FOUR_PHASE force one.
+    int nt_a;               // XQ_GEMM_NT_A: non-temporal LDS-DMA loads of the (K-major or K-strided, not gathered) A operand (A/B timing)
     int banded;             // XQ_GEMM_BANDED: XCD-banded whole-tile order (below) instead of row-major — opt-in: it cuts the fabric traffic
                             // but measured 4 - 10 % SLOWER on the forward products (profiles/r03_gemm_schedules.txt), so it is not the default
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
@@ -116,7 +123,8 @@ struct Stager {
     unsigned off[2][2];     // [half][i]
     const char *base;       // tile base at K tile 0 (wave-uniform)
     long adv;               // bytes per K tile
-    __device__ __forceinline__ void bind(const GemmArgs &) {}
+    int nt;                 // non-temporal LDS-DMA loads (XQ_GEMM_NT_A: the A operand is streamed once per XCD and round)
+    __device__ __forceinline__ void bind(const GemmArgs &g) { nt = IS_A ? g.nt_a : 0; }
     // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
     __device__ __forceinline__ void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn,
                                          int halves) {
@@ -148,9 +156,15 @@ struct Stager {
     // issue the two LDS-DMA instructions of piece `half` of K tile `kt` into LDS `dst` (wave-uniform piece base)
     __device__ __forceinline__ void issue(int half, long kt, char *dst, int wave) const {
         const char *b = base + kt * adv;
+        if (nt) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 2 /* nt */);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+        }
     }
 };
 
@@ -1026,6 +1040,64 @@ int plan_band(long tiles_m, long tiles_n, long K) {
     return best_c;
 }
 
+// ---- schedule selection by measurement -------------------------------------------------------------------------------------
+// Two- and four-phase persistent kernels compute the same sums in the same order (bit-identical outputs), but neither is faster on
+// every product (r03 measurements: the weight gradients and most data gradients prefer two phases, the qkv forward four).  The first
+// call of a (kernel, M, N, K) outside a stream capture times both — one warm-up launch and two timed launches each, HIP events on the
+// caller's stream, outputs rewritten with the same values — and the winner is cached for the life of the process.  XQ_GEMM_TUNE=0
+// turns this off (two phases everywhere); inside a hipGraph capture an untuned shape takes two phases without recording a choice.
+typedef std::tuple<int, int, int, int, long, long, long, long> TuneKey;    // AK, BK, ACT, conv mode, M, N, K, grid
+std::mutex g_tune_mu;
+std::map<TuneKey, int> g_tune_db;
+
+bool tuning_enabled() {
+    static const bool on = [] { const char *e = std::getenv("XQ_GEMM_TUNE"); return !(e && e[0] == '0'); }();
+    return on;
+}
+
+template <int AK, int BK, int ACT>
+void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t s) {
+    if (phases == 4) hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 4>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+    else hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 2>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+}
+
+template <int AK, int BK, int ACT>
+int pick_phases(const GemmArgs &g, long grid, int lds, hipStream_t s) {
+    if (g.phases == 2 || g.phases == 4) return g.phases;
+    if (!tuning_enabled()) return 2;
+    const TuneKey key(AK, BK, ACT, AK == gm::KMAJOR_CONV ? (g.cv_stride * 4 + g.cv_up * 2 + g.cv_transposed) * 4096 + g.cv_Cin : 0, g.M, g.N,
+                      (long)g.kt_full * gm::BKT, grid);
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune_db.find(key);
+        if (it != g_tune_db.end()) return it->second;
+    }
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return 2;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return 2; }
+    float best_ms = 0.f;
+    int best = 2;
+    for (int ph : {2, 4}) {
+        launch_pring<AK, BK, ACT>(g, ph, grid, lds, s);
+        (void)hipEventRecord(e0, s);
+        launch_pring<AK, BK, ACT>(g, ph, grid, lds, s);
+        launch_pring<AK, BK, ACT>(g, ph, grid, lds, s);
+        (void)hipEventRecord(e1, s);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); best = 2; break; }
+        if (ph == 2 || ms < best_ms) { best_ms = ms; best = ph; }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune_db[key] = best;
+    return best;
+}
+
 template <int AK, int BK, int EPI, int ACT = ACT_NONE>
 int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStream_t s, const char *fn, double flops, int prof_kind = XQ_PROF_GEMM) {
     const long tiles = (long)g.tiles_m * g.tiles_n;
@@ -1058,13 +1130,9 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
             g.band_full = 0;
         }
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
-        if (!g.four_phase) {      // default: two phases of 16 MFMAs per K tile
-            if (set_lds<gemm_pring_kernel<AK, BK, ACT, 2>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 2>), dim3((unsigned)grid), dim3(GT), lds, s, g);
-        } else {
-            if (set_lds<gemm_pring_kernel<AK, BK, ACT, 4>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 4>), dim3((unsigned)grid), dim3(GT), lds, s, g);
-        }
+        if (set_lds<gemm_pring_kernel<AK, BK, ACT, 2>>(lds) || set_lds<gemm_pring_kernel<AK, BK, ACT, 4>>(lds))
+            return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+        launch_pring<AK, BK, ACT>(g, pick_phases<AK, BK, ACT>(g, grid, lds, s), grid, lds, s);
         if (EPI == EPI_BF16 && pl.tail_tiles)
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
                                pl.main_items, g.tiles_m, g.tiles_n, g.grp_c, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
@@ -1127,8 +1195,9 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     GemmArgs g{};
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
+    g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
     g.banded = (impl & XQ_GEMM_BANDED) ? 1 : 0;
+    g.nt_a = (impl & XQ_GEMM_NT_A) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1146,8 +1215,9 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
+    g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
     g.banded = (impl & XQ_GEMM_BANDED) ? 1 : 0;
+    g.nt_a = (impl & XQ_GEMM_NT_A) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1166,7 +1236,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     hipStream_t s = (hipStream_t)stream;
     const int BN = pick_bn(Q, impl);
     const int tile_major_debug = (impl & XQ_GEMM_TILE_MAJOR) ? 1 : 0;
-    const int four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
+    const int phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
     impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
@@ -1182,7 +1252,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
         if (impl == XQ_GEMM_AUTO) impl = BN == 256 ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
         compact = impl == XQ_GEMM_PERSISTENT;
         g.tile_major_debug = tile_major_debug;
-        g.four_phase = four_phase;
+        g.phases = phases;
         if (!compact && (ws_bytes < (size_t)splits * P * Q * 4 || !ws)) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
         const int rc = launch_gemm<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, ws, ws_bytes, s, fn, 2.0 * P * Q * (double)(kt_all * 64));
         if (rc) return rc;
@@ -1249,11 +1319,11 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     if ((long)B * Hi * Wi >= 0x7fffffffL || Ho > 32767 || Wo > 32767) return xq_set_error(XQ_EINVAL, "%s: image too large for 32-bit pixel indices", fn);
     const long M = (long)B * Ho * Wo, K = 9L * Cin;
     const int BN = pick_bn(Cout, impl);
-    const int banded = (impl & XQ_GEMM_BANDED) ? 1 : 0, four_phase = (impl & XQ_GEMM_FOUR_PHASE) ? 1 : 0;
+    const int banded = (impl & XQ_GEMM_BANDED) ? 1 : 0, phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
     impl &= 0xff;
     GemmArgs g{};
     g.banded = banded;
-    g.four_phase = four_phase;
+    g.phases = phases;
     g.nt_store = 1;
     g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;
     g.M = M; g.N = Cout; g.lda = K; g.ldb = K; g.ldc = Cout;

@@ -1,9 +1,10 @@
 """Dense-layer op table for the encoder/decoder (E1-E4 of SURVEY.md §8a).
 
 Every tensor op of the ViT / CNN encoder-decoder (and of the VQLoss networks) goes through one of these functions:
-  * "hip"     — hand-written gfx950 kernel from libxq_ops.so (through autograd Functions in ops_dense.py);
-  * "library" — PyTorch-ROCm library op (hipBLASLt / MIOpen / ATen): plain GEMMs by design, and the ops whose HIP
-                kernel has not landed yet (fp32 parity path, unsupported shapes).
+  * "hip"     — hand-written gfx950 kernel from libxq_ops.so (through autograd Functions in ops_dense.py): every op of the bf16
+                training step and of the fp32 inference (reference-parity) path, the Linear / conv GEMMs included;
+  * "library" — PyTorch-ROCm library op (ATen / hipBLASLt / MIOpen): CPU tensors (the host mirror the CPU tests compare with the
+                reference), fp32 TRAINING on the GPU (not a configuration of the reference), shapes outside a kernel's contract.
 `IMPL[name]` records what each op last ran on; `bench.py` reports the table in its config so a number is
 never quoted without saying which ops were hand-written.  The fp32 numerics reference for every HIP op here is the
 ATen implementation of the same op (tests/test_dense_ops_gpu.py).
@@ -20,7 +21,7 @@ def _lib_ran(name, what):
     """a library fallback executed: say so (on the GPU only — CPU runs are the host mirror, not the product path)"""
     IMPL[name] = what
 
-# ViT blocks as fused HIP row kernels + attention kernels + library GEMMs (ops_dense.run_blocks) instead of per-op ATen calls
+# ViT blocks as fused HIP row kernels + attention kernels + the hand-written GEMMs (ops_dense.run_blocks) instead of per-op ATen calls
 FUSED_BLOCKS = True
 
 
@@ -96,22 +97,34 @@ def residual_scale_add(x, y, gamma=None, mask=None):
     return x + y
 
 
+def _weight_2d(weight):
+    """(out, in * kh * kw) view of a conv weight for the GEMM path.  The view is a new tensor object: hand it the bf16 shadow of its
+    base (the optimizer-maintained one for trainable parameters, ops_dense._w16) so that LinearFn does not re-cast fp32 -> bf16 on
+    every call (quant_conv / post_quant_conv / patch embedding weights)."""
+    w2 = weight.reshape(weight.shape[0], -1)
+    if weight.is_cuda and weight.dtype == torch.float32:
+        from .ops_dense import _w16
+        w2._xq_w16 = _w16(weight).reshape(w2.shape)
+        w2._xq_w16_version = w2._version          # a view shares its base's version counter
+    return w2
+
+
 def patch_embed(x, weight, bias, patch):
-    IMPL["patch_embed"] = "linear over patchified pixels (see `linear`)"
     """Conv2d(kernel = stride = patch) + flatten(2).transpose(1, 2): (B,3,H,W) -> (B, (H/p)*(W/p), D).
     A non-overlapping conv is a GEMM over patchified pixels: (B*gh*gw, 3*p*p) @ W^T.  (MIOpen has no tuned bf16
     solver for this shape on gfx950 and falls back to naive_conv_* kernels: 35 % of the step in profiles/r01.)"""
+    IMPL["patch_embed"] = "linear over patchified pixels (see `linear`)"
     B, Cin, H, W = x.shape
     gh, gw = H // patch, W // patch
     cols = x.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cin * patch * patch)
-    return linear(cols, weight.reshape(weight.shape[0], -1), bias)
+    return linear(cols, _weight_2d(weight), bias)
 
 
 def conv1x1(x, weight, bias=None):
     """1x1 Conv2d on NCHW as a GEMM over the channel axis (quant_conv / post_quant_conv, xqgan_model.py:89-146).
     The input is usually a permuted view of a channels-last token tensor, so the permute below is free."""
     xt = x.permute(0, 2, 3, 1)
-    w2 = weight.reshape(weight.shape[0], -1)
+    w2 = _weight_2d(weight)
     if x.is_cuda and torch.is_autocast_enabled("cuda") and xt.dtype == torch.float32 and torch.get_autocast_dtype("cuda") == torch.bfloat16:
         xt = xt.to(torch.bfloat16)         # what autocast does to the input of the conv
     if x.is_cuda and xt.dtype == torch.bfloat16:

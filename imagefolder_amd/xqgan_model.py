@@ -330,6 +330,7 @@ class VQModel(nn.Module):
         else:  # host RNG like upstream (:274): fixes the dropout depth across the product quantizers
             dropout_rand = torch.randint(self.start_drop, len(self.v_patch_nums) + 1, (b,))
 
+        self._last_dropout_rand = dropout_rand     # the depths this forward drew (tests / logging; device tensor on the device path)
         if self.product_quant > 1:
             side = int(sqrt(l // self.product_quant))
             quant_list, usages_list, vq_list, commit_list, ent_list = [], [], [], [], []

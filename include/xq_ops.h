@@ -393,8 +393,11 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_DEBUG_NO_STORE 0x200 /* OR-ed into impl (NT, persistent schedule): skip the output stores — timing experiments, result unusable */
 #define XQ_GEMM_TILE_MAJOR 0x400 /* OR-ed into impl (TN, persistent schedule): execute the K-split items tile-major instead of split-major (A/B timing) */
 #define XQ_GEMM_PLAIN_STORE 0x800 /* OR-ed into impl (persistent schedule): plain instead of non-temporal output stores (A/B timing) */
-#define XQ_GEMM_FOUR_PHASE 0x4000 /* OR-ed into impl (persistent schedule): the round-2 schedule, 4 phases of 8 MFMAs per K tile, instead of
-                                     the default 2 phases of 16 (A/B timing; results are bit-identical) */
+#define XQ_GEMM_TWO_PHASE 0x1000  /* OR-ed into impl (persistent schedule): force 2 phases of 16 MFMAs per K tile                                  */
+#define XQ_GEMM_FOUR_PHASE 0x4000 /* OR-ed into impl (persistent schedule): force 4 phases of 8 MFMAs per K tile (the round-2 schedule).  With neither
+                                     bit the library times both on the first call of a shape and keeps the faster one (XQ_GEMM_TUNE=0 in the
+                                     environment: always two phases); the two schedules give bit-identical results */
+#define XQ_GEMM_NT_A 0x8000 /* OR-ed into impl (NT / NN, persistent schedule): non-temporal LDS-DMA loads of the A operand (A/B timing) */
 #define XQ_GEMM_BANDED 0x2000 /* OR-ed into impl (persistent schedule): XCD-banded whole-tile order (column groups sized to the L2, one contiguous
                                  band per XCD) instead of row-major; less fabric traffic, measured slower on the forward products: opt-in */
 #define XQ_GEMM_OP_NT 0

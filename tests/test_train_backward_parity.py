@@ -9,8 +9,9 @@ LPIPS / GAN terms need downloaded checkpoints); gradients of ~25 parameter tenso
 recorded twice — fp32, and under torch.autocast('cpu', bfloat16): the reference's own reduced-precision backward.
 
 Checked here on the MI355X:
-  (a) fp32 step (HIP quantizers + perturbation with their hand-written backward, fp32 dense path): every tapped gradient within
-      REL_F32 of the reference's fp32 gradient (relative L2 over the sub-sample);
+  (a) fp32 step (HIP quantizers + perturbation with their hand-written backward; fp32 TRAINING runs the dense layers on ATen, the
+      hand-written dense kernels are the bf16 ones of (b)): every tapped gradient within REL_F32 of the reference's fp32 gradient
+      (relative L2 over the sub-sample);
   (b) the bf16 TRAINING path (hand-written bf16 MFMA GEMMs fwd / dgrad / wgrad, attention fwd / bwd, fused row kernels, quantizer
       backward): its distance to the reference's fp32 gradient is bounded by the distance of the reference's OWN bf16-autocast
       backward to it (x SLACK + FLOOR) — tensor by tensor;
@@ -28,7 +29,13 @@ from test_train_forward_parity import CASES, COMMON
 
 pytestmark = pytest.mark.gpu
 
-REL_F32 = 2e-3          # (a): fp32 path vs reference fp32 (ATen CPU sums in another order; near-tie flips)
+REL_F32 = 1e-4          # (a): fp32 path vs reference fp32 (measured: <= 1.1e-5 on cfg 2 / 3 / 4, profiles/r03_gradient_parity.txt)
+# cfg 5 (RobustTok): add_perturbation picks, per token, the code of RANK r among the 100 nearest (latent_perturbation.py:20-24) —
+# neighbouring ranks are separated by ~1e-6 in distance, so the fp32 rounding of the encoder (ATen's GPU GEMMs in this fp32 TRAINING
+# pass vs ATen's CPU GEMMs in the reference) moves a few of the 128 randomly ranked tokens to the neighbouring code
+# ("parity on exact ties is only defined up to the chosen code's distance").  The codebook gradient (vq loss only: no
+# perturbed sample reaches it) still matches to 1e-6; everything downstream of the perturbed sample moves by <= ~1.7e-2.
+REL_F32_PERTURBED = 2.5e-2
 SLACK, FLOOR = 1.5, 3e-3   # (b): err_ours <= SLACK * err_reference_bf16 + FLOOR
 
 
@@ -103,7 +110,7 @@ def test_model_level_gradients_match_the_reference_autograd(name, monkeypatch):
     # ---- (a) fp32 ----
     lr = 1e-4
     loss32, g32, after32, seed = _run(name, None, monkeypatch, lr=lr)
-    np.testing.assert_allclose(loss32, float(gb["loss_f32"]), rtol=2e-4)
+    np.testing.assert_allclose(loss32, float(gb["loss_f32"]), rtol=1e-4 if name == "train_bwd_cfg5_robusttok" else 5e-6)
     rows = []
     for n in taps:
         ref = gb[f"f32:{n}"]
@@ -119,8 +126,11 @@ def test_model_level_gradients_match_the_reference_autograd(name, monkeypatch):
     print(f"\n{name}: loss fp32 {loss32:.6f} (ref {float(gb['loss_f32']):.6f}), bf16 {loss16:.6f} (ref bf16 {float(gb['loss_bf16']):.6f})")
     for (n, e32, l2), (_, e16, r16) in zip(rows, rows16):
         print(f"  {n:48s} |g| {l2:9.3e}  fp32 rel {e32:8.2e}   bf16 rel {e16:8.2e}  (reference's own bf16: {r16:8.2e})")
-    bad32 = [(n, e) for n, e, _ in rows if e > REL_F32]
+    perturbed = name == "train_bwd_cfg5_robusttok"
+    bad32 = [(n, e) for n, e, _ in rows if e > (REL_F32_PERTURBED if perturbed else REL_F32)]
     assert not bad32, f"fp32 gradients off the reference: {bad32}"
+    if perturbed:
+        assert dict((n, e) for n, e, _ in rows)["quantize.embedding.weight"] <= REL_F32
     bad16 = [(n, e, r) for n, e, r in rows16 if e > SLACK * r + FLOOR]
     assert not bad16, f"bf16 gradients further from the reference's fp32 gradient than its own bf16 backward allows: {bad16}"
     assert abs(loss16 - float(gb["loss_f32"])) <= SLACK * abs(float(gb["loss_bf16"]) - float(gb["loss_f32"])) + 2e-3 * abs(float(gb["loss_f32"]))
