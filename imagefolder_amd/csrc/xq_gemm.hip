@@ -123,7 +123,9 @@ struct Stager {
     unsigned off[2][2];     // [half][i]
     const char *base;       // tile base at K tile 0 (wave-uniform)
     long adv;               // bytes per K tile
-    int nt;                 // non-temporal LDS-DMA loads (XQ_GEMM_NT_A: the A operand is streamed once per XCD and round)
+    int nt = 0;             // non-temporal LDS-DMA loads (XQ_GEMM_NT_A: the A operand is streamed once per XCD and round).  Initialised
+                            // here: the kernels only bind() their A stager, and a branch on an indeterminate value is undefined behaviour
+                            // (the optimiser turned every GEMM into an empty kernel when this member was left unset for B)
     __device__ __forceinline__ void bind(const GemmArgs &g) { nt = IS_A ? g.nt_a : 0; }
     // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
     __device__ __forceinline__ void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn,
@@ -352,6 +354,7 @@ __global__ __launch_bounds__(GT) void gemm_simple_kernel(const GemmArgs g0) {
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.bind(g);
+    sb.bind(g);
     sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, NFJ);
 
@@ -432,6 +435,7 @@ __global__ __launch_bounds__(GT) void gemm_ring_kernel(const GemmArgs g) {
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.bind(g);
+    sb.bind(g);
     sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, 2);
 
@@ -607,6 +611,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.bind(g);
+    sb.bind(g);
     sa.init(g.A, g.lda, cit.m0, g.M, cit.k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, cit.n0, g.N, cit.k0, wave, lane, WTN, 2);
     long sp = cp;

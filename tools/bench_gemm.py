@@ -69,6 +69,7 @@ def main():
                         return run
                     cases += [
                         (f"fwd  hip nt {tag}", mk(lambda: od.gemm_nt(x, w, bias))),
+                        (f"fwd  hip nt NO BIAS {tag}", mk(lambda: od.gemm_nt(x, w, None))),
                         (f"gx   hip nn {tag}", mk(lambda: od.gemm_nn(g, w))),
                         (f"gW   hip tn {tag}", mk(lambda: od.gemm_tn(g, x))),
                     ]

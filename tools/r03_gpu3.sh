@@ -1,7 +1,7 @@
 #!/bin/bash
 # round-3 GPU call 3: tuned schedules, order / nt-load A/B, traffic counters per order, all BASELINE configs, bulk tokenisation, kernel trace
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-OUT=gpurun_out/r03c; mkdir -p $OUT
+OUT=gpurun_out/r03d; mkdir -p $OUT
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_gemm_gpu.py tests/test_conv_gemm_gpu.py -m gpu -q > $OUT/gemm_tests.txt 2>&1; echo "gemm tests rc=$?"; tail -3 $OUT/gemm_tests.txt
 timeout 900 python -m pytest tests/test_model_gpu.py tests/test_rfid_parity_gpu.py tests/test_train_arena_gpu.py "tests/test_train_backward_parity.py::test_model_level_gradients_match_the_reference_autograd[train_bwd_cfg5_robusttok]" -m gpu -q -s > $OUT/pytest_sel.txt 2>&1; echo "selected tests rc=$?"; tail -6 $OUT/pytest_sel.txt
@@ -33,11 +33,11 @@ for CFG in VQ-4096 VP2-16384 MSVR10P2-4096 RobustTok; do
   timeout 300 python bench.py --config $CFG --steps 10 --warmup 3 --no-cpu-baseline --no-mfu >> $OUT/bench_configs.jsonl 2>> $OUT/bench_configs.err; echo "$CFG rc=$?"
 done
 timeout 300 python tools/bench_tokenize.py --out $OUT/bulk_tokenize.jsonl 2> $OUT/bulk_tokenize.err; echo "tokenize rc=$?"
-timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_r03c -o step -- python bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-mfu --graph off > $OUT/trace_bench.json 2> $OUT/trace.err; echo "trace rc=$?"
-find /tmp/prof_r03c -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/step_kernel_stats.csv
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_r03d -o step -- python bench.py --steps 7 --warmup 3 --no-cpu-baseline --no-mfu --graph off > $OUT/trace_bench.json 2> $OUT/trace.err; echo "trace rc=$?"
+find /tmp/prof_r03d -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $OUT/step_kernel_stats.csv
 python - <<'PY'
 import json, glob
-for f in sorted(glob.glob("gpurun_out/r03c/bench*.json*")) + ["gpurun_out/r03c/trace_bench.json"]:
+for f in sorted(glob.glob("gpurun_out/r03d/bench*.json*")) + ["gpurun_out/r03d/trace_bench.json"]:
     try:
         for l in open(f):
             if l.startswith("{"):
