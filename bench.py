@@ -449,6 +449,9 @@ def main():
                 if all(k in traffic for k in keys):
                     e["traffic"] = sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)
                     e["traffic_source"] = traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, average bytes per launch; per-shape rows in the file)"
+                    e["traffic_note"] = ("fabric-side bytes: requests the eight L2s sent to the Infinity Fabric (they include Infinity-Cache hits) — an "
+                                         "UPPER bound on HBM bytes, MI355X_MICROARCH.md §HBM; collected on the round-2 kernels: the round-3 schedule "
+                                         "change (two phases per K tile) walks the same tiles in the same order")
         entries.sort(key=lambda e: -e["ms_per_step"])
         out["roofline"] = dict(entries[0], note="kernel family with the most GPU time in the timed region (every MFMA kernel of "
                                                 "the step is hand-written and instrumented: HIP events on its launch stream); "
