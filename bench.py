@@ -310,6 +310,21 @@ def main():
                 for _ in range(2):
                     captured.replay()
                 graph_note = "on (torch.cuda.CUDAGraph over the whole step: train.CapturedStep)"
+                if args.graph == "auto":
+                    # the replay is not a win for every config: the ladder configs launch thousands of sub-10-us kernels, which the
+                    # graph executor of this ROCm release runs no faster (MSVR10P2: slower) than the eager stream — measure, then choose
+                    def _time(fn, n=3):
+                        torch.cuda.synchronize()
+                        t = time.perf_counter()
+                        for _ in range(n):
+                            fn()
+                        torch.cuda.synchronize()
+                        return (time.perf_counter() - t) / n * 1e3
+                    t_replay, t_eager = _time(captured.replay), _time(step)
+                    if t_eager < 0.99 * t_replay:
+                        graph_note = (f"off (auto: captured, but the eager step measured faster on this config: {t_eager:.1f} vs {t_replay:.1f} ms "
+                                      "over 3 steps each)")
+                        captured = None
             except Exception as e:  # noqa: BLE001
                 if args.graph == "on":
                     raise

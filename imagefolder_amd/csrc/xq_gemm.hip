@@ -79,23 +79,9 @@ struct GemmArgs {
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
     int phases;             // phases per K tile of the persistent kernel: 2 (16 MFMAs each), 4 (8 MFMAs each: the round-2 schedule) or
-                            // 0 = pick per shape by timing both once (pick_phases below).  The two schedules give bit-identical results;
-                            // which one is faster depends on the product (profiles/r03_gemm_schedules_v2.txt: two phases +7..17 % on the
-                            // weight gradient, -11..+4 % forward).  XQ_GEMM_TWO_PHASE / XQ_GEMM_FOUR_PHASE force one.
-    int nt_a;               // XQ_GEMM_NT_A: non-temporal LDS-DMA loads of the (K-major or K-strided, not gathered) A operand (A/B timing)
-    int banded;             // XQ_GEMM_BANDED: XCD-banded whole-tile order (below) instead of row-major — opt-in: it cuts the fabric traffic
-                            // but measured 4 - 10 % SLOWER on the forward products (profiles/r03_gemm_schedules.txt), so it is not the default
+                            // 0 = default (two; or timed per shape under XQ_GEMM_TUNE=1: pick_phases below).  Bit-identical results.
+                            // XQ_GEMM_TWO_PHASE / XQ_GEMM_FOUR_PHASE force one.
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
-    // XCD-banded tile order of the persistent schedule's whole-tile items (NT / NN / implicit-GEMM conv).  The tile grid is cut
-    // into column GROUPS of grp_c column tiles; the tile sequence runs group by group, row-major inside a group; XCD x (workgroups
-    // x, x + 8, ...) owns the contiguous eighth [x, x + 1) * band_full / 8 of that sequence and walks it round by round.  So the B
-    // panels an XCD needs (grp_c x 256 x K x 2 bytes, sized by plan_band() to stay resident in its 4 MiB L2) are fetched once per
-    // XCD instead of once per round, and successive rounds move DOWN the rows of one group instead of jumping 256 tiles ahead
-    // (row-major order made every XCD stream the whole weight matrix every round: 4 - 6x re-fetch of it through the fabric,
-    // profiles/r02_kernel_hbm_traffic_shapes.json).  band_full = the items under this mapping (a multiple of the grid size; the
-    // last partial round and the K-split tail keep sequence position = item index); grp_c = 0: plain row-major (the default).
-    int grp_c;
-    long band_full;
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
                             // ONE range of g / x rows through its L2 for all of that range's output tiles; tile-major order (0, the
@@ -123,10 +109,7 @@ struct Stager {
     unsigned off[2][2];     // [half][i]
     const char *base;       // tile base at K tile 0 (wave-uniform)
     long adv;               // bytes per K tile
-    int nt = 0;             // non-temporal LDS-DMA loads (XQ_GEMM_NT_A: the A operand is streamed once per XCD and round).  Initialised
-                            // here: the kernels only bind() their A stager, and a branch on an indeterminate value is undefined behaviour
-                            // (the optimiser turned every GEMM into an empty kernel when this member was left unset for B)
-    __device__ __forceinline__ void bind(const GemmArgs &g) { nt = IS_A ? g.nt_a : 0; }
+    __device__ __forceinline__ void bind(const GemmArgs &) {}
     // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
     __device__ __forceinline__ void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn,
                                          int halves) {
@@ -158,15 +141,9 @@ struct Stager {
     // issue the two LDS-DMA instructions of piece `half` of K tile `kt` into LDS `dst` (wave-uniform piece base)
     __device__ __forceinline__ void issue(int half, long kt, char *dst, int wave) const {
         const char *b = base + kt * adv;
-        if (nt) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 2 /* nt */);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
-        }
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
     }
 };
 
@@ -354,7 +331,6 @@ __global__ __launch_bounds__(GT) void gemm_simple_kernel(const GemmArgs g0) {
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.bind(g);
-    sb.bind(g);
     sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, NFJ);
 
@@ -435,7 +411,6 @@ __global__ __launch_bounds__(GT) void gemm_ring_kernel(const GemmArgs g) {
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.bind(g);
-    sb.bind(g);
     sa.init(g.A, g.lda, m0, g.M, k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, n0, g.N, k0, wave, lane, WTN, 2);
 
@@ -558,6 +533,11 @@ __global__ __launch_bounds__(GT) void gemm_ring_kernel(const GemmArgs g) {
 //                                   the next item; ring slot parity = parity of the cursor's global K-tile count
 //   per item                      : [wave row 1: +1 barrier] K tiles [wave row 0: +1 barrier] epilogue — both wave rows run
 //                                   their epilogues side by side; the epilogue stages through 4 KiB per wave OUTSIDE the ring
+//   tile order                    : row-major items, XCD k takes a contiguous run of every round (xcd_order).  Tried in round 3 and taken out
+//                                   again (git history: "XCD-banded tile order"): column groups sized to the 4 MiB L2, one contiguous run of
+//                                   the sequence per XCD — 5-14 % fewer fabric bytes, no speed-up (profiles/r03_gemm_fabric_traffic_by_order.txt,
+//                                   r03_gemm_schedules_v3.txt), and its index arithmetic cost registers in a kernel that already spills;
+//                                   likewise non-temporal LDS-DMA loads of the A operand (-1..-4 %)
 //   vmcnt                         : stores of the epilogue may still be outstanding in the next item's first phases; they only
 //                                   make the counted waits stricter (more operations pending than the count assumes)
 // =====================================================================================================================
@@ -581,10 +561,8 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
         it.slab = 1;
         it.slab_idx = tl * nsplit + split;       // slab layout [tile][split] whatever the execution order (slab_reduce_kernel)
     }
-    long tm, tn;
-    gm::band_tile(gm::band_seq(p < g.main_items ? p : tile, g.band_full, (long)gridDim.x), g.tiles_m, g.tiles_n, g.grp_c, &tm, &tn);
-    it.m0 = tm * gm::BM;
-    it.n0 = tn * 256;
+    it.m0 = (tile / g.tiles_n) * gm::BM;
+    it.n0 = (tile % g.tiles_n) * 256;
     const long base = g.kt_full / nsplit, rem = g.kt_full % nsplit;
     it.k0 = (split * base + (split < rem ? split : rem)) * gm::BKT;
     it.KT = (int)(base + (split < rem ? 1 : 0));
@@ -611,7 +589,6 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.bind(g);
-    sb.bind(g);
     sa.init(g.A, g.lda, cit.m0, g.M, cit.k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, cit.n0, g.N, cit.k0, wave, lane, WTN, 2);
     long sp = cp;
@@ -903,16 +880,14 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 
 // slabs [item = tail tile * nsplit + split][256][256] fp32 -> output: the sum over the splits of every tail tile,
 //   bf16 (+ bias) into C (NT / NN tail tiles), or fp32 into out (TN; + the < 64 remainder rows of the reduction, folded in here)
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_m, int tiles_n,
-                                                          int grp_c, long M, long N, long ldc, const float *__restrict__ bias,
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_n,
+                                                          long M, long N, long ldc, const float *__restrict__ bias,
                                                           __hip_bfloat16 *__restrict__ out16, float *__restrict__ out32,
                                                           const __hip_bfloat16 *__restrict__ G, const __hip_bfloat16 *__restrict__ X,
                                                           long r_begin, long r_end) {
     const long t = blockIdx.x;
     const long tile = first_tile + t;
-    long tm, tn;
-    gm::band_tile(tile, tiles_m, tiles_n, grp_c, &tm, &tn);     // tail tiles: sequence position = tile index (decode_item)
-    const long m0 = tm * 256, n0 = tn * 256;
+    const long m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
     const int rl = blockIdx.y * 8 + (threadIdx.x >> 5), cl = (threadIdx.x & 31) * 8;
     const long gr = m0 + rl, gc = n0 + cl;
     if (gr >= M || gc + 8 > N) return;
@@ -1022,41 +997,19 @@ PPlan plan_persistent(long tiles, int kt_full, bool weight_grad) {
     return p;
 }
 
-// column-group width of the banded order (GemmArgs::grp_c): the c that minimises the bytes the eight L2s pull through the fabric,
-//   A panels: every row panel is fetched once per column group                      -> A_bytes * ceil(tiles_n / c)
-//   B panels: a group that fits the L2 budget stays resident, fetched once per XCD   -> 8 * c * panel_B
-//             one that does not is streamed again by every XCD in every round        -> rounds * 8 * c * panel_B
-// (panel_B = 256 x K x 2 bytes; budget 2.5 MiB of the 4 MiB L2: the A panels of the round in flight and the output stream need the rest)
-int plan_band(long tiles_m, long tiles_n, long K) {
-    const double panel_b = 256.0 * (double)K * 2.0, a_bytes = (double)tiles_m * 256.0 * (double)K * 2.0;
-    const double rounds = (double)(tiles_m * tiles_n) / (double)num_cus();
-    const double budget = 2.5 * 1048576.0;
-    double best = -1.0;
-    int best_c = (int)tiles_n;
-    for (long c = 1; c <= tiles_n; ++c) {
-        const long groups = (tiles_n + c - 1) / c;
-        if ((groups - 1) * c >= tiles_n) continue;
-        const long cw = (tiles_n + groups - 1) / groups;          // balanced widths: ceil(tiles_n / groups)
-        if (cw != c) continue;
-        const double fb = (c * panel_b <= budget ? 1.0 : (rounds > 1.0 ? rounds : 1.0)) * 8.0 * (double)c * panel_b;
-        const double cost = a_bytes * (double)groups + fb;
-        if (best < 0.0 || cost < best) { best = cost; best_c = (int)c; }
-    }
-    return best_c;
-}
-
-// ---- schedule selection by measurement -------------------------------------------------------------------------------------
-// Two- and four-phase persistent kernels compute the same sums in the same order (bit-identical outputs), but neither is faster on
-// every product (r03 measurements: the weight gradients and most data gradients prefer two phases, the qkv forward four).  The first
-// call of a (kernel, M, N, K) outside a stream capture times both — one warm-up launch and two timed launches each, HIP events on the
-// caller's stream, outputs rewritten with the same values — and the winner is cached for the life of the process.  XQ_GEMM_TUNE=0
-// turns this off (two phases everywhere); inside a hipGraph capture an untuned shape takes two phases without recording a choice.
+// ---- schedule selection ------------------------------------------------------------------------------------------------------
+// Two- and four-phase persistent kernels compute the same sums in the same order (bit-identical outputs).  Round-3 measurements on
+// the ViT-B shapes (profiles/r03_gemm_schedules_v3.txt): two phases are never slower — weight gradients +10..15 %, data gradients
+// 0..+4 %, forward 0..+2 % — so two phases are the default.  (Two earlier A/B runs had suggested shape-dependent winners; that was
+// the first-measured-row penalty of the bench harness, not the schedule.)  XQ_GEMM_TUNE=1 in the environment makes the first call of
+// a (kernel, M, N, K) outside a stream capture time both — one warm-up launch and two timed launches each, HIP events on the caller's
+// stream, outputs rewritten with the same values — and cache the winner for the life of the process: for shapes nobody measured.
 typedef std::tuple<int, int, int, int, long, long, long, long> TuneKey;    // AK, BK, ACT, conv mode, M, N, K, grid
 std::mutex g_tune_mu;
 std::map<TuneKey, int> g_tune_db;
 
 bool tuning_enabled() {
-    static const bool on = [] { const char *e = std::getenv("XQ_GEMM_TUNE"); return !(e && e[0] == '0'); }();
+    static const bool on = [] { const char *e = std::getenv("XQ_GEMM_TUNE"); return e && e[0] == '1'; }();
     return on;
 }
 
@@ -1127,20 +1080,13 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         g.slabs = (float *)ws;
         const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
         const long grid = items < num_cus() ? items : num_cus();
-        if (EPI == EPI_BF16 && g.banded && grid % 8 == 0 && pl.main_items >= grid) {
-            g.grp_c = plan_band(g.tiles_m, g.tiles_n, (long)g.kt_full * gm::BKT);
-            g.band_full = (pl.main_items / grid) * grid;
-        } else {
-            g.grp_c = 0;
-            g.band_full = 0;
-        }
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
         if (set_lds<gemm_pring_kernel<AK, BK, ACT, 2>>(lds) || set_lds<gemm_pring_kernel<AK, BK, ACT, 4>>(lds))
             return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
         launch_pring<AK, BK, ACT>(g, pick_phases<AK, BK, ACT>(g, grid, lds, s), grid, lds, s);
         if (EPI == EPI_BF16 && pl.tail_tiles)
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
-                               pl.main_items, g.tiles_m, g.tiles_n, g.grp_c, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
+                               pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
                                (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L);
     } else {
         if (ACT != ACT_NONE) return xq_set_error(XQ_EINVAL, "%s: the fused activation needs the persistent schedule", fn);
@@ -1201,8 +1147,6 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
-    g.banded = (impl & XQ_GEMM_BANDED) ? 1 : 0;
-    g.nt_a = (impl & XQ_GEMM_NT_A) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1221,8 +1165,6 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
-    g.banded = (impl & XQ_GEMM_BANDED) ? 1 : 0;
-    g.nt_a = (impl & XQ_GEMM_NT_A) ? 1 : 0;
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1264,7 +1206,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     }
     const long done = splits ? kt_all * 64 : 0;   // rows covered by whole K tiles
     if (compact) {
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)tiles, 32), dim3(256), 0, s, (const float *)ws, splits, 0L, g.tiles_m, g.tiles_n, 0, (long)P,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)tiles, 32), dim3(256), 0, s, (const float *)ws, splits, 0L, g.tiles_n, (long)P,
                            (long)Q, (long)Q, (const float *)nullptr, (__hip_bfloat16 *)nullptr, g_w, (const __hip_bfloat16 *)g_y,
                            (const __hip_bfloat16 *)x, done, (long)R);
     } else {
@@ -1324,10 +1266,9 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     if ((long)B * Hi * Wi >= 0x7fffffffL || Ho > 32767 || Wo > 32767) return xq_set_error(XQ_EINVAL, "%s: image too large for 32-bit pixel indices", fn);
     const long M = (long)B * Ho * Wo, K = 9L * Cin;
     const int BN = pick_bn(Cout, impl);
-    const int banded = (impl & XQ_GEMM_BANDED) ? 1 : 0, phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
+    const int phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
     impl &= 0xff;
     GemmArgs g{};
-    g.banded = banded;
     g.phases = phases;
     g.nt_store = 1;
     g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;

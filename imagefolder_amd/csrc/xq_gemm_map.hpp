@@ -100,22 +100,4 @@ GM_HD long xcd_order(long id, long total) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
 }
 
-// XCD-banded order of the persistent schedule (GemmArgs::grp_c / band_full, csrc/xq_gemm.hip).
-// band_seq: item index p (workgroup b = x + 8 i runs items xcd_order(b, G) + j G = x G/8 + i + j G, j = 0, 1, ...) -> position in
-// the tile sequence: XCD x owns [x, x + 1) * band_full / 8, round j takes the next G / 8 positions of it.  Identity beyond band_full.
-GM_HD long band_seq(long p, long band_full, long G) {
-    if (p >= band_full) return p;
-    const long per = G / 8, j = p / G, r = p % G;
-    return (r / per) * (band_full / 8) + j * per + (r % per);
-}
-// band_tile: sequence position -> (row tile, column tile): column groups of grp_c tiles (the last one narrower), row-major
-// inside a group; grp_c <= 0: row-major over the whole grid.
-GM_HD void band_tile(long s, long tiles_m, long tiles_n, long grp_c, long *tm, long *tn) {
-    if (grp_c <= 0 || grp_c >= tiles_n) { *tm = s / tiles_n; *tn = s % tiles_n; return; }
-    const long per_group = tiles_m * grp_c, grp = s / per_group, w = s % per_group;
-    const long width = (grp + 1) * grp_c <= tiles_n ? grp_c : tiles_n - grp * grp_c;
-    *tm = w / width;
-    *tn = grp * grp_c + w % width;
-}
-
 }  // namespace gm

@@ -395,11 +395,8 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_PLAIN_STORE 0x800 /* OR-ed into impl (persistent schedule): plain instead of non-temporal output stores (A/B timing) */
 #define XQ_GEMM_TWO_PHASE 0x1000  /* OR-ed into impl (persistent schedule): force 2 phases of 16 MFMAs per K tile                                  */
 #define XQ_GEMM_FOUR_PHASE 0x4000 /* OR-ed into impl (persistent schedule): force 4 phases of 8 MFMAs per K tile (the round-2 schedule).  With neither
-                                     bit the library times both on the first call of a shape and keeps the faster one (XQ_GEMM_TUNE=0 in the
-                                     environment: always two phases); the two schedules give bit-identical results */
-#define XQ_GEMM_NT_A 0x8000 /* OR-ed into impl (NT / NN, persistent schedule): non-temporal LDS-DMA loads of the A operand (A/B timing) */
-#define XQ_GEMM_BANDED 0x2000 /* OR-ed into impl (persistent schedule): XCD-banded whole-tile order (column groups sized to the L2, one contiguous
-                                 band per XCD) instead of row-major; less fabric traffic, measured slower on the forward products: opt-in */
+                                     bit: two phases (measured never slower, profiles/r03_gemm_schedules_v3.txt); XQ_GEMM_TUNE=1 in the environment
+                                     times both on the first call of a shape and keeps the faster one.  Bit-identical results either way */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2

@@ -178,29 +178,6 @@ int main() {
         }
         for (int c : seen) if (c != 1) { g_fail++; std::printf("xcd_order(total=%ld) is not a bijection\n", total); break; }
     }
-    // XCD-banded order of the persistent schedule: item -> sequence position -> tile is a bijection on the whole-tile items, keeps the
-    // K-split tail tiles where slab_reduce_kernel looks for them, and gives XCD x (items x G/8 + i + j G) one contiguous band
-    for (long tiles_m : {1L, 5L, 129L, 257L}) for (long tiles_n : {1L, 3L, 9L, 12L}) for (long grp_c : {0L, 1L, 3L, 4L, 5L, 6L, 12L}) {
-        const long G = 256, T = tiles_m * tiles_n;
-        for (long main_items : {T, T - T % G}) {
-            if (main_items <= 0) continue;
-            const long band_full = main_items >= G ? (main_items / G) * G : 0;
-            std::vector<int> seen(T, 0);
-            for (long p = 0; p < T; ++p) {
-                long tm, tn;
-                band_tile(band_seq(p, band_full, G), tiles_m, tiles_n, grp_c, &tm, &tn);
-                if (tm < 0 || tm >= tiles_m || tn < 0 || tn >= tiles_n) { g_fail++; std::printf("band order out of range\n"); break; }
-                seen[tm * tiles_n + tn]++;
-            }
-            for (int c : seen) if (c != 1) { g_fail++; std::printf("band order (%ld x %ld, c=%ld) is not a bijection\n", tiles_m, tiles_n, grp_c); break; }
-            // one XCD's items of consecutive rounds are consecutive sequence positions
-            if (band_full >= 2 * G) {
-                const long x = 3, i = 5, p0 = x * (G / 8) + i, p1 = p0 + G;
-                if (band_seq(p1, band_full, G) - band_seq(p0, band_full, G) != G / 8) { g_fail++; std::printf("band rounds are not adjacent\n"); }
-                if (band_seq(p0, band_full, G) / (band_full / 8) != x) { g_fail++; std::printf("band does not belong to its XCD\n"); }
-            }
-        }
-    }
     std::printf(g_fail ? "FAILED\n" : "ALL OK\n");
     return g_fail ? 1 : 0;
 }

@@ -58,7 +58,7 @@ def main():
                     ("gx   library mm", lambda: torch.mm(g, w)),
                     ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
                 ]
-                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent (phases timed per shape)", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)", 0x1003: "persistent TWO-PHASE", 0x4003: "persistent FOUR-PHASE (round-2 schedule)", 0x2003: "persistent XCD-banded (tuned)", 0x3003: "persistent TWO-PHASE XCD-banded", 0x6003: "persistent FOUR-PHASE XCD-banded", 0x9003: "persistent TWO-PHASE nt-A loads", 0xB003: "persistent TWO-PHASE XCD-banded nt-A"}.get(int(x, 0), x)) for x in a.scheds]:
+                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent (default: two phases)", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)", 0x1003: "persistent TWO-PHASE", 0x4003: "persistent FOUR-PHASE (round-2 schedule)"}.get(int(x, 0), x)) for x in a.scheds]:
                     def mk(f, sched=sched):
                         def run():
                             od.GEMM_SCHEDULE = sched
@@ -76,6 +76,12 @@ def main():
                 if a.only:
                     key = {"nt": "fwd", "nn": "gx", "tn": "gW"}[a.only]
                     cases = [c for c in cases if c[0].startswith(key)]
+                for label, fn in cases:          # first touches of freshly allocated operands / cold caches cost the FIRST row up to
+                    try:                         # 15 % (rounds 1-3 mis-read that as a schedule effect): one untimed pass over all rows first
+                        fn()
+                    except Exception:  # noqa: BLE001
+                        pass
+                torch.cuda.synchronize()
                 for label, fn in cases:
                     try:
                         ms = timeit(fn, iters=a.iters)
