@@ -80,6 +80,25 @@ extern "C" int xq_prof_collect_kind(int kind, double *ms_total, int *launches, d
     if (work_total) *work_total = work;
     return XQ_OK;
 }
+// per-launch view of one kind: fills ms[i] / work[i] for up to `cap` recorded launches in launch order, returns how many there are
+// (tools/prof_gemm_shapes.py groups them by their algorithmic work = by shape)
+extern "C" int xq_prof_entries(int kind, double *ms_out, double *work_out, int cap) {
+    int n = 0;
+    for (int i = 0; i < g_prof_n; ++i) {
+        if (g_prof_kind[i] != kind) continue;
+        if (n < cap && ms_out && work_out) {
+            float ms = 0.f;
+            if (hipEventSynchronize(g_prof_ev[i][1]) != hipSuccess || hipEventElapsedTime(&ms, g_prof_ev[i][0], g_prof_ev[i][1]) != hipSuccess) {
+                xq_set_error(XQ_ELAUNCH, "%s", "xq_prof_entries: event query failed");
+                return -1;
+            }
+            ms_out[n] = ms;
+            work_out[n] = g_prof_work[i];
+        }
+        ++n;
+    }
+    return n;
+}
 extern "C" int xq_prof_collect(double *assign_ms_total, int *assign_launches) {
     const int rc = xq_prof_collect_kind(XQ_PROF_ASSIGN, assign_ms_total, assign_launches, nullptr);
     g_prof_n = 0;

@@ -454,6 +454,9 @@ int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_
 int xq_prof_enable(int on);
 int xq_prof_collect_kind(int kind, double *ms_total, int *launches, double *work_total);
 int xq_prof_collect(double *assign_ms_total, int *assign_launches);
+/* per-launch (milliseconds, algorithmic work) of the recorded launches of `kind`, in launch order, up to cap entries; returns the
+ * number of recorded launches of that kind (may exceed cap), -1 on an event error */
+int xq_prof_entries(int kind, double *ms_out, double *work_out, int cap);
 /* adds `delta` (may be negative) to the algorithmic work recorded for the most recent launch of `kind`: for launches that run
  * zero-padded operands (conv1_1 data gradient: 3 input channels padded to 64), so that only un-padded flops are reported */
 int xq_prof_add_work(int kind, double delta);
