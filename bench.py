@@ -297,6 +297,14 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    # eager time of the warmed-up step, measured BEFORE any capture (a replay must never follow an eager step: train.CapturedStep)
+    t_eager_pre = None
+    if args.workload == "train_step" and args.graph == "auto":
+        te = time.perf_counter()
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        t_eager_pre = (time.perf_counter() - te) / 3 * 1e3
     # hipGraph: record the complete step once, replay it in the timed region (same kernels, same buffers; torch's device RNG
     # advances per replay; nothing of the step is skipped).  The per-kernel HIP-event instrumentation is not part of the graph:
     # in graph mode the roofline timings come from PROF_STEPS instrumented eager steps run right after the timed region.
@@ -310,20 +318,18 @@ def main():
                 for _ in range(2):
                     captured.replay()
                 graph_note = "on (torch.cuda.CUDAGraph over the whole step: train.CapturedStep)"
-                if args.graph == "auto":
+                if args.graph == "auto" and t_eager_pre is not None:
                     # the replay is not a win for every config: the ladder configs launch thousands of sub-10-us kernels, which the
                     # graph executor of this ROCm release runs no faster (MSVR10P2: slower) than the eager stream — measure, then choose
-                    def _time(fn, n=3):
-                        torch.cuda.synchronize()
-                        t = time.perf_counter()
-                        for _ in range(n):
-                            fn()
-                        torch.cuda.synchronize()
-                        return (time.perf_counter() - t) / n * 1e3
-                    t_replay, t_eager = _time(captured.replay), _time(step)
-                    if t_eager < 0.99 * t_replay:
-                        graph_note = (f"off (auto: captured, but the eager step measured faster on this config: {t_eager:.1f} vs {t_replay:.1f} ms "
-                                      "over 3 steps each)")
+                    torch.cuda.synchronize()
+                    tr = time.perf_counter()
+                    for _ in range(3):
+                        captured.replay()
+                    torch.cuda.synchronize()
+                    t_replay = (time.perf_counter() - tr) / 3 * 1e3
+                    if t_eager_pre < 0.99 * t_replay:
+                        graph_note = (f"off (auto: captured, but the eager step measured faster on this config: {t_eager_pre:.1f} vs "
+                                      f"{t_replay:.1f} ms over 3 steps each)")
                         captured = None
             except Exception as e:  # noqa: BLE001
                 if args.graph == "on":

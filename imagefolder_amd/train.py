@@ -445,7 +445,12 @@ class CapturedStep:
     move to the device generator for a captured model: VQModel.device_dropout_rng),
     learning rates, and the quantizers' `record_hit` counters, i.e. which coefficient (0.9 during the first 100 updates, then 0.99:
     xqgan_model.py:779-785) the codebook-usage EMA uses — a statistic only, but capture after the first 100 steps if it is logged.
-    Single process only (collectives are not recorded): with world > 1 use the eager step."""
+    Single process only (collectives are not recorded): with world > 1 use the eager step.
+    Replays must not be interleaved with eager steps of the same TokenizerTrainStep: eager steps AFTER the last replay are fine, a replay
+    AFTER an eager step is refused (RuntimeError; capture again).  Measured in round 3 at B = 128: replay -> eager step -> replay ended
+    in a GPU memory access fault on one box and in a hang on another (profiles/r03_replay_after_eager.txt); replay-only and
+    replays-then-eager runs of the same build are clean.  The eager step replaces host-side objects whose device memory the recorded
+    kernels still address (gradient tensors adopted by autograd, per-step caches); the exact object was not located."""
 
     def __init__(self, ts: "TokenizerTrainStep", imgs: torch.Tensor, epoch=0, alpha=0.0, beta=0.0, delta=100, warmup: int = 2,
                  allow_frozen_host_rng: bool = False):
@@ -489,16 +494,21 @@ class CapturedStep:
                 disc.opt.arena.step_count, disc.global_step = d0
                 disc.opt.arena.epoch += 1
         self._disc = disc
+        self._expected_step = ts.arena.step_count      # host step count the next replay must find (see the class docstring)
 
     def replay(self, imgs: Optional[torch.Tensor] = None):
+        if self.ts.arena.step_count != self._expected_step:
+            raise RuntimeError("CapturedStep.replay: eager steps were taken since the capture / the last replay "
+                               f"(step count {self.ts.arena.step_count}, expected {self._expected_step}); capture the step again")
         if imgs is not None and imgs.data_ptr() != self.static_imgs.data_ptr():
             self.static_imgs.copy_(imgs, non_blocking=True)
-        # the device step counters follow the host ones (eager steps taken between replays, a loaded checkpoint): the graph adds 1
+        # the device step counters follow the host ones (a loaded checkpoint between capture and replay): the graph adds 1
         self.ts.opt._step_dev.fill_(float(self.ts.arena.step_count))
         if self._disc is not None:
             self._disc.opt._step_dev.fill_(float(self._disc.opt.arena.step_count))
         self.graph.replay()
         self.ts.arena.step_count += 1
+        self._expected_step += 1
         self.ts.arena.epoch += 1
         if self._disc is not None:
             self._disc.opt.arena.step_count += 1

@@ -169,6 +169,10 @@ def test_captured_step_trains_the_tiny_tokenizer_and_captures_quantizer_dropout(
     losses = [float(cap.replay(x)) for _ in range(30)]
     assert np.isfinite(losses).all() and np.mean(losses[-5:]) < np.mean(first)
     assert ts.arena.step_count == 3 + 1 + 30
+    # eager steps after the last replay are fine; a replay after an eager step is refused (train.CapturedStep docstring)
+    ts.step(x, 0, 0.0, 0.0, 10)
+    with pytest.raises(RuntimeError, match="capture the step again"):
+        cap.replay(x)
     # product quantizer x ladder with quantizer dropout (cfg 4 structure): the depths move to the device generator, so the capture
     # succeeds and successive replays see different depths (different losses on the same batch with a frozen learning rate of 0)
     md = tiny_model(P=2, pns=(1, 2, 3), L=9, drop=0.5).cuda().train()
