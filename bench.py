@@ -74,10 +74,12 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mfu", action="store_true", help="skip the FlopCounterMode pass (mfu = null)")
     p.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the links")
-    p.add_argument("--graph", default="auto", choices=["auto", "on", "off"],
-                   help="replay the train step from a hipGraph (train.CapturedStep): auto = single process (every BASELINE config captures: "
-                        "quantizer-dropout depths are drawn on the device for a captured model), falling back to the eager step if the "
-                        "capture fails")
+    p.add_argument("--graph", default="off", choices=["auto", "on", "off"],
+                   help="off (default): the eager step — the program every N > 1 run executes, and since round 3 level with the replay "
+                        "(profiles/r03_bench_configs.jsonl); on / auto: replay the step from a hipGraph (train.CapturedStep; every BASELINE "
+                        "config captures), auto keeping whichever of eager / replay measures faster and falling back to eager if the capture "
+                        "fails.  Not the default because hipGraph replays on this ROCm / PyTorch build are not robust to allocator activity "
+                        "between replays — even for a graph of ATen kernels only (tools/graph_alloc_probe.py, profiles/r03_replay_after_eager.txt)")
     return p.parse_args()
 
 
@@ -308,7 +310,7 @@ def main():
     # hipGraph: record the complete step once, replay it in the timed region (same kernels, same buffers; torch's device RNG
     # advances per replay; nothing of the step is skipped).  The per-kernel HIP-event instrumentation is not part of the graph:
     # in graph mode the roofline timings come from PROF_STEPS instrumented eager steps run right after the timed region.
-    captured, graph_note = None, "off"
+    captured, graph_note = None, "off (default: eager step; --graph on | auto replays it from a hipGraph)"
     if args.workload == "train_step" and args.graph != "off":
         if use_dist:
             graph_note = "off (collectives are not recorded: eager step with world > 1)"

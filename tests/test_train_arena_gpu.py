@@ -79,7 +79,7 @@ def test_bench_recovers_from_a_failed_hipgraph_capture():
     """bench.py --graph auto: when the capture of the train step fails half way, the process re-executes itself with --graph off
     (the invalidated capture state would otherwise kill the eager step that follows) and still prints its JSON line.
     The failure is injected from here: the step function is wrapped so that it raises while the stream is capturing."""
-    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-mfu"]
+    argv = ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-mfu", "--graph", "auto"]
     prog = (
         "import sys, torch\n"
         f"sys.path.insert(0, {ROOT!r})\n"
@@ -117,9 +117,10 @@ def test_bench_spawns_its_ranks_under_torch_distributed_run():
     assert res["mfu"] is not None and res["mfu"]["flops_per_image"] > 0      # counted after the process group was torn down
 
 
-def test_bench_replays_the_step_from_a_hipgraph_by_default():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--no-cpu-baseline", "--no-mfu"], capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    assert res["config"]["hip_graph"].startswith("on") and res["value"] > 0 and res["roofline"]["launches"] > 0
+def test_bench_replays_the_step_from_a_hipgraph_on_request_and_runs_eager_by_default():
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8", "--no-cpu-baseline", "--no-mfu"]
+    for extra, want in ((["--graph", "on"], "on"), ([], "off")):
+        out = subprocess.run(base + extra, capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert out.returncode == 0, out.stderr[-2000:]
+        res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert res["config"]["hip_graph"].startswith(want) and res["value"] > 0 and res["roofline"]["launches"] > 0
