@@ -370,6 +370,18 @@ def main():
             step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - te) / n_eager * 1e3
+    # the eager timed region carries the HIP-event instrumentation of the roofline leg (two event records around each of the ~700
+    # instrumented launches per step): the same step without it, for the record (not `value`)
+    plain_ms = None
+    if captured is None and args.workload == "train_step":
+        lib.xq_prof_enable(0)          # (keeps what the timed region recorded)
+        n_plain = min(args.steps, 10)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(n_plain):
+            step()
+        torch.cuda.synchronize()
+        plain_ms = (time.perf_counter() - tp) / n_plain * 1e3
     PROF_STEPS = 3
     prof_steps = args.steps
     if captured is not None:
@@ -433,6 +445,7 @@ def main():
                 "loss": args.loss,
                 "hip_graph": graph_note,
                 "hip_graph_eager_ms_per_step": eager_ms,
+                "eager_ms_per_step_without_roofline_events": plain_ms,
                 "roofline_timing": ("HIP events around every instrumented launch over the timed region" if captured is None else
                                     f"HIP events around every instrumented launch over {PROF_STEPS} eager steps of the same workload run "
                                     "right after the timed replays (the graph holds the same kernels without the event records)"),

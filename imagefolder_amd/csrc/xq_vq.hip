@@ -58,9 +58,9 @@ static int g_prof_kind[PROF_MAX];
 static double g_prof_work[PROF_MAX];
 static int g_prof_n = 0, g_prof_created = 0;
 
-extern "C" int xq_prof_enable(int on) {
+extern "C" int xq_prof_enable(int on) {     // 0: off (recorded launches stay collectable), 1: reset + arm, 2: arm, keeping what is recorded
     g_prof_on = on != 0;
-    g_prof_n = 0;
+    if (on == 1) g_prof_n = 0;
     return XQ_OK;
 }
 extern "C" int xq_prof_collect_kind(int kind, double *ms_total, int *launches, double *work_total) {

@@ -444,7 +444,7 @@ int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_
                     size_t workspace_bytes, int impl, xq_stream_t stream);
 
 /* ---- measurement hooks (bench.py): HIP events recorded around the instrumented hand-written kernels on the stream they
- *      are launched on.  xq_prof_enable(1) resets and arms; xq_prof_collect_kind synchronises the recorded events of one
+ *      are launched on.  xq_prof_enable(1) resets and arms, (0) disarms and keeps what was recorded, (2) arms without resetting; xq_prof_collect_kind synchronises the recorded events of one
  *      kernel kind and returns their summed duration, launch count and summed algorithmic work (flops) since arming;
  *      xq_prof_collect = the XQ_PROF_ASSIGN kind + reset (kept for older callers). ------------------------------------ */
 #define XQ_PROF_ASSIGN 0     /* assign_kernel: 2*N*Vpad*C flops per launch                                        */
