@@ -346,11 +346,21 @@ def main():
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
+    # roofline leg: HIP events around every instrumented launch, live inside the timed region — on every PROF_EVERY-th step (two event
+    # records around each of ~630 launches cost ~4.5 ms per instrumented step, 2.3 % of it: measured, profiles/r03_bench_default.json)
+    PROF_EVERY = 4
+    instrumented_steps = 0
     if captured is None:
         lib.xq_prof_enable(1)
+        lib.xq_prof_enable(0)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if captured is None and i % PROF_EVERY == 0:
+            lib.xq_prof_enable(2)             # arm without dropping the earlier records
+            instrumented_steps += 1
         run()
+        if captured is None and i % PROF_EVERY == 0:
+            lib.xq_prof_enable(0)
         if use_dist and args.workload == "train_step":
             ts.reducer.collect_exposed_ms()   # (elapsed_time of the previous step's events: no extra synchronisation)
     torch.cuda.synchronize()
@@ -370,8 +380,7 @@ def main():
             step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - te) / n_eager * 1e3
-    # the eager timed region carries the HIP-event instrumentation of the roofline leg (two event records around each of the ~700
-    # instrumented launches per step): the same step without it, for the record (not `value`)
+    # the same step with no event records at all, for the record (not `value`)
     plain_ms = None
     if captured is None and args.workload == "train_step":
         lib.xq_prof_enable(0)          # (keeps what the timed region recorded)
@@ -383,7 +392,7 @@ def main():
         torch.cuda.synchronize()
         plain_ms = (time.perf_counter() - tp) / n_plain * 1e3
     PROF_STEPS = 3
-    prof_steps = args.steps
+    prof_steps = max(1, instrumented_steps)
     if captured is not None:
         lib.xq_prof_enable(1)
         for _ in range(PROF_STEPS):
@@ -446,7 +455,8 @@ def main():
                 "hip_graph": graph_note,
                 "hip_graph_eager_ms_per_step": eager_ms,
                 "eager_ms_per_step_without_roofline_events": plain_ms,
-                "roofline_timing": ("HIP events around every instrumented launch over the timed region" if captured is None else
+                "roofline_timing": (f"HIP events around every instrumented launch of every {PROF_EVERY}th step of the timed region "
+                                    f"({instrumented_steps} of {args.steps} steps)" if captured is None else
                                     f"HIP events around every instrumented launch over {PROF_STEPS} eager steps of the same workload run "
                                     "right after the timed replays (the graph holds the same kernels without the event records)"),
                 "not_in_timed_region": ((None if args.loss == "full" else
