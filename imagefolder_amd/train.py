@@ -428,7 +428,12 @@ class TokenizerTrainStep:
         return loss_gen.detach()
 
     def capture(self, imgs, epoch=0, alpha=0.0, beta=0.0, delta=100, **kw) -> "CapturedStep":
-        """record this step into a hipGraph: see CapturedStep"""
+        """record this step into a hipGraph: see CapturedStep (and its caveat about allocator activity between replays)"""
+        import warnings
+        warnings.warn("CapturedStep: on ROCm 7.2 / PyTorch 2.10 a hipGraph replay that follows allocator activity (an eager step, a large "
+                      "allocation) has ended in illegal memory accesses — with a graph of ATen kernels only, in silently wrong values "
+                      "(profiles/r03_replay_after_eager.txt). Keep the replay loop allocation-free and validate what it computes.",
+                      RuntimeWarning, stacklevel=2)
         return CapturedStep(self, imgs, epoch, alpha, beta, delta, **kw)
 
 
@@ -450,7 +455,10 @@ class CapturedStep:
     AFTER an eager step is refused (RuntimeError; capture again).  Measured in round 3 at B = 128: replay -> eager step -> replay ended
     in a GPU memory access fault on one box and in a hang on another (profiles/r03_replay_after_eager.txt); replay-only and
     replays-then-eager runs of the same build are clean.  The eager step replaces host-side objects whose device memory the recorded
-    kernels still address (gradient tensors adopted by autograd, per-step caches); the exact object was not located."""
+    kernels still address (gradient tensors adopted by autograd, per-step caches); the exact object was not located — and the same
+    pattern breaks a graph of ATen kernels only (tools/graph_alloc_probe.py: silently wrong values after a 1 GiB allocation between two
+    replays), so this is a property of the hipGraph + caching-allocator stack, not of these kernels.  Keep the replay loop allocation-free
+    (replay(imgs) copies into the static input buffer; allocate `imgs` from a fixed pool, e.g. two pinned staging buffers)."""
 
     def __init__(self, ts: "TokenizerTrainStep", imgs: torch.Tensor, epoch=0, alpha=0.0, beta=0.0, delta=100, warmup: int = 2,
                  allow_frozen_host_rng: bool = False):
