@@ -153,3 +153,34 @@ def test_product_and_multiscale_tokens_equal_the_reference_indices(oracle, name)
     agree = (tok == g["tokens"]).mean(axis=1)
     print(f"{name}: end-to-end token agreement per image {agree.tolist()}")
     assert agree.min() >= (0.9 if multi else 0.97)
+
+
+def _pretok_worker(rank, world, port, cached):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    model = _FakeModel(P=1, pns=(2,))
+    # every rank tokenises its own shard of the "dataset" (pretokenization.py:150-239: DistributedSampler shards, per-rank json)
+    batches = [(torch.randn(3, 3, 8, 8), torch.tensor([10 * rank + 1, 10 * rank + 2, 10 * rank + 3]))]
+    out = tk.pretokenize(model, batches, cached, augment="flip")
+    assert os.path.basename(out) == "pretokenized.jsonl"
+    dist.destroy_process_group()
+
+
+def test_pretokenize_two_ranks_merge_into_one_jsonl(tmp_path):
+    """scripts/pretokenization.py:236-259 under two ranks (gloo): each rank dumps pretokenized_{rank}.json, rank 0 merges them into
+    pretokenized.jsonl after the barrier — 2 ranks x 3 images x 2 views = 12 records, both ranks' labels present."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_pretok_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["pretokenized.jsonl", "pretokenized_0.json", "pretokenized_1.json"]
+    lines = [json.loads(l) for l in open(os.path.join(tmp_path, "pretokenized.jsonl"))]
+    assert len(lines) == 12
+    assert sorted(set(r["class_id"] for r in lines)) == [1, 2, 3, 11, 12, 13]
+    assert all(len(r["tokens"]) == 4 for r in lines)
+    c, t = tk.read_jsonl_record(os.path.join(tmp_path, "pretokenized.jsonl"), 7)
+    assert t.dtype == torch.int64 and t.numel() == 4
