@@ -7,9 +7,6 @@ import torch.nn.functional as F
 import torch.distributed as dist
 
 
-BLAS_FREE_ON_GPU = __import__("os").environ.get("XQ_CLIPLOSS_BLAS", "0") != "1"
-
-
 class ClipLoss(nn.Module):
     def __init__(self, local_loss=False, gather_with_grad=False, cache_labels=False, rank=0, world_size=1, use_horovod=False):
         super().__init__()
@@ -46,12 +43,6 @@ class ClipLoss(nn.Module):
                 gi[self.rank], gt[self.rank] = image_features, text_features
                 all_i, all_t = torch.cat(gi, dim=0), torch.cat(gt, dim=0)
             logits_per_image = logit_scale * all_i @ all_t.T
-            logits_per_text = logits_per_image.T
-        elif image_features.is_cuda and BLAS_FREE_ON_GPU and image_features.shape[0] * text_features.shape[0] * image_features.shape[1] <= (1 << 24):
-            # (B, C) x (C, B) with B <= 1024, C <= 64: a broadcast product + row sums instead of a library GEMM.  Not for speed: the step
-            # then holds no hipBLASLt / rocBLAS call at all, whose workspaces are one suspect for hipGraph replays breaking after
-            # allocator activity on this stack (profiles/r03_replay_after_eager.txt)
-            logits_per_image = logit_scale * (image_features[:, None, :] * text_features[None, :, :]).sum(-1)
             logits_per_text = logits_per_image.T
         else:
             logits_per_image = logit_scale * image_features @ text_features.T
