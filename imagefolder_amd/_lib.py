@@ -117,6 +117,7 @@ SIGNATURES = {
     "xq_prof_collect_kind": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int),
                                             ctypes.POINTER(ctypes.c_double)]),
     "xq_prof_add_work": (ctypes.c_int, [ctypes.c_int, ctypes.c_double]),
+    "xq_gemm_trace_bind": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int]),
     "xq_prof_entries": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
     "xq_prof_marker": (ctypes.c_int, [ctypes.c_int, vp]),
 }

@@ -82,6 +82,8 @@ struct GemmArgs {
                             // 0 = default (two; or timed per shape under XQ_GEMM_TUNE=1: pick_phases below).  Bit-identical results.
                             // XQ_GEMM_TWO_PHASE / XQ_GEMM_FOUR_PHASE force one.
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
+    unsigned long long *trace;   // XQ_GEMM_TRACE (diagnostics): s_memtime stamps of the phases of workgroup trace_block's first item,
+    int trace_cap, trace_block;  // [8 waves][trace_cap] (layout: xq_gemm_trace_bind in include/xq_ops.h); null = off
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
                             // ONE range of g / x rows through its L2 for all of that range's output tiles; tile-major order (0, the
@@ -571,9 +573,36 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int AK, int BK, int ACT, int PH = 4>
+template <int AK, int BK, int ACT, int PH = 4, int TRACE = 0>
 __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int WTN = 64;
+    // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 5 points of each phase (start, fragment
+    // reads landed, vmcnt wait over, 8 of the 16 MFMAs issued, all 16 issued — no stamp right behind the first barrier: the compiler's
+    // own lgkmcnt(0) in front of the first MFMA would wait for that clock read on the critical path); the waves of one
+    // workgroup keep the stamps of its first item's first 25 K tiles (LDS, upper half of the wave's epilogue staging area) and copy
+    // them out before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
+    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+    const bool tr_on = TRACE && g.trace != nullptr && (int)blockIdx.x == g.trace_block;
+    int tr_n = 0;
+    bool tr_first = true;
+#define PR_T(I)                                                   \
+    do {                                                          \
+        if (TRACE) {                                              \
+            __builtin_amdgcn_sched_barrier(0);                    \
+            ts[I] = __builtin_amdgcn_s_memtime();                 \
+            __builtin_amdgcn_sched_barrier(0);                    \
+        }                                                         \
+    } while (0)
+#define PR_T_KEEP()                                                                                              \
+    do {                                                                                                         \
+        if (TRACE) {                                                                                             \
+            if (tr_on && tr_first && tr_n < 50 && lane == 0) {                                                   \
+                _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_)                                                 \
+                    *reinterpret_cast<unsigned long long *>(region + 2048 + (tr_n * 5 + i_) * 8) = ts[i_];       \
+            }                                                                                                    \
+            ++tr_n;                                                                                              \
+        }                                                                                                        \
+    } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 8 ring slots + 8 x 4 KiB epilogue staging
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -706,27 +735,39 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     } while (0)
 #define PR_TILE2()                                                            \
     do {                                                                      \
+        PR_T(0);                                                              \
         PR_READ_B(bl, 1)                                                      \
         PR_READ_B(br, 2)                                                      \
         PR_READ_A(0)                                                          \
         PR_STAGE(2);                                                          \
         PR_STAGE(3);                                                          \
         GR_LGKM0();                                                           \
+        PR_T(1);                                                              \
         GR_VMCNT(8);                                                          \
+        PR_T(2);                                                              \
         GR_BARRIER();                                                         \
         PR_MFMA(0, 0, bl);                                                    \
+        PR_T(3);                                                              \
         PR_MFMA(0, 1, br);                                                    \
+        PR_T(4);                                                              \
         GR_BARRIER();                                                         \
+        PR_T_KEEP();                                                          \
+        PR_T(0);                                                              \
         PR_READ_A(3)                                                          \
         PR_ADVANCE();                                                         \
         PR_STAGE(0);                                                          \
         PR_STAGE(1);                                                          \
         GR_LGKM0();                                                           \
+        PR_T(1);                                                              \
         GR_VMCNT(6);                                                          \
+        PR_T(2);                                                              \
         GR_BARRIER();                                                         \
         PR_MFMA(2, 1, br);                                                    \
+        PR_T(3);                                                              \
         PR_MFMA(2, 0, bl);                                                    \
+        PR_T(4);                                                              \
         GR_BARRIER();                                                         \
+        PR_T_KEEP();                                                          \
         r_par ^= 1;                                                           \
     } while (0)
 
@@ -749,6 +790,17 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         else { for (int kt = 0; kt < cit.KT; ++kt) PR_TILE(); }
         if (wr == 0) GR_BARRIER();
         if (!has_next) GR_VMCNT(0);      // the dummy pieces target `region`
+        if (TRACE) {
+            if (tr_on && tr_first && lane == 0) {
+                unsigned long long *out = g.trace + (long)wave * g.trace_cap;
+                const int n = (tr_n < 50 ? tr_n : 50) / 2;      // tr_n counts phases
+                out[0] = (unsigned long long)n;
+                out[1] = __builtin_amdgcn_s_memtime();
+                out[3] = (unsigned long long)cit.KT;
+                for (int i = 0; i < n * 10 && 4 + i < g.trace_cap; ++i)
+                    out[4 + i] = *reinterpret_cast<const unsigned long long *>(region + 2048 + i * 8);
+            }
+        }
 
         // ---- epilogue of this item (the next item's first pieces are landing meanwhile) ----
         if (cit.slab) {
@@ -858,11 +910,17 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                 }
             }
         }
+        if (TRACE) {
+            if (tr_on && tr_first && lane == 0) g.trace[(long)wave * g.trace_cap + 2] = __builtin_amdgcn_s_memtime();
+            tr_first = false;
+        }
         if (!has_next) break;
         PR_ZERO()
         cp += G;
         decode_item(g, cp, cit);
     }
+#undef PR_T
+#undef PR_T_KEEP
 #undef PR_TILE
 #undef PR_TILE2
 #undef GR_LGKM0
@@ -1015,6 +1073,14 @@ bool tuning_enabled() {
 
 template <int AK, int BK, int ACT>
 void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t s) {
+    if (g.trace) {      // diagnostics (XQ_GEMM_TRACE): the two-phase kernel with clock stamps; plain NT / NN / TN only
+        if (ACT == ACT_NONE && AK != gm::KMAJOR_CONV) {
+            constexpr int A2 = AK == gm::KMAJOR_CONV ? (int)gm::KMAJOR : AK;
+            if (set_lds<gemm_pring_kernel<A2, BK, ACT_NONE, 2, 1>>(lds)) return;
+            hipLaunchKernelGGL((gemm_pring_kernel<A2, BK, ACT_NONE, 2, 1>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+            return;
+        }
+    }
     if (phases == 4) hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 4>), dim3((unsigned)grid), dim3(GT), lds, s, g);
     else hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 2>), dim3((unsigned)grid), dim3(GT), lds, s, g);
 }
@@ -1109,6 +1175,13 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
     return xq_check_launch(fn);
 }
 
+// XQ_GEMM_TRACE target (xq_gemm_trace_bind)
+unsigned long long *g_trace_buf = nullptr;
+int g_trace_cap = 0, g_trace_block = 0;
+void bind_trace(GemmArgs &g, int impl) {
+    if ((impl & XQ_GEMM_TRACE) && g_trace_buf && g_trace_cap >= 8) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block; }
+}
+
 int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
     if (M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
     if (K < 64 || K % 64 || N % 8 || N < 32)
@@ -1121,6 +1194,14 @@ int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
 // ---------------------------------------------------------------------------------------------------------------------
 // C-ABI
 // ---------------------------------------------------------------------------------------------------------------------
+extern "C" int xq_gemm_trace_bind(void *buf, int cap_per_wave, int workgroup) {
+    if (buf && cap_per_wave < 8) return xq_set_error(XQ_EINVAL, "xq_gemm_trace_bind: cap_per_wave < 8");
+    g_trace_buf = (unsigned long long *)buf;
+    g_trace_cap = buf ? cap_per_wave : 0;
+    g_trace_block = workgroup;
+    return XQ_OK;
+}
+
 extern "C" size_t xq_gemm_bf16_workspace_bytes(int op, int64_t M, int64_t N, int64_t K) {
     if (M <= 0 || N <= 0 || K < 0) return 0;
     // enough for either tile width (the XQ_GEMM_WIDE_TILES bit may force 256-column tiles)
@@ -1147,6 +1228,7 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
+    bind_trace(g, impl);
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1165,6 +1247,7 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
+    bind_trace(g, impl);
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1184,9 +1267,11 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     const int BN = pick_bn(Q, impl);
     const int tile_major_debug = (impl & XQ_GEMM_TILE_MAJOR) ? 1 : 0;
     const int phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
+    const int impl_bits = impl;
     impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
+    bind_trace(g, impl_bits);
     g.A = (const char *)g_y; g.B = (const char *)x; g.C = (char *)ws;
     g.M = P; g.N = Q; g.lda = P; g.ldb = Q; g.ldc = Q;
     g.tiles_m = (int)((P + 255) / 256); g.tiles_n = (int)((Q + BN - 1) / BN);

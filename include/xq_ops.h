@@ -397,10 +397,18 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_FOUR_PHASE 0x4000 /* OR-ed into impl (persistent schedule): force 4 phases of 8 MFMAs per K tile (the round-2 schedule).  With neither
                                      bit: two phases (measured never slower, profiles/r03_gemm_schedules_v3.txt); XQ_GEMM_TUNE=1 in the environment
                                      times both on the first call of a shape and keeps the faster one.  Bit-identical results either way */
+#define XQ_GEMM_TRACE 0x8000      /* OR-ed into impl (NT / NN / TN, persistent schedule): run the two-phase kernel with shader-clock stamps into the
+                                     buffer bound by xq_gemm_trace_bind (diagnostics; results unchanged) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2
 #define XQ_PROF_GEMM 4       /* gemm_*_kernel: 2*M*N*K flops per launch (xq_prof_collect_kind)                               */
+/* diagnostics (no reference counterpart): where the stamps of XQ_GEMM_TRACE launches go.  buf = device memory, uint64 [8 waves][cap_per_wave];
+ * the 8 waves of workgroup `workgroup` record their first work item: [0] = K tiles recorded (<= 25), [1] = clock at the end of the K
+ * loop, [2] = clock at the end of the epilogue, [3] = K tiles of the item, [4 + 10 t + i] = clock at point i of K tile t
+ * (i = 0..4 first phase, 5..9 second phase: phase start, fragment reads landed + DMA issued, vmcnt wait over, first 8 MFMAs of the
+ * segment issued, all 16 issued).  buf = NULL unbinds.  tools/gemm_timeline.py prints the timeline. */
+int xq_gemm_trace_bind(void *buf, int cap_per_wave, int workgroup);
 /* bytes of workspace for op (XQ_GEMM_OP_*) at output rows M, columns N, reduction depth K (TN: M = P, N = Q, K = R);
  * NT / NN run without one (workspace NULL: no K-split of the tail tiles). */
 size_t xq_gemm_bf16_workspace_bytes(int op, int64_t M, int64_t N, int64_t K);

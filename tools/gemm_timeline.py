@@ -1,0 +1,177 @@
+"""Phase timeline of the persistent two-phase GEMM kernel (csrc/xq_gemm.hip, gemm_pring_kernel<.., PH = 2, TRACE = 1>): the 8 waves of one
+workgroup stamp the shader clock (s_memtime) at five points of every phase of their first work item; this tool runs the ViT-B layer
+shapes with XQ_GEMM_TRACE, reads the stamps back and prints where a K tile's cycles go:
+
+    reads   phase start -> fragment reads landed (ds_read_b128 / ds_read_b64_tr_b16) + this phase's 4 LDS-DMA instructions issued
+    vmcnt   -> counted s_waitcnt vmcnt over (the pieces the NEXT phase reads have landed)
+    bar1+8  -> first barrier passed and the first 8 v_mfma_f32_32x32x16_bf16 of the segment issued
+    mfma8   -> the other 8 issued (256 cycles when the matrix pipe is this wave's alone); bar1 wait ~ (bar1+8) - mfma8
+    bar2    -> second barrier passed (= next phase start)
+
+plus, for the SIMD shared by waves w and w + 4 (wave rows 0 and 1), how much of the traced span its matrix pipe was inside either
+wave's MFMA segment.  tick = shader cycle (MI355X_MICROARCH.md); the stamps cost the traced workgroup a few % (the other workgroups
+run the same code, their unused clock reads are dropped by the compiler).
+
+    python tools/gemm_timeline.py [--rows 65664] [--layers qkv fc1] [--ops nt nn tn] [--block 37] [--out gpurun_out/gemm_timeline.txt]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from imagefolder_amd import _lib, ops_dense as od  # noqa: E402
+
+TRACE = 0x8000 | 0x1000 | 3      # XQ_GEMM_TRACE | XQ_GEMM_TWO_PHASE | XQ_GEMM_PERSISTENT
+PLAIN = 0x1000 | 3
+CAP = 512
+SEG = ["reads", "vmcnt", "bar1+8", "mfma8", "bar2"]
+
+
+def timed(fn, iters=5):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def run_traced(fn, block):
+    buf = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
+    rc = _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), CAP, block)
+    assert rc == 0
+    od.GEMM_SCHEDULE = TRACE
+    try:
+        fn()
+        torch.cuda.synchronize()
+    finally:
+        od.GEMM_SCHEDULE = 0
+        _lib.lib().xq_gemm_trace_bind(None, 0, 0)
+    return buf.cpu().numpy()
+
+
+def analyse(tr, emit, label):
+    n = int(tr[0, 0])
+    if n < 4:
+        emit(f"  {label}: only {n} K tiles recorded (workgroup without a long enough first item?)")
+        return
+    kt = int(tr[0, 3])
+    st = np.stack([tr[w, 4:4 + n * 10].reshape(n * 2, 5) for w in range(8)]).astype(np.int64)     # [wave][phase][point]
+    t0 = st[:, 0, 0].min()
+    st = st - t0
+    ph = st.shape[1]
+    nxt = np.concatenate([st[:, 1:, 0], st[:, -1:, 4]], axis=1)         # next phase start (last: no bar2 figure)
+    seg = np.stack([st[:, :, 1] - st[:, :, 0], st[:, :, 2] - st[:, :, 1], st[:, :, 3] - st[:, :, 2], st[:, :, 4] - st[:, :, 3],
+                    nxt - st[:, :, 4]], axis=2)                        # [wave][phase][5]
+    steady = slice(4, ph - 1)                                           # skip the first two K tiles and the last phase
+    emit(f"  {label}: item of {kt} K tiles, {n} recorded; cycles per PHASE (8 MFMAs = 256 at full rate), steady-state mean [min..max]")
+    emit(f"    {'wave (row, col)':18s}" + "".join(f"{s:>22s}" for s in SEG) + f"{'phase':>10s}")
+    for w in range(8):
+        s = seg[w, steady]
+        cells = "".join(f"{s[:, i].mean():9.0f} [{s[:, i].min():4d}..{s[:, i].max():5d}]" for i in range(5))
+        emit(f"    wave {w} ({w >> 2}, {w & 3})     {cells}{s.sum(axis=1).mean():10.0f}")
+    per_tile = float(st[0, ph - 2, 0] - st[0, 4, 0]) / ((ph - 2 - 4) / 2.0)
+    emit(f"    K tile period {per_tile:7.0f} cycles  ->  MFMA-pipe utilisation {2048 / per_tile:5.2f} "
+         f"(2 waves x 32 MFMAs x 32 cycles per SIMD and K tile = 2048)")
+    # per SIMD pair (w, w + 4): union of the MFMA segments
+    for w in range(4):
+        # MFMA segment of a phase ~ [T3 - (T4 - T3), T4]: the first 8 MFMAs taken at the rate of the last 8
+        iv = sorted([(int(2 * st[x, p, 3] - st[x, p, 4]), int(st[x, p, 4])) for x in (w, w + 4) for p in range(4, ph - 1)])
+        lo, hi = iv[0][0], max(e for _, e in iv)
+        busy, cur_s, cur_e, overlap = 0, iv[0][0], iv[0][1], 0
+        for s_, e_ in iv[1:]:
+            if s_ <= cur_e:
+                overlap += min(cur_e, e_) - s_
+                cur_e = max(cur_e, e_)
+            else:
+                busy += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+        busy += cur_e - cur_s
+        emit(f"    waves {w} + {w + 4}: inside an MFMA segment {busy / (hi - lo):5.2f} of the span, both at once {overlap / (hi - lo):5.2f}")
+    # raw timeline of two K tiles for wave rows 0 and 1 (waves 0 and 4)
+    emit("    timeline, K tiles 3-4 (cycles since the first stamp): point = start / reads landed / vmcnt over / 8 MFMAs issued / 16 issued")
+    for p in range(6, 10):
+        emit(f"      phase {p:2d}   wave0 " + " ".join(f"{int(v):7d}" for v in st[0, p]) + "   | wave4 " + " ".join(f"{int(v):7d}" for v in st[4, p]))
+    ep = (tr[:, 2] - tr[:, 1]).astype(np.int64)
+    emit(f"    epilogue (K loop end -> stores issued, incl. the trace copy-out): {ep.min()} .. {ep.max()} cycles per wave")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=65664)
+    ap.add_argument("--dim", type=int, default=768)
+    ap.add_argument("--layers", nargs="*", default=["qkv", "fc1"])
+    ap.add_argument("--ops", nargs="*", default=["nt", "nn", "tn"])
+    ap.add_argument("--block", type=int, default=37)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    lines = []
+    raws = {}
+
+    def emit(s):
+        print(s, flush=True)
+        lines.append(s)
+
+    D, M = a.dim, a.rows
+    layers = {"qkv": (3 * D, D), "proj": (D, D), "fc1": (4 * D, D), "fc2": (D, 4 * D)}
+    emit(f"# gemm_pring_kernel<.., PH = 2, TRACE = 1>, workgroup {a.block}, M = {M} tokens; {torch.cuda.get_device_name(0)}")
+    for name in a.layers:
+        N, K = layers[name]
+        x = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(N, K, device="cuda") * 0.03).to(torch.bfloat16)
+        g = torch.randn(M, N, device="cuda").to(torch.bfloat16)
+        bias = torch.randn(N, device="cuda")
+        cases = {"nt": (lambda: od.gemm_nt(x, w, bias), 2.0 * M * N * K, f"NT forward y[{M},{N}] = x[{M},{K}] w^T"),
+                 "nn": (lambda: od.gemm_nn(g, w), 2.0 * M * N * K, f"NN data gradient gx[{M},{K}] = g[{M},{N}] w"),
+                 "tn": (lambda: od.gemm_tn(g, x), 2.0 * M * N * K, f"TN weight gradient gW[{N},{K}] = g^T x")}
+        for op in a.ops:
+            fn, fl, desc = cases[op]
+
+            def plain(fn=fn):
+                od.GEMM_SCHEDULE = PLAIN
+                try:
+                    fn()
+                finally:
+                    od.GEMM_SCHEDULE = 0
+
+            def traced(fn=fn):
+                od.GEMM_SCHEDULE = TRACE
+                try:
+                    fn()
+                finally:
+                    od.GEMM_SCHEDULE = 0
+            ms = timed(plain)
+            emit(f"\n## {name} {desc}: {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s untraced")
+            od.GEMM_SCHEDULE = PLAIN
+            ref = fn()
+            od.GEMM_SCHEDULE = TRACE
+            buf0 = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
+            _lib.lib().xq_gemm_trace_bind(buf0.data_ptr(), CAP, a.block)
+            got = fn()
+            od.GEMM_SCHEDULE = 0
+            _lib.lib().xq_gemm_trace_bind(None, 0, 0)
+            emit(f"  traced kernel output bit-identical to the untraced one: {bool(torch.equal(ref, got))}")
+            del ref, got
+            tr = run_traced(fn, a.block)
+            raws[f"{name}_{op}"] = tr
+            buf = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
+            _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), CAP, a.block)
+            ms_t = timed(traced)
+            _lib.lib().xq_gemm_trace_bind(None, 0, 0)
+            emit(f"  traced build: {ms_t:.3f} ms ({(ms_t / ms - 1) * 100:+.1f} %)")
+            analyse(tr, emit, f"{name} {op}")
+    if a.out:
+        os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
+        np.savez_compressed(os.path.splitext(a.out)[0] + "_raw.npz", **raws)
+        with open(a.out, "w") as f:
+            f.write("\n".join(lines) + "\n")
+
+
+if __name__ == "__main__":
+    main()
