@@ -84,6 +84,7 @@ struct GemmArgs {
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
     unsigned long long *trace;   // XQ_GEMM_TRACE (diagnostics): s_memtime stamps of the phases of workgroup trace_block's first item,
     int trace_cap, trace_block;  // [8 waves][trace_cap] (layout: xq_gemm_trace_bind in include/xq_ops.h); null = off
+    int variant;                 // VAR bits 2 / 4 of gemm_pring_kernel (XQ_GEMM_NO_SEGMENT_PRIO / XQ_GEMM_ROW1_PRIO)
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
                             // ONE range of g / x rows through its L2 for all of that range's output tiles; tile-major order (0, the
@@ -573,9 +574,14 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int AK, int BK, int ACT, int PH = 4, int TRACE = 0>
+template <int AK, int BK, int ACT, int PH = 4, int VAR = 0>
 __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int WTN = 64;
+    // VAR bits (diagnostics / A-B, PH = 2): 1 = clock stamps (XQ_GEMM_TRACE), 2 = no s_setprio around the MFMA segments
+    // (XQ_GEMM_NO_SEGMENT_PRIO), 4 = wave row 1 at priority 1 for the whole kernel (XQ_GEMM_ROW1_PRIO; with bit 2)
+    constexpr int TRACE = VAR & 1;
+    constexpr bool SEG_PRIO = !(VAR & 2);
+    constexpr bool ROW1_PRIO = (VAR & 4) != 0;
     // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 5 points of each phase (start, fragment
     // reads landed, vmcnt wait over, 8 of the 16 MFMAs issued, all 16 issued — no stamp right behind the first barrier: the compiler's
     // own lgkmcnt(0) in front of the first MFMA would wait for that clock read on the critical path); the waves of one
@@ -679,14 +685,14 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     do {                                                                                                               \
         PR_PIN(acc[FI0][FJ]);                                                                                          \
         PR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
-        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        if (SEG_PRIO) __builtin_amdgcn_s_setprio(1);                                                                   \
         _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                             \
             acc[FI0][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[0][s_], acc[FI0][FJ], 0, 0, 0);         \
             acc[FI0 + 1][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[1][s_], acc[FI0 + 1][FJ], 0, 0, 0); \
         }                                                                                                              \
         PR_PIN(acc[FI0][FJ]);                                                                                          \
         PR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
-        __builtin_amdgcn_s_setprio(0);                                                                                 \
+        if (SEG_PRIO) __builtin_amdgcn_s_setprio(0);                                                                   \
     } while (0)
     // one K tile (phases as in gemm_ring_kernel): always one piece staged per phase, always vmcnt(8)
 #define PR_TILE()                                                             \
@@ -783,6 +789,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     GR_BARRIER();
 
     const int h = lane >> 5;
+    if (ROW1_PRIO && wr == 1) __builtin_amdgcn_s_setprio(1);
     for (;;) {
         const bool has_next = cp + G < items;
         if (wr == 1) GR_BARRIER();
@@ -1073,12 +1080,20 @@ bool tuning_enabled() {
 
 template <int AK, int BK, int ACT>
 void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t s) {
-    if (g.trace) {      // diagnostics (XQ_GEMM_TRACE): the two-phase kernel with clock stamps; plain NT / NN / TN only
+    if (g.trace || g.variant) {      // diagnostics / A-B (XQ_GEMM_TRACE, XQ_GEMM_NO_SEGMENT_PRIO, XQ_GEMM_ROW1_PRIO): two phases, plain NT / NN / TN only
         if (ACT == ACT_NONE && AK != gm::KMAJOR_CONV) {
             constexpr int A2 = AK == gm::KMAJOR_CONV ? (int)gm::KMAJOR : AK;
-            if (set_lds<gemm_pring_kernel<A2, BK, ACT_NONE, 2, 1>>(lds)) return;
-            hipLaunchKernelGGL((gemm_pring_kernel<A2, BK, ACT_NONE, 2, 1>), dim3((unsigned)grid), dim3(GT), lds, s, g);
-            return;
+            const int var = (g.trace ? 1 : 0) | g.variant;
+#define XQ_VAR_CASE(V)                                                                                                           \
+    case V:                                                                                                                      \
+        if (set_lds<gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>>(lds)) return;                                                     \
+        hipLaunchKernelGGL((gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>), dim3((unsigned)grid), dim3(GT), lds, s, g);              \
+        return;
+            switch (var) {
+                XQ_VAR_CASE(1) XQ_VAR_CASE(2) XQ_VAR_CASE(3) XQ_VAR_CASE(6) XQ_VAR_CASE(7)
+                default: break;
+            }
+#undef XQ_VAR_CASE
         }
     }
     if (phases == 4) hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 4>), dim3((unsigned)grid), dim3(GT), lds, s, g);
@@ -1179,6 +1194,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
 unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
 void bind_trace(GemmArgs &g, int impl) {
+    g.variant = (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
     if ((impl & XQ_GEMM_TRACE) && g_trace_buf && g_trace_cap >= 8) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block; }
 }
 

@@ -399,6 +399,8 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
                                      times both on the first call of a shape and keeps the faster one.  Bit-identical results either way */
 #define XQ_GEMM_TRACE 0x8000      /* OR-ed into impl (NT / NN / TN, persistent schedule): run the two-phase kernel with shader-clock stamps into the
                                      buffer bound by xq_gemm_trace_bind (diagnostics; results unchanged) */
+#define XQ_GEMM_NO_SEGMENT_PRIO 0x10000 /* OR-ed into impl (NT / NN / TN, persistent two-phase): no s_setprio around the MFMA segments (A/B) */
+#define XQ_GEMM_ROW1_PRIO 0x20000       /* ... and wave row 1 (waves 4-7) at priority 1 for the whole kernel instead (A/B) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2

@@ -27,6 +27,9 @@ from imagefolder_amd import _lib, ops_dense as od  # noqa: E402
 TRACE = 0x8000 | 0x1000 | 3      # XQ_GEMM_TRACE | XQ_GEMM_TWO_PHASE | XQ_GEMM_PERSISTENT
 PLAIN = 0x1000 | 3
 CAP = 512
+VARIANTS = [("segprio: s_setprio 1 around every MFMA segment (the default kernel)", 0),
+            ("noprio: no s_setprio at all", 0x10000),
+            ("row1prio: waves 4-7 at priority 1 for the whole kernel, no per-segment flips", 0x20000)]
 SEG = ["reads", "vmcnt", "bar1+8", "mfma8", "bar2"]
 
 
@@ -56,7 +59,7 @@ def run_traced(fn, block):
     return buf.cpu().numpy()
 
 
-def analyse(tr, emit, label):
+def analyse(tr, emit, label, brief=False):
     n = int(tr[0, 0])
     if n < 4:
         emit(f"  {label}: only {n} K tiles recorded (workgroup without a long enough first item?)")
@@ -72,7 +75,7 @@ def analyse(tr, emit, label):
     steady = slice(4, ph - 1)                                           # skip the first two K tiles and the last phase
     emit(f"  {label}: item of {kt} K tiles, {n} recorded; cycles per PHASE (8 MFMAs = 256 at full rate), steady-state mean [min..max]")
     emit(f"    {'wave (row, col)':18s}" + "".join(f"{s:>22s}" for s in SEG) + f"{'phase':>10s}")
-    for w in range(8):
+    for w in ([0, 4] if brief else range(8)):
         s = seg[w, steady]
         cells = "".join(f"{s[:, i].mean():9.0f} [{s[:, i].min():4d}..{s[:, i].max():5d}]" for i in range(5))
         emit(f"    wave {w} ({w >> 2}, {w & 3})     {cells}{s.sum(axis=1).mean():10.0f}")
@@ -80,7 +83,7 @@ def analyse(tr, emit, label):
     emit(f"    K tile period {per_tile:7.0f} cycles  ->  MFMA-pipe utilisation {2048 / per_tile:5.2f} "
          f"(2 waves x 32 MFMAs x 32 cycles per SIMD and K tile = 2048)")
     # per SIMD pair (w, w + 4): union of the MFMA segments
-    for w in range(4):
+    for w in range(1 if brief else 4):
         # MFMA segment of a phase ~ [T3 - (T4 - T3), T4]: the first 8 MFMAs taken at the rate of the last 8
         iv = sorted([(int(2 * st[x, p, 3] - st[x, p, 4]), int(st[x, p, 4])) for x in (w, w + 4) for p in range(4, ph - 1)])
         lo, hi = iv[0][0], max(e for _, e in iv)
@@ -110,6 +113,9 @@ def main():
     ap.add_argument("--ops", nargs="*", default=["nt", "nn", "tn"])
     ap.add_argument("--block", type=int, default=37)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--variants", nargs="*", default=None, help="subset of segprio noprio row1prio")
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--brief", action="store_true", help="two waves per table for the non-default variants")
     a = ap.parse_args()
     lines = []
     raws = {}
@@ -132,40 +138,42 @@ def main():
                  "tn": (lambda: od.gemm_tn(g, x), 2.0 * M * N * K, f"TN weight gradient gW[{N},{K}] = g^T x")}
         for op in a.ops:
             fn, fl, desc = cases[op]
-
-            def plain(fn=fn):
-                od.GEMM_SCHEDULE = PLAIN
-                try:
-                    fn()
-                finally:
-                    od.GEMM_SCHEDULE = 0
-
-            def traced(fn=fn):
-                od.GEMM_SCHEDULE = TRACE
-                try:
-                    fn()
-                finally:
-                    od.GEMM_SCHEDULE = 0
-            ms = timed(plain)
-            emit(f"\n## {name} {desc}: {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s untraced")
+            emit(f"\n## {name} {desc}")
             od.GEMM_SCHEDULE = PLAIN
             ref = fn()
-            od.GEMM_SCHEDULE = TRACE
-            buf0 = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
-            _lib.lib().xq_gemm_trace_bind(buf0.data_ptr(), CAP, a.block)
-            got = fn()
             od.GEMM_SCHEDULE = 0
-            _lib.lib().xq_gemm_trace_bind(None, 0, 0)
-            emit(f"  traced kernel output bit-identical to the untraced one: {bool(torch.equal(ref, got))}")
-            del ref, got
-            tr = run_traced(fn, a.block)
-            raws[f"{name}_{op}"] = tr
-            buf = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
-            _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), CAP, a.block)
-            ms_t = timed(traced)
-            _lib.lib().xq_gemm_trace_bind(None, 0, 0)
-            emit(f"  traced build: {ms_t:.3f} ms ({(ms_t / ms - 1) * 100:+.1f} %)")
-            analyse(tr, emit, f"{name} {op}")
+            for vname, bits in VARIANTS:
+                if a.variants and vname.split()[0] not in a.variants:
+                    continue
+
+                def plain(fn=fn, bits=bits):
+                    od.GEMM_SCHEDULE = PLAIN | bits
+                    try:
+                        return fn()
+                    finally:
+                        od.GEMM_SCHEDULE = 0
+
+                def traced(fn=fn, bits=bits):
+                    od.GEMM_SCHEDULE = TRACE | bits
+                    try:
+                        return fn()
+                    finally:
+                        od.GEMM_SCHEDULE = 0
+                ms = timed(plain, a.iters)
+                buf = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
+                _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), CAP, a.block)
+                got = traced()
+                torch.cuda.synchronize()
+                tr = buf.cpu().numpy()
+                ms_t = timed(traced, a.iters)
+                _lib.lib().xq_gemm_trace_bind(None, 0, 0)
+                same = bool(torch.equal(ref, got)) and bool(torch.equal(ref, plain()))
+                emit(f"  [{vname}] {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s untraced; with stamps {ms_t:.3f} ms ({(ms_t / ms - 1) * 100:+.1f} %); "
+                     f"outputs bit-identical to the default kernel: {same}")
+                del got
+                raws[f"{name}_{op}_{vname.split()[0]}"] = tr
+                analyse(tr, emit, f"{name} {op} [{vname}]", brief=a.brief and bits != 0)
+            del ref
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         np.savez_compressed(os.path.splitext(a.out)[0] + "_raw.npz", **raws)
