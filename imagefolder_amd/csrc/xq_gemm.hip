@@ -582,12 +582,13 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int TRACE = VAR & 1;
     constexpr bool SEG_PRIO = !(VAR & 2);
     constexpr bool ROW1_PRIO = (VAR & 4) != 0;
-    // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 5 points of each phase (start, fragment
-    // reads landed, vmcnt wait over, 8 of the 16 MFMAs issued, all 16 issued — no stamp right behind the first barrier: the compiler's
-    // own lgkmcnt(0) in front of the first MFMA would wait for that clock read on the critical path); the waves of one
-    // workgroup keep the stamps of its first item's first 25 K tiles (LDS, upper half of the wave's epilogue staging area) and copy
-    // them out before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
-    unsigned long long ts[5] = {0, 0, 0, 0, 0};
+    // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 7 points of each phase (0 phase start,
+    // 1 fragment reads issued, 2 LDS-DMA issued, 3 lgkmcnt(0) over, 4 vmcnt wait over, 5 eight of the 16 MFMAs issued, 6 all 16 issued
+    // — no stamp right behind the first barrier: the compiler's own lgkmcnt(0) in front of the first MFMA would wait for that clock
+    // read on the critical path); the waves of one workgroup keep the stamps of its first item's first 36 phases (LDS, upper half of the
+    // wave's epilogue staging area; written in front of the first barrier, so a record holds points 0-4 of its phase and points 5-6 of
+    // the phase before) and copy them out before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
+    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
     const bool tr_on = TRACE && g.trace != nullptr && (int)blockIdx.x == g.trace_block;
     int tr_n = 0;
     bool tr_first = true;
@@ -602,9 +603,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #define PR_T_KEEP()                                                                                              \
     do {                                                                                                         \
         if (TRACE) {                                                                                             \
-            if (tr_on && tr_first && tr_n < 50 && lane == 0) {                                                   \
-                _Pragma("unroll") for (int i_ = 0; i_ < 5; ++i_)                                                 \
-                    *reinterpret_cast<unsigned long long *>(region + 2048 + (tr_n * 5 + i_) * 8) = ts[i_];       \
+            if (tr_on && tr_first && tr_n < 36 && lane == 0) {                                                   \
+                _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_)                                                 \
+                    *reinterpret_cast<unsigned long long *>(region + 2048 + (tr_n * 7 + i_) * 8) = ts[i_];       \
             }                                                                                                    \
             ++tr_n;                                                                                              \
         }                                                                                                        \
@@ -745,35 +746,39 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         PR_READ_B(bl, 1)                                                      \
         PR_READ_B(br, 2)                                                      \
         PR_READ_A(0)                                                          \
+        PR_T(1);                                                              \
         PR_STAGE(2);                                                          \
         PR_STAGE(3);                                                          \
-        GR_LGKM0();                                                           \
-        PR_T(1);                                                              \
-        GR_VMCNT(8);                                                          \
         PR_T(2);                                                              \
+        GR_LGKM0();                                                           \
+        PR_T(3);                                                              \
+        GR_VMCNT(8);                                                          \
+        PR_T(4);                                                              \
+        PR_T_KEEP();                                                          \
         GR_BARRIER();                                                         \
         PR_MFMA(0, 0, bl);                                                    \
-        PR_T(3);                                                              \
+        PR_T(5);                                                              \
         PR_MFMA(0, 1, br);                                                    \
-        PR_T(4);                                                              \
+        PR_T(6);                                                              \
         GR_BARRIER();                                                         \
-        PR_T_KEEP();                                                          \
         PR_T(0);                                                              \
         PR_READ_A(3)                                                          \
+        PR_T(1);                                                              \
         PR_ADVANCE();                                                         \
         PR_STAGE(0);                                                          \
         PR_STAGE(1);                                                          \
-        GR_LGKM0();                                                           \
-        PR_T(1);                                                              \
-        GR_VMCNT(6);                                                          \
         PR_T(2);                                                              \
+        GR_LGKM0();                                                           \
+        PR_T(3);                                                              \
+        GR_VMCNT(6);                                                          \
+        PR_T(4);                                                              \
+        PR_T_KEEP();                                                          \
         GR_BARRIER();                                                         \
         PR_MFMA(2, 1, br);                                                    \
-        PR_T(3);                                                              \
+        PR_T(5);                                                              \
         PR_MFMA(2, 0, bl);                                                    \
-        PR_T(4);                                                              \
+        PR_T(6);                                                              \
         GR_BARRIER();                                                         \
-        PR_T_KEEP();                                                          \
         r_par ^= 1;                                                           \
     } while (0)
 
@@ -800,11 +805,11 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         if (TRACE) {
             if (tr_on && tr_first && lane == 0) {
                 unsigned long long *out = g.trace + (long)wave * g.trace_cap;
-                const int n = (tr_n < 50 ? tr_n : 50) / 2;      // tr_n counts phases
+                const int n = tr_n < 36 ? tr_n : 36;      // phases
                 out[0] = (unsigned long long)n;
                 out[1] = __builtin_amdgcn_s_memtime();
                 out[3] = (unsigned long long)cit.KT;
-                for (int i = 0; i < n * 10 && 4 + i < g.trace_cap; ++i)
+                for (int i = 0; i < n * 7 && 4 + i < g.trace_cap; ++i)
                     out[4 + i] = *reinterpret_cast<const unsigned long long *>(region + 2048 + i * 8);
             }
         }

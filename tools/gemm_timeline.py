@@ -2,14 +2,16 @@
 workgroup stamp the shader clock (s_memtime) at five points of every phase of their first work item; this tool runs the ViT-B layer
 shapes with XQ_GEMM_TRACE, reads the stamps back and prints where a K tile's cycles go:
 
-    reads   phase start -> fragment reads landed (ds_read_b128 / ds_read_b64_tr_b16) + this phase's 4 LDS-DMA instructions issued
-    vmcnt   -> counted s_waitcnt vmcnt over (the pieces the NEXT phase reads have landed)
-    bar1+8  -> first barrier passed and the first 8 v_mfma_f32_32x32x16_bf16 of the segment issued
-    mfma8   -> the other 8 issued (256 cycles when the matrix pipe is this wave's alone); bar1 wait ~ (bar1+8) - mfma8
-    bar2    -> second barrier passed (= next phase start)
+    rd-issue    phase start (second barrier of the phase before passed) -> the phase's fragment reads issued (16 or 8 ds_read_b128 /
+                twice as many ds_read_b64_tr_b16, with their address arithmetic)
+    dma-issue   -> the phase's 4 LDS-DMA instructions (global_load_lds_dwordx4) issued, with their address arithmetic
+    lgkm0       -> s_waitcnt lgkmcnt(0) over: the fragments have landed
+    vmcnt       -> counted s_waitcnt vmcnt over: the pieces the NEXT phase reads have landed
+    keep+bar1+8 -> (trace record written,) first barrier passed and the first 8 v_mfma_f32_32x32x16_bf16 of the segment issued
+    mfma8       -> the other 8 issued (256 cycles when the matrix pipe is this wave's alone)
+    bar2        -> second barrier passed (= next phase start)
 
-plus, for the SIMD shared by waves w and w + 4 (wave rows 0 and 1), how much of the traced span its matrix pipe was inside either
-wave's MFMA segment.  tick = shader cycle (MI355X_MICROARCH.md); the stamps cost the traced workgroup a few % (the other workgroups
+and the merged event list of waves 0 and 4 (one SIMD).  tick = shader cycle (MI355X_MICROARCH.md); the stamps cost the traced workgroup a few % (the other workgroups
 run the same code, their unused clock reads are dropped by the compiler).
 
     python tools/gemm_timeline.py [--rows 65664] [--layers qkv fc1] [--ops nt nn tn] [--block 37] [--out gpurun_out/gemm_timeline.txt]
@@ -30,7 +32,7 @@ CAP = 512
 VARIANTS = [("segprio: s_setprio 1 around every MFMA segment (the default kernel)", 0),
             ("noprio: no s_setprio at all", 0x10000),
             ("row1prio: waves 4-7 at priority 1 for the whole kernel, no per-segment flips", 0x20000)]
-SEG = ["reads", "vmcnt", "bar1+8", "mfma8", "bar2"]
+SEG = ["rd-issue", "dma-issue", "lgkm0", "vmcnt", "keep+bar1+8", "mfma8", "bar2"]
 
 
 def timed(fn, iters=5):
@@ -60,47 +62,35 @@ def run_traced(fn, block):
 
 
 def analyse(tr, emit, label, brief=False):
-    n = int(tr[0, 0])
-    if n < 4:
-        emit(f"  {label}: only {n} K tiles recorded (workgroup without a long enough first item?)")
+    n = int(tr[0, 0])                       # records = phases
+    if n < 10:
+        emit(f"  {label}: only {n} phases recorded (workgroup without a long enough first item?)")
         return
     kt = int(tr[0, 3])
-    st = np.stack([tr[w, 4:4 + n * 10].reshape(n * 2, 5) for w in range(8)]).astype(np.int64)     # [wave][phase][point]
-    t0 = st[:, 0, 0].min()
-    st = st - t0
+    rec = np.stack([tr[w, 4:4 + n * 7].reshape(n, 7) for w in range(8)]).astype(np.int64)     # [wave][record][point]
+    st = np.concatenate([rec[:, :-1, :5], rec[:, 1:, 5:7]], axis=2)     # points 5, 6 of phase p sit in record p + 1
+    st = st - st[:, 0, 0].min()
     ph = st.shape[1]
-    nxt = np.concatenate([st[:, 1:, 0], st[:, -1:, 4]], axis=1)         # next phase start (last: no bar2 figure)
-    seg = np.stack([st[:, :, 1] - st[:, :, 0], st[:, :, 2] - st[:, :, 1], st[:, :, 3] - st[:, :, 2], st[:, :, 4] - st[:, :, 3],
-                    nxt - st[:, :, 4]], axis=2)                        # [wave][phase][5]
-    steady = slice(4, ph - 1)                                           # skip the first two K tiles and the last phase
-    emit(f"  {label}: item of {kt} K tiles, {n} recorded; cycles per PHASE (8 MFMAs = 256 at full rate), steady-state mean [min..max]")
+    nxt = st[:, 1:, 0]
+    cur = st[:, :-1]
+    seg = np.stack([cur[:, :, 1] - cur[:, :, 0], cur[:, :, 2] - cur[:, :, 1], cur[:, :, 3] - cur[:, :, 2], cur[:, :, 4] - cur[:, :, 3],
+                    cur[:, :, 5] - cur[:, :, 4], cur[:, :, 6] - cur[:, :, 5], nxt - cur[:, :, 6]], axis=2)     # [wave][phase][7]
+    steady = slice(4, ph - 1)
+    emit(f"  {label}: item of {kt} K tiles, {ph} phases; cycles per PHASE (8 MFMAs = 256 at full rate), steady-state mean [min..max]")
     emit(f"    {'wave (row, col)':18s}" + "".join(f"{s:>22s}" for s in SEG) + f"{'phase':>10s}")
     for w in ([0, 4] if brief else range(8)):
-        s = seg[w, steady]
-        cells = "".join(f"{s[:, i].mean():9.0f} [{s[:, i].min():4d}..{s[:, i].max():5d}]" for i in range(5))
-        emit(f"    wave {w} ({w >> 2}, {w & 3})     {cells}{s.sum(axis=1).mean():10.0f}")
+        x = seg[w, steady]
+        cells = "".join(f"{x[:, i].mean():9.0f} [{x[:, i].min():4d}..{x[:, i].max():5d}]" for i in range(7))
+        emit(f"    wave {w} ({w >> 2}, {w & 3})     {cells}{x.sum(axis=1).mean():10.0f}")
     per_tile = float(st[0, ph - 2, 0] - st[0, 4, 0]) / ((ph - 2 - 4) / 2.0)
     emit(f"    K tile period {per_tile:7.0f} cycles  ->  MFMA-pipe utilisation {2048 / per_tile:5.2f} "
          f"(2 waves x 32 MFMAs x 32 cycles per SIMD and K tile = 2048)")
-    # per SIMD pair (w, w + 4): union of the MFMA segments
-    for w in range(1 if brief else 4):
-        # MFMA segment of a phase ~ [T3 - (T4 - T3), T4]: the first 8 MFMAs taken at the rate of the last 8
-        iv = sorted([(int(2 * st[x, p, 3] - st[x, p, 4]), int(st[x, p, 4])) for x in (w, w + 4) for p in range(4, ph - 1)])
-        lo, hi = iv[0][0], max(e for _, e in iv)
-        busy, cur_s, cur_e, overlap = 0, iv[0][0], iv[0][1], 0
-        for s_, e_ in iv[1:]:
-            if s_ <= cur_e:
-                overlap += min(cur_e, e_) - s_
-                cur_e = max(cur_e, e_)
-            else:
-                busy += cur_e - cur_s
-                cur_s, cur_e = s_, e_
-        busy += cur_e - cur_s
-        emit(f"    waves {w} + {w + 4}: inside an MFMA segment {busy / (hi - lo):5.2f} of the span, both at once {overlap / (hi - lo):5.2f}")
-    # raw timeline of two K tiles for wave rows 0 and 1 (waves 0 and 4)
-    emit("    timeline, K tiles 3-4 (cycles since the first stamp): point = start / reads landed / vmcnt over / 8 MFMAs issued / 16 issued")
-    for p in range(6, 10):
-        emit(f"      phase {p:2d}   wave0 " + " ".join(f"{int(v):7d}" for v in st[0, p]) + "   | wave4 " + " ".join(f"{int(v):7d}" for v in st[4, p]))
+    emit("    events of waves 0 and 4 (one SIMD), phases 6-9, cycles since the first stamp:")
+    names = ["phase start (barrier 2 passed)", "fragment reads issued", "LDS-DMA issued", "lgkmcnt(0) over", "vmcnt over -> barrier 1",
+             "8 MFMAs issued", "16 MFMAs issued -> barrier 2"]
+    ev = sorted((int(st[w, p, i]), w, p, names[i]) for w in (0, 4) for p in range(6, min(10, ph)) for i in range(7))
+    for t, w, p, nm in ev:
+        emit(f"      {t:7d}  {'                                   ' if w == 4 else ''}wave{w} phase {p:2d}: {nm}")
     ep = (tr[:, 2] - tr[:, 1]).astype(np.int64)
     emit(f"    epilogue (K loop end -> stores issued, incl. the trace copy-out): {ep.min()} .. {ep.max()} cycles per wave")
 
