@@ -133,7 +133,7 @@ def main():
             ref = fn()
             od.GEMM_SCHEDULE = 0
             for vname, bits in VARIANTS:
-                if a.variants and vname.split()[0] not in a.variants:
+                if a.variants and vname.split()[0].rstrip(":") not in a.variants:
                     continue
 
                 def plain(fn=fn, bits=bits):
@@ -161,7 +161,7 @@ def main():
                 emit(f"  [{vname}] {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s untraced; with stamps {ms_t:.3f} ms ({(ms_t / ms - 1) * 100:+.1f} %); "
                      f"outputs bit-identical to the default kernel: {same}")
                 del got
-                raws[f"{name}_{op}_{vname.split()[0]}"] = tr
+                raws[f"{name}_{op}_{vname.split()[0].rstrip(chr(58))}"] = tr
                 analyse(tr, emit, f"{name} {op} [{vname}]", brief=a.brief and bits != 0)
             del ref
     if a.out:
