@@ -84,6 +84,7 @@ struct GemmArgs {
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
     unsigned long long *trace;   // XQ_GEMM_TRACE (diagnostics): s_memtime stamps of the phases of workgroup trace_block's first item,
     int trace_cap, trace_block;  // [8 waves][trace_cap] (layout: xq_gemm_trace_bind in include/xq_ops.h); null = off
+    int trace_item;              // which item of that workgroup's list is recorded (0 = first)
     int variant;                 // VAR bits 2 / 4 of gemm_pring_kernel (XQ_GEMM_NO_SEGMENT_PRIO / XQ_GEMM_ROW1_PRIO)
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
@@ -591,7 +592,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
     const bool tr_on = TRACE && g.trace != nullptr && (int)blockIdx.x == g.trace_block;
     int tr_n = 0;
-    bool tr_first = true;
+    int tr_cur = 0;          // index of the current item in this workgroup's list; item g.trace_item is the recorded one
 #define PR_T(I)                                                   \
     do {                                                          \
         if (TRACE) {                                              \
@@ -603,7 +604,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #define PR_T_KEEP()                                                                                              \
     do {                                                                                                         \
         if (TRACE) {                                                                                             \
-            if (tr_on && tr_first && tr_n < 36 && lane == 0) {                                                   \
+            if (tr_on && tr_cur == g.trace_item && tr_n < 36 && lane == 0) {                                     \
                 _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_)                                                 \
                     *reinterpret_cast<unsigned long long *>(region + 2048 + (tr_n * 7 + i_) * 8) = ts[i_];       \
             }                                                                                                    \
@@ -803,11 +804,11 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         if (wr == 0) GR_BARRIER();
         if (!has_next) GR_VMCNT(0);      // the dummy pieces target `region`
         if (TRACE) {
-            if (tr_on && tr_first && lane == 0) {
+            if (tr_on && tr_cur == 0 && lane == 0) g.trace[(long)wave * g.trace_cap + 1] = __builtin_amdgcn_s_memtime();
+            if (tr_on && tr_cur == g.trace_item && lane == 0) {
                 unsigned long long *out = g.trace + (long)wave * g.trace_cap;
                 const int n = tr_n < 36 ? tr_n : 36;      // phases
                 out[0] = (unsigned long long)n;
-                out[1] = __builtin_amdgcn_s_memtime();
                 out[3] = (unsigned long long)cit.KT;
                 for (int i = 0; i < n * 7 && 4 + i < g.trace_cap; ++i)
                     out[4 + i] = *reinterpret_cast<const unsigned long long *>(region + 2048 + i * 8);
@@ -923,8 +924,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             }
         }
         if (TRACE) {
-            if (tr_on && tr_first && lane == 0) g.trace[(long)wave * g.trace_cap + 2] = __builtin_amdgcn_s_memtime();
-            tr_first = false;
+            if (tr_on && tr_cur == 0 && lane == 0) g.trace[(long)wave * g.trace_cap + 2] = __builtin_amdgcn_s_memtime();
+            ++tr_cur;
+            tr_n = 0;
         }
         if (!has_next) break;
         PR_ZERO()
@@ -1200,7 +1202,7 @@ unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
 void bind_trace(GemmArgs &g, int impl) {
     g.variant = (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
-    if ((impl & XQ_GEMM_TRACE) && g_trace_buf && g_trace_cap >= 8) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block; }
+    if ((impl & XQ_GEMM_TRACE) && g_trace_buf && g_trace_cap >= 8) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block & 0xffff; g.trace_item = g_trace_block >> 16; }
 }
 
 int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {

@@ -406,7 +406,7 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_OP_TN 2
 #define XQ_PROF_GEMM 4       /* gemm_*_kernel: 2*M*N*K flops per launch (xq_prof_collect_kind)                               */
 /* diagnostics (no reference counterpart): where the stamps of XQ_GEMM_TRACE launches go.  buf = device memory, uint64 [8 waves][cap_per_wave];
- * the 8 waves of workgroup `workgroup` record their first work item: [0] = phases recorded (<= 36, two per K tile), [1] = clock at the
+ * the 8 waves of workgroup (`workgroup` & 0xffff) record item (`workgroup` >> 16) of their list ([1], [2]: always of its first item): [0] = phases recorded (<= 36, two per K tile), [1] = clock at the
  * end of the K loop, [2] = clock at the end of the epilogue, [3] = K tiles of the item, [4 + 7 p + i] = clock at point i of record p:
  * i = 0 phase p start, 1 fragment reads issued, 2 LDS-DMA issued, 3 lgkmcnt(0) over, 4 vmcnt wait over (record written here, in front
  * of the phase's first barrier), i = 5, 6 = eight / all sixteen MFMAs of phase p - 1 issued.  buf = NULL unbinds.

@@ -61,7 +61,7 @@ def run_traced(fn, block):
     return buf.cpu().numpy()
 
 
-def analyse(tr, emit, label, brief=False):
+def analyse(tr, emit, label, brief=False, first=0):
     n = int(tr[0, 0])                       # records = phases
     if n < 10:
         emit(f"  {label}: only {n} phases recorded (workgroup without a long enough first item?)")
@@ -82,6 +82,10 @@ def analyse(tr, emit, label, brief=False):
         x = seg[w, steady]
         cells = "".join(f"{x[:, i].mean():9.0f} [{x[:, i].min():4d}..{x[:, i].max():5d}]" for i in range(7))
         emit(f"    wave {w} ({w >> 2}, {w & 3})     {cells}{x.sum(axis=1).mean():10.0f}")
+    if first:
+        emit(f"    the first {first} phases one by one (waves 0 and 4):")
+        for p in range(min(first, ph - 1)):
+            emit(f"      phase {p:2d}  wave0 " + " ".join(f"{int(v):6d}" for v in seg[0, p]) + "   | wave4 " + " ".join(f"{int(v):6d}" for v in seg[4, p]))
     per_tile = float(st[0, ph - 2, 0] - st[0, 4, 0]) / ((ph - 2 - 4) / 2.0)
     emit(f"    K tile period {per_tile:7.0f} cycles  ->  MFMA-pipe utilisation {2048 / per_tile:5.2f} "
          f"(2 waves x 32 MFMAs x 32 cycles per SIMD and K tile = 2048)")
@@ -102,6 +106,8 @@ def main():
     ap.add_argument("--layers", nargs="*", default=["qkv", "fc1"])
     ap.add_argument("--ops", nargs="*", default=["nt", "nn", "tn"])
     ap.add_argument("--block", type=int, default=37)
+    ap.add_argument("--item", type=int, default=0, help="which item of the workgroup's list to record (1: the K loop that follows an epilogue)")
+    ap.add_argument("--first-phases", type=int, default=0, help="also print the segments of the first N phases one by one (waves 0 and 4)")
     ap.add_argument("--out", default=None)
     ap.add_argument("--variants", nargs="*", default=None, help="subset of segprio noprio row1prio")
     ap.add_argument("--iters", type=int, default=5)
@@ -151,7 +157,7 @@ def main():
                         od.GEMM_SCHEDULE = 0
                 ms = timed(plain, a.iters)
                 buf = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
-                _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), CAP, a.block)
+                _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), CAP, a.block | (a.item << 16))
                 got = traced()
                 torch.cuda.synchronize()
                 tr = buf.cpu().numpy()
@@ -162,7 +168,7 @@ def main():
                      f"outputs bit-identical to the default kernel: {same}")
                 del got
                 raws[f"{name}_{op}_{vname.split()[0].rstrip(chr(58))}"] = tr
-                analyse(tr, emit, f"{name} {op} [{vname}]", brief=a.brief and bits != 0)
+                analyse(tr, emit, f"{name} {op} [{vname}] item {a.item}", brief=a.brief and bits != 0, first=a.first_phases)
             del ref
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
