@@ -583,13 +583,13 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int TRACE = VAR & 1;
     constexpr bool SEG_PRIO = !(VAR & 2);
     constexpr bool ROW1_PRIO = (VAR & 4) != 0;
-    // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 7 points of each phase (0 phase start,
-    // 1 fragment reads issued, 2 LDS-DMA issued, 3 lgkmcnt(0) over, 4 vmcnt wait over, 5 eight of the 16 MFMAs issued, 6 all 16 issued
-    // — no stamp right behind the first barrier: the compiler's own lgkmcnt(0) in front of the first MFMA would wait for that clock
-    // read on the critical path); the waves of one workgroup keep the stamps of its first item's first 36 phases (LDS, upper half of the
-    // wave's epilogue staging area; written in front of the first barrier, so a record holds points 0-4 of its phase and points 5-6 of
-    // the phase before) and copy them out before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
-    unsigned long long ts[7] = {0, 0, 0, 0, 0, 0, 0};
+    // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 9 points of each phase (0 phase start,
+    // 1 fragment reads issued, 2 LDS-DMA issued, 3 lgkmcnt(0) over, 4 vmcnt wait over, 5 trace record written = arrival at the first
+    // barrier, 6 first barrier passed, 7 eight of the 16 MFMAs issued, 8 all 16 issued = arrival at the second barrier); the waves of one
+    // workgroup keep the stamps of the recorded item's first 28 phases (LDS, upper half of the wave's epilogue staging area; written in
+    // front of the first barrier, so a record holds points 0-4 of its phase and points 5-8 of the phase before) and copy them out
+    // before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
+    unsigned long long ts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool tr_on = TRACE && g.trace != nullptr && (int)blockIdx.x == g.trace_block;
     int tr_n = 0;
     int tr_cur = 0;          // index of the current item in this workgroup's list; item g.trace_item is the recorded one
@@ -604,9 +604,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #define PR_T_KEEP()                                                                                              \
     do {                                                                                                         \
         if (TRACE) {                                                                                             \
-            if (tr_on && tr_cur == g.trace_item && tr_n < 36 && lane == 0) {                                     \
-                _Pragma("unroll") for (int i_ = 0; i_ < 7; ++i_)                                                 \
-                    *reinterpret_cast<unsigned long long *>(region + 2048 + (tr_n * 7 + i_) * 8) = ts[i_];       \
+            if (tr_on && tr_cur == g.trace_item && tr_n < 28 && lane == 0) {                                     \
+                _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_)                                                 \
+                    *reinterpret_cast<unsigned long long *>(region + 2048 + (tr_n * 9 + i_) * 8) = ts[i_];       \
             }                                                                                                    \
             ++tr_n;                                                                                              \
         }                                                                                                        \
@@ -756,11 +756,13 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         GR_VMCNT(8);                                                          \
         PR_T(4);                                                              \
         PR_T_KEEP();                                                          \
-        GR_BARRIER();                                                         \
-        PR_MFMA(0, 0, bl);                                                    \
         PR_T(5);                                                              \
-        PR_MFMA(0, 1, br);                                                    \
+        GR_BARRIER();                                                         \
         PR_T(6);                                                              \
+        PR_MFMA(0, 0, bl);                                                    \
+        PR_T(7);                                                              \
+        PR_MFMA(0, 1, br);                                                    \
+        PR_T(8);                                                              \
         GR_BARRIER();                                                         \
         PR_T(0);                                                              \
         PR_READ_A(3)                                                          \
@@ -774,11 +776,13 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         GR_VMCNT(6);                                                          \
         PR_T(4);                                                              \
         PR_T_KEEP();                                                          \
-        GR_BARRIER();                                                         \
-        PR_MFMA(2, 1, br);                                                    \
         PR_T(5);                                                              \
-        PR_MFMA(2, 0, bl);                                                    \
+        GR_BARRIER();                                                         \
         PR_T(6);                                                              \
+        PR_MFMA(2, 1, br);                                                    \
+        PR_T(7);                                                              \
+        PR_MFMA(2, 0, bl);                                                    \
+        PR_T(8);                                                              \
         GR_BARRIER();                                                         \
         r_par ^= 1;                                                           \
     } while (0)
@@ -807,10 +811,10 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             if (tr_on && tr_cur == 0 && lane == 0) g.trace[(long)wave * g.trace_cap + 1] = __builtin_amdgcn_s_memtime();
             if (tr_on && tr_cur == g.trace_item && lane == 0) {
                 unsigned long long *out = g.trace + (long)wave * g.trace_cap;
-                const int n = tr_n < 36 ? tr_n : 36;      // phases
+                const int n = tr_n < 28 ? tr_n : 28;      // phases
                 out[0] = (unsigned long long)n;
                 out[3] = (unsigned long long)cit.KT;
-                for (int i = 0; i < n * 7 && 4 + i < g.trace_cap; ++i)
+                for (int i = 0; i < n * 9 && 4 + i < g.trace_cap; ++i)
                     out[4 + i] = *reinterpret_cast<const unsigned long long *>(region + 2048 + i * 8);
             }
         }

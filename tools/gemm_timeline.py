@@ -7,8 +7,9 @@ shapes with XQ_GEMM_TRACE, reads the stamps back and prints where a K tile's cyc
     dma-issue   -> the phase's 4 LDS-DMA instructions (global_load_lds_dwordx4) issued, with their address arithmetic
     lgkm0       -> s_waitcnt lgkmcnt(0) over: the fragments have landed
     vmcnt       -> counted s_waitcnt vmcnt over: the pieces the NEXT phase reads have landed
-    keep+bar1+8 -> (trace record written,) first barrier passed and the first 8 v_mfma_f32_32x32x16_bf16 of the segment issued
-    mfma8       -> the other 8 issued (256 cycles when the matrix pipe is this wave's alone)
+    record      -> the trace record of the phase written (lane 0: ~17 VALU + 4 ds_write; does not exist in the untraced kernel) = arrival at barrier 1
+    bar1        -> first barrier passed
+    mfma8 x 2   -> eight / all sixteen v_mfma_f32_32x32x16_bf16 issued (256 cycles each when the matrix pipe is this wave's alone) = arrival at barrier 2
     bar2        -> second barrier passed (= next phase start)
 
 and the merged event list of waves 0 and 4 (one SIMD).  tick = shader cycle (MI355X_MICROARCH.md); the stamps cost the traced workgroup a few % (the other workgroups
@@ -32,7 +33,10 @@ CAP = 512
 VARIANTS = [("segprio: s_setprio 1 around every MFMA segment (the default kernel)", 0),
             ("noprio: no s_setprio at all", 0x10000),
             ("row1prio: waves 4-7 at priority 1 for the whole kernel, no per-segment flips", 0x20000)]
-SEG = ["rd-issue", "dma-issue", "lgkm0", "vmcnt", "keep+bar1+8", "mfma8", "bar2"]
+NP = 9
+SEG = ["rd-issue", "dma-issue", "lgkm0", "vmcnt", "record", "bar1", "mfma8", "mfma8", "bar2"]
+POINTS = ["phase start (barrier 2 passed)", "fragment reads issued", "LDS-DMA issued", "lgkmcnt(0) over", "vmcnt over", "at barrier 1 (record written)",
+          "barrier 1 passed", "8 MFMAs issued", "16 MFMAs issued -> at barrier 2"]
 
 
 def timed(fn, iters=5):
@@ -64,39 +68,52 @@ def run_traced(fn, block):
 def analyse(tr, emit, label, brief=False, first=0):
     n = int(tr[0, 0])                       # records = phases
     if n < 10:
-        emit(f"  {label}: only {n} phases recorded (workgroup without a long enough first item?)")
+        emit(f"  {label}: only {n} phases recorded (workgroup without a long enough item?)")
         return
     kt = int(tr[0, 3])
-    rec = np.stack([tr[w, 4:4 + n * 7].reshape(n, 7) for w in range(8)]).astype(np.int64)     # [wave][record][point]
-    st = np.concatenate([rec[:, :-1, :5], rec[:, 1:, 5:7]], axis=2)     # points 5, 6 of phase p sit in record p + 1
+    rec = np.stack([tr[w, 4:4 + n * NP].reshape(n, NP) for w in range(8)]).astype(np.int64)     # [wave][record][point]
+    st = np.concatenate([rec[:, :-1, :5], rec[:, 1:, 5:NP]], axis=2)     # points 5.. of phase p sit in record p + 1
     st = st - st[:, 0, 0].min()
     ph = st.shape[1]
     nxt = st[:, 1:, 0]
     cur = st[:, :-1]
-    seg = np.stack([cur[:, :, 1] - cur[:, :, 0], cur[:, :, 2] - cur[:, :, 1], cur[:, :, 3] - cur[:, :, 2], cur[:, :, 4] - cur[:, :, 3],
-                    cur[:, :, 5] - cur[:, :, 4], cur[:, :, 6] - cur[:, :, 5], nxt - cur[:, :, 6]], axis=2)     # [wave][phase][7]
+    seg = np.stack([cur[:, :, i + 1] - cur[:, :, i] for i in range(NP - 1)] + [nxt - cur[:, :, NP - 1]], axis=2)     # [wave][phase][NP]
     steady = slice(4, ph - 1)
     emit(f"  {label}: item of {kt} K tiles, {ph} phases; cycles per PHASE (8 MFMAs = 256 at full rate), steady-state mean [min..max]")
-    emit(f"    {'wave (row, col)':18s}" + "".join(f"{s:>22s}" for s in SEG) + f"{'phase':>10s}")
+    emit(f"    {'wave (row, col)':18s}" + "".join(f"{s:>20s}" for s in SEG) + f"{'phase':>8s}")
     for w in ([0, 4] if brief else range(8)):
         x = seg[w, steady]
-        cells = "".join(f"{x[:, i].mean():9.0f} [{x[:, i].min():4d}..{x[:, i].max():5d}]" for i in range(7))
-        emit(f"    wave {w} ({w >> 2}, {w & 3})     {cells}{x.sum(axis=1).mean():10.0f}")
+        cells = "".join(f"{x[:, i].mean():7.0f} [{x[:, i].min():4d}..{x[:, i].max():5d}]" for i in range(NP))
+        emit(f"    wave {w} ({w >> 2}, {w & 3})     {cells}{x.sum(axis=1).mean():8.0f}")
     if first:
         emit(f"    the first {first} phases one by one (waves 0 and 4):")
         for p in range(min(first, ph - 1)):
-            emit(f"      phase {p:2d}  wave0 " + " ".join(f"{int(v):6d}" for v in seg[0, p]) + "   | wave4 " + " ".join(f"{int(v):6d}" for v in seg[4, p]))
+            emit(f"      phase {p:2d}  wave0 " + " ".join(f"{int(v):5d}" for v in seg[0, p]) + "   | wave4 " + " ".join(f"{int(v):5d}" for v in seg[4, p]))
     per_tile = float(st[0, ph - 2, 0] - st[0, 4, 0]) / ((ph - 2 - 4) / 2.0)
     emit(f"    K tile period {per_tile:7.0f} cycles  ->  MFMA-pipe utilisation {2048 / per_tile:5.2f} "
          f"(2 waves x 32 MFMAs x 32 cycles per SIMD and K tile = 2048)")
-    emit("    events of waves 0 and 4 (one SIMD), phases 6-9, cycles since the first stamp:")
-    names = ["phase start (barrier 2 passed)", "fragment reads issued", "LDS-DMA issued", "lgkmcnt(0) over", "vmcnt over -> barrier 1",
-             "8 MFMAs issued", "16 MFMAs issued -> barrier 2"]
-    ev = sorted((int(st[w, p, i]), w, p, names[i]) for w in (0, 4) for p in range(6, min(10, ph)) for i in range(7))
+    # barrier instances.  X(p): wave row 0 at its FIRST barrier of phase p (arrives at point 5, leaves at 6) with wave row 1 at its SECOND
+    # barrier of phase p - 1 (arrives at point 8, leaves at point 0 of phase p).  Y(p): row 0 at its second barrier of phase p with row 1 at its
+    # first barrier of phase p.
+    for name, arr0, rel0, arr1, rel1 in (("row 0 before its MFMAs / row 1 after its MFMAs", lambda p: st[:4, p, 5], lambda p: st[:4, p, 6], lambda p: st[4:, p - 1, 8], lambda p: st[4:, p, 0]),
+                                         ("row 0 after its MFMAs / row 1 before its MFMAs", lambda p: st[:4, p, 8], lambda p: st[:4, p + 1, 0], lambda p: st[4:, p, 5], lambda p: st[4:, p, 6])):
+        lat, last0, spread = [], 0, []
+        for p in range(4, ph - 2):
+            a0, a1 = arr0(p), arr1(p)
+            r = np.concatenate([rel0(p), rel1(p)])
+            last = max(a0.max(), a1.max())
+            lat.append(int(r.min() - last))
+            spread.append(int(r.max() - r.min()))
+            last0 += int(a0.max() >= a1.max())
+        lat = np.array(lat)
+        emit(f"    barrier [{name}]: last arrival -> first wave past it {lat.mean():5.0f} [{lat.min()}..{lat.max()}] cycles; first -> last wave past it "
+             f"{np.mean(spread):4.0f}; row 0 arrived last in {last0} of {len(lat)}")
+    emit("    events of waves 0 and 4 (one SIMD), phases 6-8, cycles since the first stamp:")
+    ev = sorted((int(st[w, p, i]), w, p, POINTS[i]) for w in (0, 4) for p in range(6, min(9, ph)) for i in range(NP))
     for t, w, p, nm in ev:
         emit(f"      {t:7d}  {'                                   ' if w == 4 else ''}wave{w} phase {p:2d}: {nm}")
     ep = (tr[:, 2] - tr[:, 1]).astype(np.int64)
-    emit(f"    epilogue (K loop end -> stores issued, incl. the trace copy-out): {ep.min()} .. {ep.max()} cycles per wave")
+    emit(f"    epilogue of the workgroup's first item (K loop end -> stores issued): {ep.min()} .. {ep.max()} cycles per wave")
 
 
 def main():
