@@ -584,11 +584,12 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr bool SEG_PRIO = !(VAR & 2);
     constexpr bool ROW1_PRIO = (VAR & 4) != 0;
     // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 9 points of each phase (0 phase start,
-    // 1 fragment reads issued, 2 LDS-DMA issued, 3 lgkmcnt(0) over, 4 vmcnt wait over, 5 trace record written = arrival at the first
+    // 1 fragment reads issued, 2 trace record written, 3 LDS-DMA issued, 4 lgkmcnt(0) over, 5 vmcnt wait over = arrival at the first
     // barrier, 6 first barrier passed, 7 eight of the 16 MFMAs issued, 8 all 16 issued = arrival at the second barrier); the waves of one
-    // workgroup keep the stamps of the recorded item's first 28 phases (LDS, upper half of the wave's epilogue staging area; written in
-    // front of the first barrier, so a record holds points 0-4 of its phase and points 5-8 of the phase before) and copy them out
-    // before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
+    // workgroup keep the stamps of the recorded item's first 28 phases (LDS, upper half of the wave's epilogue staging area; the record
+    // is written between the fragment reads and the LDS-DMA issue — a DS write behind the wave's own LDS-DMA waits for that DMA to land,
+    // profiles/r03_gemm_phase_timeline_*.txt — so a record holds points 0-1 of its phase and points 2-8 of the phase before) and copy
+    // them out before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
     unsigned long long ts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const bool tr_on = TRACE && g.trace != nullptr && (int)blockIdx.x == g.trace_block;
     int tr_n = 0;
@@ -748,14 +749,14 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         PR_READ_B(br, 2)                                                      \
         PR_READ_A(0)                                                          \
         PR_T(1);                                                              \
+        PR_T_KEEP();                                                          \
+        PR_T(2);                                                              \
         PR_STAGE(2);                                                          \
         PR_STAGE(3);                                                          \
-        PR_T(2);                                                              \
-        GR_LGKM0();                                                           \
         PR_T(3);                                                              \
-        GR_VMCNT(8);                                                          \
+        GR_LGKM0();                                                           \
         PR_T(4);                                                              \
-        PR_T_KEEP();                                                          \
+        GR_VMCNT(8);                                                          \
         PR_T(5);                                                              \
         GR_BARRIER();                                                         \
         PR_T(6);                                                              \
@@ -767,15 +768,15 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         PR_T(0);                                                              \
         PR_READ_A(3)                                                          \
         PR_T(1);                                                              \
+        PR_T_KEEP();                                                          \
+        PR_T(2);                                                              \
         PR_ADVANCE();                                                         \
         PR_STAGE(0);                                                          \
         PR_STAGE(1);                                                          \
-        PR_T(2);                                                              \
-        GR_LGKM0();                                                           \
         PR_T(3);                                                              \
-        GR_VMCNT(6);                                                          \
+        GR_LGKM0();                                                           \
         PR_T(4);                                                              \
-        PR_T_KEEP();                                                          \
+        GR_VMCNT(6);                                                          \
         PR_T(5);                                                              \
         GR_BARRIER();                                                         \
         PR_T(6);                                                              \

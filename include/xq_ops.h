@@ -408,9 +408,9 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 /* diagnostics (no reference counterpart): where the stamps of XQ_GEMM_TRACE launches go.  buf = device memory, uint64 [8 waves][cap_per_wave];
  * the 8 waves of workgroup (`workgroup` & 0xffff) record item (`workgroup` >> 16) of their list: [0] = phases recorded (<= 28, two per K
  * tile), [1] = clock at the end of the K loop of the workgroup's FIRST item, [2] = clock at the end of that item's epilogue, [3] = K tiles
- * of the recorded item, [4 + 9 p + i] = clock at point i of record p: i = 0 phase p start, 1 fragment reads issued, 2 LDS-DMA issued,
- * 3 lgkmcnt(0) over, 4 vmcnt wait over (record written here); i = 5..8 belong to phase p - 1: arrival at its first barrier, first
- * barrier passed, eight / all sixteen MFMAs issued (= arrival at the second barrier).  buf = NULL unbinds.
+ * of the recorded item, [4 + 9 p + i] = clock at point i of record p: i = 0 phase p start, 1 fragment reads issued (record written here);
+ * i = 2..8 belong to phase p - 1: record written, LDS-DMA issued, lgkmcnt(0) over, vmcnt wait over (= arrival at its first barrier),
+ * first barrier passed, eight / all sixteen MFMAs issued (= arrival at the second barrier).  buf = NULL unbinds.
  * tools/gemm_timeline.py prints the timeline. */
 int xq_gemm_trace_bind(void *buf, int cap_per_wave, int workgroup);
 /* bytes of workspace for op (XQ_GEMM_OP_*) at output rows M, columns N, reduction depth K (TN: M = P, N = Q, K = R);

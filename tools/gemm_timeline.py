@@ -4,10 +4,11 @@ shapes with XQ_GEMM_TRACE, reads the stamps back and prints where a K tile's cyc
 
     rd-issue    phase start (second barrier of the phase before passed) -> the phase's fragment reads issued (16 or 8 ds_read_b128 /
                 twice as many ds_read_b64_tr_b16, with their address arithmetic)
+    record      -> the trace record written (lane 0: s_waitcnt lgkmcnt(0) = the fragments have landed, ~17 VALU, 4 ds_write; not in the
+                untraced kernel).  It sits BEFORE the DMA issue: behind it, its ds_write waited ~450 cycles for the wave's own LDS-DMA to land
     dma-issue   -> the phase's 4 LDS-DMA instructions (global_load_lds_dwordx4) issued, with their address arithmetic
-    lgkm0       -> s_waitcnt lgkmcnt(0) over: the fragments have landed
-    vmcnt       -> counted s_waitcnt vmcnt over: the pieces the NEXT phase reads have landed
-    record      -> the trace record of the phase written (lane 0: ~17 VALU + 4 ds_write; does not exist in the untraced kernel) = arrival at barrier 1
+    lgkm0       -> s_waitcnt lgkmcnt(0) over
+    vmcnt       -> counted s_waitcnt vmcnt over: the pieces the NEXT phase reads have landed = arrival at barrier 1
     bar1        -> first barrier passed
     mfma8 x 2   -> eight / all sixteen v_mfma_f32_32x32x16_bf16 issued (256 cycles each when the matrix pipe is this wave's alone) = arrival at barrier 2
     bar2        -> second barrier passed (= next phase start)
@@ -34,8 +35,9 @@ VARIANTS = [("segprio: s_setprio 1 around every MFMA segment (the default kernel
             ("noprio: no s_setprio at all", 0x10000),
             ("row1prio: waves 4-7 at priority 1 for the whole kernel, no per-segment flips", 0x20000)]
 NP = 9
-SEG = ["rd-issue", "dma-issue", "lgkm0", "vmcnt", "record", "bar1", "mfma8", "mfma8", "bar2"]
-POINTS = ["phase start (barrier 2 passed)", "fragment reads issued", "LDS-DMA issued", "lgkmcnt(0) over", "vmcnt over", "at barrier 1 (record written)",
+NCUR = 2         # points of a phase that sit in its own record (the rest in the next one)
+SEG = ["rd-issue", "record", "dma-issue", "lgkm0", "vmcnt", "bar1", "mfma8", "mfma8", "bar2"]
+POINTS = ["phase start (barrier 2 passed)", "fragment reads issued", "record written", "LDS-DMA issued", "lgkmcnt(0) over", "vmcnt over -> at barrier 1",
           "barrier 1 passed", "8 MFMAs issued", "16 MFMAs issued -> at barrier 2"]
 
 
@@ -72,7 +74,7 @@ def analyse(tr, emit, label, brief=False, first=0):
         return
     kt = int(tr[0, 3])
     rec = np.stack([tr[w, 4:4 + n * NP].reshape(n, NP) for w in range(8)]).astype(np.int64)     # [wave][record][point]
-    st = np.concatenate([rec[:, :-1, :5], rec[:, 1:, 5:NP]], axis=2)     # points 5.. of phase p sit in record p + 1
+    st = np.concatenate([rec[:, :-1, :NCUR], rec[:, 1:, NCUR:NP]], axis=2)     # points NCUR.. of phase p sit in record p + 1
     st = st - st[:, 0, 0].min()
     ph = st.shape[1]
     nxt = st[:, 1:, 0]
