@@ -581,6 +581,35 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     // VAR bits (diagnostics / A-B, PH = 2): 1 = clock stamps (XQ_GEMM_TRACE), 2 = no s_setprio around the MFMA segments
     // (XQ_GEMM_NO_SEGMENT_PRIO), 4 = wave row 1 at priority 1 for the whole kernel (XQ_GEMM_ROW1_PRIO; with bit 2)
     constexpr int TRACE = VAR & 1;
+    // VAR bit 8 (XQ_GEMM_TRACE_SUMS): the low-perturbation form of the trace — four clock reads per phase (phase start, arrival at the
+    // first barrier, first barrier passed, arrival at the second barrier), differenced and summed in SGPRs (scalar ALU only: no VALU, no
+    // LDS, no extra s_waitcnt — the differences are taken right behind the phase's own lgkmcnt(0), one phase late), over every phase of
+    // every item of the workgroup except each item's first; the traced workgroup writes the six numbers at the end of the kernel.
+    constexpr bool SUMS = (VAR & 8) != 0;
+    unsigned long long q_s = 0, q_a = 0, q_p = 0, q_e = 0;
+    unsigned q_s_prev = 0, q_n = 0, q_phases = 0, q_items = 0, q_load = 0, q_bar1 = 0, q_mfma = 0, q_bar2 = 0;
+#define PR_Q(X)                                                   \
+    do {                                                          \
+        if (SUMS) {                                               \
+            __builtin_amdgcn_sched_barrier(0);                    \
+            X = __builtin_amdgcn_s_memtime();                     \
+            __builtin_amdgcn_sched_barrier(0);                    \
+        }                                                         \
+    } while (0)
+#define PR_Q_ACC()                                                                       \
+    do {                                                                                 \
+        if (SUMS) {                                                                      \
+            if (q_n) {                                                                   \
+                q_load += (unsigned)q_a - q_s_prev;                                      \
+                q_bar1 += (unsigned)q_p - (unsigned)q_a;                                 \
+                q_mfma += (unsigned)q_e - (unsigned)q_p;                                 \
+                q_bar2 += (unsigned)q_s - (unsigned)q_e;                                 \
+                ++q_phases;                                                              \
+            }                                                                            \
+            q_s_prev = (unsigned)q_s;                                                    \
+            ++q_n;                                                                       \
+        }                                                                                \
+    } while (0)
     constexpr bool SEG_PRIO = !(VAR & 2);
     constexpr bool ROW1_PRIO = (VAR & 4) != 0;
     // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 9 points of each phase (0 phase start,
@@ -745,6 +774,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #define PR_TILE2()                                                            \
     do {                                                                      \
         PR_T(0);                                                              \
+        PR_Q(q_s);                                                            \
         PR_READ_B(bl, 1)                                                      \
         PR_READ_B(br, 2)                                                      \
         PR_READ_A(0)                                                          \
@@ -755,17 +785,22 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         PR_STAGE(3);                                                          \
         PR_T(3);                                                              \
         GR_LGKM0();                                                           \
+        PR_Q_ACC();                                                           \
         PR_T(4);                                                              \
         GR_VMCNT(8);                                                          \
         PR_T(5);                                                              \
+        PR_Q(q_a);                                                            \
         GR_BARRIER();                                                         \
         PR_T(6);                                                              \
+        PR_Q(q_p);                                                            \
         PR_MFMA(0, 0, bl);                                                    \
         PR_T(7);                                                              \
         PR_MFMA(0, 1, br);                                                    \
         PR_T(8);                                                              \
+        PR_Q(q_e);                                                            \
         GR_BARRIER();                                                         \
         PR_T(0);                                                              \
+        PR_Q(q_s);                                                            \
         PR_READ_A(3)                                                          \
         PR_T(1);                                                              \
         PR_T_KEEP();                                                          \
@@ -775,15 +810,19 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         PR_STAGE(1);                                                          \
         PR_T(3);                                                              \
         GR_LGKM0();                                                           \
+        PR_Q_ACC();                                                           \
         PR_T(4);                                                              \
         GR_VMCNT(6);                                                          \
         PR_T(5);                                                              \
+        PR_Q(q_a);                                                            \
         GR_BARRIER();                                                         \
         PR_T(6);                                                              \
+        PR_Q(q_p);                                                            \
         PR_MFMA(2, 1, br);                                                    \
         PR_T(7);                                                              \
         PR_MFMA(2, 0, bl);                                                    \
         PR_T(8);                                                              \
+        PR_Q(q_e);                                                            \
         GR_BARRIER();                                                         \
         r_par ^= 1;                                                           \
     } while (0)
@@ -933,11 +972,21 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             ++tr_cur;
             tr_n = 0;
         }
+        if (SUMS) { q_n = 0; ++q_items; }      // the first phase of the next item is not differenced against this item's last
         if (!has_next) break;
         PR_ZERO()
         cp += G;
         decode_item(g, cp, cit);
     }
+    if (SUMS) {
+        if (g.trace != nullptr && (int)blockIdx.x == g.trace_block && lane == 0) {
+            unsigned long long *out = g.trace + (long)wave * g.trace_cap;
+            out[0] = 0;
+            out[8] = q_phases; out[9] = q_load; out[10] = q_bar1; out[11] = q_mfma; out[12] = q_bar2; out[13] = q_items;
+        }
+    }
+#undef PR_Q
+#undef PR_Q_ACC
 #undef PR_T
 #undef PR_T_KEEP
 #undef PR_TILE
@@ -1095,14 +1144,14 @@ void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t
     if (g.trace || g.variant) {      // diagnostics / A-B (XQ_GEMM_TRACE, XQ_GEMM_NO_SEGMENT_PRIO, XQ_GEMM_ROW1_PRIO): two phases, plain NT / NN / TN only
         if (ACT == ACT_NONE && AK != gm::KMAJOR_CONV) {
             constexpr int A2 = AK == gm::KMAJOR_CONV ? (int)gm::KMAJOR : AK;
-            const int var = (g.trace ? 1 : 0) | g.variant;
+            const int var = (g.variant & 8) ? 8 : ((g.trace ? 1 : 0) | g.variant);
 #define XQ_VAR_CASE(V)                                                                                                           \
     case V:                                                                                                                      \
         if (set_lds<gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>>(lds)) return;                                                     \
         hipLaunchKernelGGL((gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>), dim3((unsigned)grid), dim3(GT), lds, s, g);              \
         return;
             switch (var) {
-                XQ_VAR_CASE(1) XQ_VAR_CASE(2) XQ_VAR_CASE(3) XQ_VAR_CASE(6) XQ_VAR_CASE(7)
+                XQ_VAR_CASE(1) XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(8)
                 default: break;
             }
 #undef XQ_VAR_CASE
@@ -1206,8 +1255,8 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
 unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
 void bind_trace(GemmArgs &g, int impl) {
-    g.variant = (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
-    if ((impl & XQ_GEMM_TRACE) && g_trace_buf && g_trace_cap >= 8) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block & 0xffff; g.trace_item = g_trace_block >> 16; }
+    g.variant = (impl & XQ_GEMM_TRACE_SUMS) ? 8 : (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
+    if ((impl & (XQ_GEMM_TRACE | XQ_GEMM_TRACE_SUMS)) && g_trace_buf && g_trace_cap >= 16) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block & 0xffff; g.trace_item = g_trace_block >> 16; }
 }
 
 int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
@@ -1223,7 +1272,7 @@ int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
 // C-ABI
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" int xq_gemm_trace_bind(void *buf, int cap_per_wave, int workgroup) {
-    if (buf && cap_per_wave < 8) return xq_set_error(XQ_EINVAL, "xq_gemm_trace_bind: cap_per_wave < 8");
+    if (buf && cap_per_wave < 16) return xq_set_error(XQ_EINVAL, "xq_gemm_trace_bind: cap_per_wave < 16");
     g_trace_buf = (unsigned long long *)buf;
     g_trace_cap = buf ? cap_per_wave : 0;
     g_trace_block = workgroup;

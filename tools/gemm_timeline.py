@@ -29,6 +29,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from imagefolder_amd import _lib, ops_dense as od  # noqa: E402
 
 TRACE = 0x8000 | 0x1000 | 3      # XQ_GEMM_TRACE | XQ_GEMM_TWO_PHASE | XQ_GEMM_PERSISTENT
+SUMS = 0x40000                   # XQ_GEMM_TRACE_SUMS
 PLAIN = 0x1000 | 3
 CAP = 512
 VARIANTS = [("segprio: s_setprio 1 around every MFMA segment (the default kernel)", 0),
@@ -118,6 +119,34 @@ def analyse(tr, emit, label, brief=False, first=0):
     emit(f"    epilogue of the workgroup's first item (K loop end -> stores issued): {ep.min()} .. {ep.max()} cycles per wave")
 
 
+def sums_case(fn, fl, ref, a, emit):
+    def run(bits):
+        od.GEMM_SCHEDULE = PLAIN | bits
+        try:
+            return fn()
+        finally:
+            od.GEMM_SCHEDULE = 0
+    ms = timed(lambda: run(0), a.iters)
+    buf = torch.zeros(8, CAP, dtype=torch.int64, device="cuda")
+    _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), CAP, a.block)
+    got = run(SUMS)
+    torch.cuda.synchronize()
+    tr = buf.cpu().numpy()
+    ms_t = timed(lambda: run(SUMS), a.iters)
+    _lib.lib().xq_gemm_trace_bind(None, 0, 0)
+    emit(f"  {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s untraced; with the four clock reads per phase {ms_t:.3f} ms ({(ms_t / ms - 1) * 100:+.1f} %); "
+         f"outputs bit-identical: {bool(torch.equal(ref, got))}")
+    emit(f"    {'wave (row, col)':18s}{'phases':>8s}{'items':>7s}{'load':>9s}{'bar1':>9s}{'mfma':>9s}{'bar2':>9s}{'phase':>9s}   "
+         "(mean cycles per phase: start -> at barrier 1 -> passed -> 16 MFMAs issued = at barrier 2 -> passed)")
+    for w in range(8):
+        n = max(1, int(tr[w, 8]))
+        load, bar1, mfma, bar2 = (tr[w, 9 + i] / n for i in range(4))
+        emit(f"    wave {w} ({w >> 2}, {w & 3})     {int(tr[w, 8]):8d}{int(tr[w, 13]):7d}{load:9.0f}{bar1:9.0f}{mfma:9.0f}{bar2:9.0f}{load + bar1 + mfma + bar2:9.0f}")
+    n = max(1, int(tr[0, 8]))
+    per_tile = 2.0 * sum(tr[0, 9 + i] for i in range(4)) / n
+    emit(f"    K tile period {per_tile:7.0f} cycles  ->  MFMA-pipe utilisation {2048 / per_tile:5.2f}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=65664)
@@ -131,6 +160,8 @@ def main():
     ap.add_argument("--variants", nargs="*", default=None, help="subset of segprio noprio row1prio")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--brief", action="store_true", help="two waves per table for the non-default variants")
+    ap.add_argument("--sums", action="store_true", help="XQ_GEMM_TRACE_SUMS instead of the per-phase records: four clock reads per phase, differenced and "
+                    "summed in scalar registers over every item of the workgroup (no VALU / LDS / extra waits: the low-perturbation measurement)")
     a = ap.parse_args()
     lines = []
     raws = {}
@@ -157,6 +188,10 @@ def main():
             od.GEMM_SCHEDULE = PLAIN
             ref = fn()
             od.GEMM_SCHEDULE = 0
+            if a.sums:
+                sums_case(fn, fl, ref, a, emit)
+                del ref
+                continue
             for vname, bits in VARIANTS:
                 if a.variants and vname.split()[0].rstrip(":") not in a.variants:
                     continue
