@@ -168,6 +168,56 @@ def test_two_phase_schedule_is_bit_identical_to_the_four_phase_one(op, M, N, K):
         assert torch.equal(o, base), f"launch {i} differs from the four-phase result in {(o != base).sum().item()} entries"
 
 
+@pytest.mark.parametrize("op", ["nt", "nn", "tn"])
+def test_clock_traces_do_not_change_the_result_and_tell_a_consistent_story(op):
+    """XQ_GEMM_TRACE / XQ_GEMM_TRACE_SUMS (include/xq_ops.h; tools/gemm_timeline.py): the instrumented builds of the persistent two-phase
+    kernel write the same bytes as the plain one; the per-phase records are monotone in time; the summed phase segments say 16 MFMAs
+    take >= 512 cycles and a K tile lasts at least the 2048 cycles its 2 x 32 MFMAs per SIMD need."""
+    import numpy as np
+    from imagefolder_amd import _lib
+    od = _ops()
+    M, N, K = 65664, 2304, 768
+    if op == "tn":
+        a, b = _rand((M, N), 7), _rand((M, K), 8)
+        run = lambda: od.gemm_tn(a, b)
+    elif op == "nn":
+        a, b = _rand((M, N), 7), _rand((N, K), 8, 0.05)
+        run = lambda: od.gemm_nn(a, b)
+    else:
+        a, b = _rand((M, K), 7), _rand((N, K), 8, 0.05)
+        bias = torch.randn(N, device="cuda")
+        run = lambda: od.gemm_nt(a, b, bias)
+    cap = 512
+    buf = torch.zeros(8, cap, dtype=torch.int64, device="cuda")
+    try:
+        od.GEMM_SCHEDULE = TWO_PHASE
+        base = run()
+        assert _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), cap, 37) == 0
+        od.GEMM_SCHEDULE = TWO_PHASE | 0x8000
+        traced = run()
+        torch.cuda.synchronize()
+        rec = buf.cpu().numpy().copy()
+        buf.zero_()
+        od.GEMM_SCHEDULE = TWO_PHASE | 0x40000
+        summed = run()
+        torch.cuda.synchronize()
+        sums = buf.cpu().numpy().copy()
+    finally:
+        od.GEMM_SCHEDULE = 0
+        _lib.lib().xq_gemm_trace_bind(None, 0, 0)
+    assert torch.equal(traced, base) and torch.equal(summed, base)
+    for w in range(8):
+        n = int(rec[w, 0])
+        assert 10 <= n <= 28 and rec[w, 3] >= 2
+        r = rec[w, 4:4 + 9 * n].reshape(n, 9)
+        assert (np.diff(r[:, 0]) > 0).all()                     # phase starts move forward
+        assert (r[:, 1] > r[:, 0]).all()                        # reads are issued after the phase started
+        assert (np.diff(r[1:, 2:], axis=1) > 0).all()           # points 2..8 of the phase before, in order
+        phases, load, bar1, mfma, bar2 = (int(sums[w, 8 + i]) for i in range(5))
+        assert phases >= 20 and sums[w, 13] >= 1
+        assert mfma / phases >= 512 and (load + bar1 + mfma + bar2) / phases >= 1024
+
+
 def test_linear_fn_matches_library_autograd():
     """LinearFn on the hand-written GEMMs vs the same Function on the library GEMMs (values and the three gradients)."""
     od = _ops()
