@@ -149,6 +149,22 @@ struct Stager {
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
     }
+    // XQ_GEMM_SCALAR_BASE (A/B, not yet the default): the tile pointer of the K tile being staged lives in scalar registers and moves by
+    // a scalar add per K tile — no v_lshl_add_u64 + 2 x v_readfirstlane per piece in the load phase (profiles/r03_gemm_where_the_cycles_go.md)
+    const char *cur;
+    __device__ __forceinline__ void make_scalar() {
+        const unsigned long long b = (unsigned long long)base, a = (unsigned long long)adv;
+        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
+        const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        cur = (const char *)(((unsigned long long)bhi << 32) | blo);
+        adv = (long)(((unsigned long long)ahi << 32) | alo);
+    }
+    __device__ __forceinline__ void step() { cur += adv; }
+    __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(cur + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+    }
 };
 
 __device__ __attribute__((aligned(64))) char xq_zero_page[64];      // zero-initialised: the source of out-of-image taps
@@ -586,6 +602,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     // LDS, no extra s_waitcnt — the differences are taken right behind the phase's own lgkmcnt(0), one phase late), over every phase of
     // every item of the workgroup except each item's first; the traced workgroup writes the six numbers at the end of the kernel.
     constexpr bool SUMS = (VAR & 8) != 0;
+    constexpr bool SB = (VAR & 16) != 0;      // XQ_GEMM_SCALAR_BASE
     unsigned long long q_s = 0, q_a = 0, q_p = 0, q_e = 0;
     unsigned q_s_prev = 0, q_n = 0, q_phases = 0, q_items = 0, q_load = 0, q_bar1 = 0, q_mfma = 0, q_bar2 = 0;
 #define PR_Q(X)                                                   \
@@ -658,6 +675,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     sa.bind(g);
     sa.init(g.A, g.lda, cit.m0, g.M, cit.k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, cit.n0, g.N, cit.k0, wave, lane, WTN, 2);
+    if constexpr (SB) { sa.make_scalar(); sb.make_scalar(); }
     long sp = cp;
     int s_kt = 0, s_KT = cit.KT, s_par = 0, r_par = 0;
     // past the last item the cursor keeps issuing the SAME number of LDS-DMA instructions per phase (re-reading its last K
@@ -679,16 +697,45 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #define PR_SDST(Q) (s_dummy ? region - wave * 2048 : PR_SSLOT(Q))
 #define PR_STAGE(Q)                                                   \
     do {                                                              \
-        if ((Q) == 0) sa.issue(0, s_kt, PR_SDST(0), wave);            \
-        else if ((Q) == 1) sb.issue(0, s_kt, PR_SDST(1), wave);       \
-        else if ((Q) == 2) sb.issue(1, s_kt, PR_SDST(2), wave);       \
-        else sa.issue(1, s_kt, PR_SDST(3), wave);                     \
+        if constexpr (SB) {                                           \
+            if ((Q) == 0) sa.issue_cur(0, PR_SDST(0), wave);          \
+            else if ((Q) == 1) sb.issue_cur(0, PR_SDST(1), wave);     \
+            else if ((Q) == 2) sb.issue_cur(1, PR_SDST(2), wave);     \
+            else sa.issue_cur(1, PR_SDST(3), wave);                   \
+        } else {                                                      \
+            if ((Q) == 0) sa.issue(0, s_kt, PR_SDST(0), wave);        \
+            else if ((Q) == 1) sb.issue(0, s_kt, PR_SDST(1), wave);   \
+            else if ((Q) == 2) sb.issue(1, s_kt, PR_SDST(2), wave);   \
+            else sa.issue(1, s_kt, PR_SDST(3), wave);                 \
+        }                                                             \
     } while (0)
     // next K tile of the stream; entering the next item retargets the stagers (once per item)
 #define PR_ADVANCE()                                                                   \
     do {                                                                               \
         s_par ^= 1;                                                                    \
-        if (!s_dummy && ++s_kt == s_KT) {                                              \
+        if constexpr (SB) {                                                            \
+            if (!s_dummy) {                                                            \
+                if (++s_kt == s_KT) {                                                  \
+                    sp += G;                                                           \
+                    if (sp < items) {                                                  \
+                        PItem nx_;                                                     \
+                        decode_item(g, sp, nx_);                                       \
+                        sa.init(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN, 2);  \
+                        sb.init(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN, 2);  \
+                        sa.make_scalar();                                              \
+                        sb.make_scalar();                                              \
+                        s_KT = nx_.KT;                                                 \
+                        s_kt = 0;                                                      \
+                    } else {                                                           \
+                        s_dummy = 1;      /* the cursor stays on the last K tile */    \
+                        s_kt = s_KT - 1;                                               \
+                    }                                                                  \
+                } else {                                                               \
+                    sa.step();                                                         \
+                    sb.step();                                                         \
+                }                                                                      \
+            }                                                                          \
+        } else if (!s_dummy && ++s_kt == s_KT) {                                       \
             sp += G;                                                                   \
             if (sp < items) {                                                          \
                 PItem nx_;                                                             \
@@ -843,7 +890,14 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     for (;;) {
         const bool has_next = cp + G < items;
         if (wr == 1) GR_BARRIER();
-        if (PH == 2) { for (int kt = 0; kt < cit.KT; ++kt) PR_TILE2(); }
+        if (PH == 2) {
+            if constexpr (SB) {      // trip count in a scalar register: no VALU compare + VCC branch per K tile
+                const int kt_n = __builtin_amdgcn_readfirstlane(cit.KT);
+                for (int kt = 0; kt < kt_n; ++kt) PR_TILE2();
+            } else {
+                for (int kt = 0; kt < cit.KT; ++kt) PR_TILE2();
+            }
+        }
         else { for (int kt = 0; kt < cit.KT; ++kt) PR_TILE(); }
         if (wr == 0) GR_BARRIER();
         if (!has_next) GR_VMCNT(0);      // the dummy pieces target `region`
@@ -1144,14 +1198,14 @@ void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t
     if (g.trace || g.variant) {      // diagnostics / A-B (XQ_GEMM_TRACE, XQ_GEMM_NO_SEGMENT_PRIO, XQ_GEMM_ROW1_PRIO): two phases, plain NT / NN / TN only
         if (ACT == ACT_NONE && AK != gm::KMAJOR_CONV) {
             constexpr int A2 = AK == gm::KMAJOR_CONV ? (int)gm::KMAJOR : AK;
-            const int var = (g.variant & 8) ? 8 : ((g.trace ? 1 : 0) | g.variant);
+            const int var = g.variant | ((g.trace && !(g.variant & 8)) ? 1 : 0);
 #define XQ_VAR_CASE(V)                                                                                                           \
     case V:                                                                                                                      \
         if (set_lds<gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>>(lds)) return;                                                     \
         hipLaunchKernelGGL((gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>), dim3((unsigned)grid), dim3(GT), lds, s, g);              \
         return;
             switch (var) {
-                XQ_VAR_CASE(1) XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(8)
+                XQ_VAR_CASE(1) XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(8) XQ_VAR_CASE(16) XQ_VAR_CASE(17) XQ_VAR_CASE(24)
                 default: break;
             }
 #undef XQ_VAR_CASE
@@ -1255,7 +1309,8 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
 unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
 void bind_trace(GemmArgs &g, int impl) {
-    g.variant = (impl & XQ_GEMM_TRACE_SUMS) ? 8 : (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
+    g.variant = ((impl & XQ_GEMM_TRACE_SUMS) ? 8 : 0) | ((impl & XQ_GEMM_SCALAR_BASE) ? 16 : 0);
+    if (!g.variant) g.variant = (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
     if ((impl & (XQ_GEMM_TRACE | XQ_GEMM_TRACE_SUMS)) && g_trace_buf && g_trace_cap >= 16) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block & 0xffff; g.trace_item = g_trace_block >> 16; }
 }
 

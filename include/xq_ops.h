@@ -405,6 +405,8 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
                                            scalar registers over the whole kernel; the traced workgroup's 8 waves write [8] = phases summed, [9] = sum of
                                            (phase start -> arrival at the first barrier), [10] = (-> passed), [11] = (-> arrival at the second barrier =
                                            the MFMA segment), [12] = (-> next phase start), [13] = items of the workgroup */
+#define XQ_GEMM_SCALAR_BASE 0x80000     /* OR-ed into impl (NT / NN / TN, persistent two-phase; A/B, not yet validated as a default): the staging cursor's
+                                           tile pointers in scalar registers, advanced by a scalar add per K tile */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2

@@ -1,0 +1,50 @@
+"""A/B variants of the persistent GEMM kernel that have NOT been validated on hardware yet (written at the end of round 3 without GPU
+time left; include/xq_ops.h XQ_GEMM_SCALAR_BASE).  Off by default so that an unvalidated kernel cannot stop the suite:
+
+    XQ_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gemm_experimental_gpu.py -q
+
+Every variant must reproduce the default kernel's output BIT for bit (same work items, same MFMA order per accumulator: only address
+arithmetic moves from vector to scalar instructions), over repeated launches on the bench shapes and on the ragged / K-split shapes."""
+import os
+
+import pytest
+import torch
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("XQ_TEST_EXPERIMENTAL", "0") != "1", reason="unvalidated A/B kernels: set XQ_TEST_EXPERIMENTAL=1")]
+
+PERSISTENT_TWO_PHASE = 3 | 0x1000
+VARIANTS = {"scalar_base": 0x80000}
+# bench shapes + ragged rows / K-split tail tiles / more tiles than CUs (tests/test_gemm_gpu.py NT_SHAPES)
+SHAPES = [(65664, 2304, 768), (65664, 768, 3072), (65664, 3072, 768), (22300, 768, 768), (2052, 2304, 768), (300, 256, 128), (51400, 768, 128), (788, 1152, 384)]
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return (torch.randn(shape, generator=g, device="cuda") * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+@pytest.mark.parametrize("op", ["nt", "nn", "tn"])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_variant_is_bit_identical_to_the_default_kernel(M, N, K, op, variant):
+    from imagefolder_amd import ops_dense as od
+    if op == "tn":
+        a, b = _rand((M, N), 7), _rand((M, K), 8)
+        run = lambda: od.gemm_tn(a, b)
+    elif op == "nn":
+        a, b = _rand((M, N), 7), _rand((N, K), 8, 0.05)
+        run = lambda: od.gemm_nn(a, b)
+    else:
+        a, b = _rand((M, K), 7), _rand((N, K), 8, 0.05)
+        bias = torch.randn(N, device="cuda")
+        run = lambda: od.gemm_nt(a, b, bias)
+    try:
+        od.GEMM_SCHEDULE = PERSISTENT_TWO_PHASE | 0x100           # wide tiles: the persistent schedule also where N is not a multiple of 256
+        base = run()
+        od.GEMM_SCHEDULE = PERSISTENT_TWO_PHASE | 0x100 | VARIANTS[variant]
+        outs = [run() for _ in range(8)]
+    finally:
+        od.GEMM_SCHEDULE = 0
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, base), f"launch {i}: {(o != base).sum().item()} entries differ from the default kernel"
