@@ -85,7 +85,11 @@ struct GemmArgs {
     unsigned long long *trace;   // XQ_GEMM_TRACE (diagnostics): s_memtime stamps of the phases of workgroup trace_block's first item,
     int trace_cap, trace_block;  // [8 waves][trace_cap] (layout: xq_gemm_trace_bind in include/xq_ops.h); null = off
     int trace_item;              // which item of that workgroup's list is recorded (0 = first)
-    int variant;                 // VAR bits 2 / 4 of gemm_pring_kernel (XQ_GEMM_NO_SEGMENT_PRIO / XQ_GEMM_ROW1_PRIO)
+    int variant;                 // VAR bits of gemm_pring_kernel (XQ_GEMM_NO_SEGMENT_PRIO / _ROW1_PRIO / _TRACE_SUMS / _SCALAR_BASE)
+    int step_r, step_c;          // grid / tiles_n, grid % tiles_n: how the (row, column) tile of a workgroup's next whole-tile item follows
+                                 // from its current one (XQ_GEMM_SCALAR_BASE builds walk the tiles with scalar adds instead of dividing)
+    int skew;                    // XQ_GEMM_SCALAR_BASE builds only (experiment, environment XQ_GEMM_SKEW): workgroups start (row tile & 3) * skew
+                                 // * 1024 cycles apart, so that their epilogues do not store at the same moment
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
                             // ONE range of g / x rows through its L2 for all of that range's output tiles; tile-major order (0, the
@@ -113,11 +117,22 @@ struct Stager {
     unsigned off[2][2];     // [half][i]
     const char *base;       // tile base at K tile 0 (wave-uniform)
     long adv;               // bytes per K tile
+    bool interior;          // the tile `off` was computed for has all 256 rows / columns inside the matrix: no lane was clamped
     __device__ __forceinline__ void bind(const GemmArgs &) {}
+    // XQ_GEMM_SCALAR_BASE: next item.  Between two interior tiles the per-lane offsets do not change — only the tile base moves
+    __device__ __forceinline__ void retarget(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn) {
+        if (interior && rc_count - rc0 >= 256) {
+            if (KIND == gm::KMAJOR) base = mat + (rc0 * ld + k0) * 2;
+            else base = mat + (k0 * ld + rc0) * 2;
+        } else {
+            init(mat, ld, rc0, rc_count, k0, wave, lane, wtn, 2);
+        }
+    }
     // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
     __device__ __forceinline__ void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn,
                                          int halves) {
         const long avail = rc_count - rc0;          // valid rows / columns from the tile origin
+        interior = avail >= 256 && halves == 2;
         if (KIND == gm::KMAJOR) {
             base = mat + (rc0 * ld + k0) * 2;
             adv = gm::BKT * 2;
@@ -588,6 +603,25 @@ __device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it
     it.KT = (int)(base + (split < rem ? 1 : 0));
 }
 
+// XQ_GEMM_SCALAR_BASE: the whole-tile items of one workgroup are `grid` tiles apart; (row, col) of the next one by scalar adds.
+// decode_item's 64-bit divisions are ~700 scalar instructions = the 1.6 - 2.3 k-cycle stall of the load phase once per item
+// (profiles/r03_gemm_where_the_cycles_go.md).  Precondition: the item before (p - grid) was a whole-tile item decoded into (row, col).
+__device__ __forceinline__ void next_item_walk(const GemmArgs &g, long p, int &row, int &col, PItem &it) {
+    if (p < g.main_items) {
+        col += g.step_c;
+        row += g.step_r;
+        if (col >= g.tiles_n) { col -= g.tiles_n; ++row; }
+        it.m0 = (long)row * gm::BM;
+        it.n0 = (long)col * 256;
+        it.k0 = 0;
+        it.KT = g.kt_full;
+        it.slab = 0;
+        it.slab_idx = 0;
+    } else {
+        decode_item(g, p, it);
+    }
+}
+
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
@@ -668,6 +702,13 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     if (cp >= items) return;
     PItem cit;
     decode_item(g, cp, cit);
+    int c_row = 0, c_col = 0, s_row = 0, s_col = 0;      // SB: tile coordinates of the compute / staging cursor's whole-tile item
+    if constexpr ((VAR & 16) != 0) {
+        c_row = __builtin_amdgcn_readfirstlane((int)(cit.m0 / gm::BM));
+        c_col = __builtin_amdgcn_readfirstlane((int)(cit.n0 / 256));
+        s_row = c_row;
+        s_col = c_col;
+    }
 
     // staging cursor
     Stager<AK, true> sa;
@@ -719,9 +760,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                     sp += G;                                                           \
                     if (sp < items) {                                                  \
                         PItem nx_;                                                     \
-                        decode_item(g, sp, nx_);                                       \
-                        sa.init(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN, 2);  \
-                        sb.init(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN, 2);  \
+                        next_item_walk(g, sp, s_row, s_col, nx_);                      \
+                        sa.retarget(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN); \
+                        sb.retarget(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN); \
                         sa.make_scalar();                                              \
                         sb.make_scalar();                                              \
                         s_KT = nx_.KT;                                                 \
@@ -886,6 +927,11 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     GR_BARRIER();
 
     const int h = lane >> 5;
+    if constexpr (SB) {
+        // the first K tiles are on their way (prologue above); hold this workgroup back by its class
+        const int hold = __builtin_amdgcn_readfirstlane((int)((cit.m0 >> 8) & 3)) * g.skew;
+        for (int i = 0; i < hold; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     if (ROW1_PRIO && wr == 1) __builtin_amdgcn_s_setprio(1);
     for (;;) {
         const bool has_next = cp + G < items;
@@ -1030,7 +1076,8 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         if (!has_next) break;
         PR_ZERO()
         cp += G;
-        decode_item(g, cp, cit);
+        if constexpr (SB) next_item_walk(g, cp, c_row, c_col, cit);
+        else decode_item(g, cp, cit);
     }
     if (SUMS) {
         if (g.trace != nullptr && (int)blockIdx.x == g.trace_block && lane == 0) {
@@ -1276,6 +1323,8 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         g.slabs = (float *)ws;
         const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
         const long grid = items < num_cus() ? items : num_cus();
+        g.step_r = (int)(grid / g.tiles_n);
+        g.step_c = (int)(grid % g.tiles_n);
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
         if (set_lds<gemm_pring_kernel<AK, BK, ACT, 2>>(lds) || set_lds<gemm_pring_kernel<AK, BK, ACT, 4>>(lds))
             return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
@@ -1310,6 +1359,10 @@ unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
 void bind_trace(GemmArgs &g, int impl) {
     g.variant = ((impl & XQ_GEMM_TRACE_SUMS) ? 8 : 0) | ((impl & XQ_GEMM_SCALAR_BASE) ? 16 : 0);
+    if (impl & XQ_GEMM_SCALAR_BASE) {
+        static const int skew = [] { const char *e = std::getenv("XQ_GEMM_SKEW"); const int v = e ? std::atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
+        g.skew = skew;
+    }
     if (!g.variant) g.variant = (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
     if ((impl & (XQ_GEMM_TRACE | XQ_GEMM_TRACE_SUMS)) && g_trace_buf && g_trace_cap >= 16) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block & 0xffff; g.trace_item = g_trace_block >> 16; }
 }

@@ -121,7 +121,7 @@ def analyse(tr, emit, label, brief=False, first=0):
 
 def sums_case(fn, fl, ref, a, emit):
     def run(bits):
-        od.GEMM_SCHEDULE = PLAIN | bits
+        od.GEMM_SCHEDULE = PLAIN | bits | a.extra_bits
         try:
             return fn()
         finally:
@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--variants", nargs="*", default=None, help="subset of segprio noprio row1prio")
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--brief", action="store_true", help="two waves per table for the non-default variants")
+    ap.add_argument("--extra-bits", type=lambda x: int(x, 0), default=0, help="impl bits OR-ed into every launch, e.g. 0x80000 = XQ_GEMM_SCALAR_BASE")
     ap.add_argument("--sums", action="store_true", help="XQ_GEMM_TRACE_SUMS instead of the per-phase records: four clock reads per phase, differenced and "
                     "summed in scalar registers over every item of the workgroup (no VALU / LDS / extra waits: the low-perturbation measurement)")
     a = ap.parse_args()
@@ -197,14 +198,14 @@ def main():
                     continue
 
                 def plain(fn=fn, bits=bits):
-                    od.GEMM_SCHEDULE = PLAIN | bits
+                    od.GEMM_SCHEDULE = PLAIN | bits | a.extra_bits
                     try:
                         return fn()
                     finally:
                         od.GEMM_SCHEDULE = 0
 
                 def traced(fn=fn, bits=bits):
-                    od.GEMM_SCHEDULE = TRACE | bits
+                    od.GEMM_SCHEDULE = TRACE | bits | a.extra_bits
                     try:
                         return fn()
                     finally:
