@@ -1252,7 +1252,11 @@ void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t
         hipLaunchKernelGGL((gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>), dim3((unsigned)grid), dim3(GT), lds, s, g);              \
         return;
             switch (var) {
-                XQ_VAR_CASE(1) XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(8) XQ_VAR_CASE(16) XQ_VAR_CASE(17) XQ_VAR_CASE(24)
+                XQ_VAR_CASE(1) XQ_VAR_CASE(8)
+#ifdef XQ_EXPERIMENTAL      // make EXTRA=-DXQ_EXPERIMENTAL: the priority A/B kernels (measured in round 3: no effect) and the scalar-base
+                            // kernels, which have not run on hardware yet, stay out of the default library
+                XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(16) XQ_VAR_CASE(17) XQ_VAR_CASE(24)
+#endif
                 default: break;
             }
 #undef XQ_VAR_CASE
@@ -1357,7 +1361,12 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
 // XQ_GEMM_TRACE target (xq_gemm_trace_bind)
 unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
-void bind_trace(GemmArgs &g, int impl) {
+int bind_trace(GemmArgs &g, int impl, const char *fn) {
+#ifndef XQ_EXPERIMENTAL
+    if (impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO))
+        return xq_set_error(XQ_EINVAL, "%s: impl bits 0x%x need a library built with -DXQ_EXPERIMENTAL (make -C imagefolder_amd/csrc EXTRA=-DXQ_EXPERIMENTAL)", fn,
+                            impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO));
+#endif
     g.variant = ((impl & XQ_GEMM_TRACE_SUMS) ? 8 : 0) | ((impl & XQ_GEMM_SCALAR_BASE) ? 16 : 0);
     if (impl & XQ_GEMM_SCALAR_BASE) {
         static const int skew = [] { const char *e = std::getenv("XQ_GEMM_SKEW"); const int v = e ? std::atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
@@ -1365,6 +1374,7 @@ void bind_trace(GemmArgs &g, int impl) {
     }
     if (!g.variant) g.variant = (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
     if ((impl & (XQ_GEMM_TRACE | XQ_GEMM_TRACE_SUMS)) && g_trace_buf && g_trace_cap >= 16) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block & 0xffff; g.trace_item = g_trace_block >> 16; }
+    return XQ_OK;
 }
 
 int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
@@ -1413,7 +1423,7 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
-    bind_trace(g, impl);
+    if (int rc = bind_trace(g, impl, fn)) return rc;
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1432,7 +1442,7 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
     g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
-    bind_trace(g, impl);
+    if (int rc = bind_trace(g, impl, fn)) return rc;
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1456,7 +1466,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
-    bind_trace(g, impl_bits);
+    if (int rc = bind_trace(g, impl_bits, fn)) return rc;
     g.A = (const char *)g_y; g.B = (const char *)x; g.C = (char *)ws;
     g.M = P; g.N = Q; g.lda = P; g.ldb = Q; g.ldc = Q;
     g.tiles_m = (int)((P + 255) / 256); g.tiles_n = (int)((Q + BN - 1) / BN);

@@ -399,14 +399,15 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
                                      times both on the first call of a shape and keeps the faster one.  Bit-identical results either way */
 #define XQ_GEMM_TRACE 0x8000      /* OR-ed into impl (NT / NN / TN, persistent schedule): run the two-phase kernel with shader-clock stamps into the
                                      buffer bound by xq_gemm_trace_bind (diagnostics; results unchanged) */
-#define XQ_GEMM_NO_SEGMENT_PRIO 0x10000 /* OR-ed into impl (NT / NN / TN, persistent two-phase): no s_setprio around the MFMA segments (A/B) */
-#define XQ_GEMM_ROW1_PRIO 0x20000       /* ... and wave row 1 (waves 4-7) at priority 1 for the whole kernel instead (A/B) */
+#define XQ_GEMM_NO_SEGMENT_PRIO 0x10000 /* EXPERIMENTAL build only (XQ_EINVAL otherwise): no s_setprio around the MFMA segments — measured in round 3: no effect */
+#define XQ_GEMM_ROW1_PRIO 0x20000       /* EXPERIMENTAL build only: ... and wave row 1 (waves 4-7) at priority 1 for the whole kernel instead — no effect either */
 #define XQ_GEMM_TRACE_SUMS 0x40000      /* OR-ed into impl with a trace buffer bound: the low-perturbation trace — per-phase clock differences summed in
                                            scalar registers over the whole kernel; the traced workgroup's 8 waves write [8] = phases summed, [9] = sum of
                                            (phase start -> arrival at the first barrier), [10] = (-> passed), [11] = (-> arrival at the second barrier =
                                            the MFMA segment), [12] = (-> next phase start), [13] = items of the workgroup */
-#define XQ_GEMM_SCALAR_BASE 0x80000     /* OR-ed into impl (NT / NN / TN, persistent two-phase; A/B, not yet validated as a default): the staging cursor's
-                                           tile pointers in scalar registers, advanced by a scalar add per K tile */
+#define XQ_GEMM_SCALAR_BASE 0x80000     /* OR-ed into impl (NT / NN / TN, persistent two-phase).  EXPERIMENTAL, not in the default build (XQ_EINVAL unless
+                                           the library was made with EXTRA=-DXQ_EXPERIMENTAL): the staging cursor's tile pointers in scalar registers,
+                                           advanced by a scalar add per K tile; whole-tile items walked by scalar adds instead of 64-bit divisions */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2

@@ -1,6 +1,7 @@
 """A/B variants of the persistent GEMM kernel that have NOT been validated on hardware yet (written at the end of round 3 without GPU
 time left; include/xq_ops.h XQ_GEMM_SCALAR_BASE).  Off by default so that an unvalidated kernel cannot stop the suite:
 
+    touch imagefolder_amd/csrc/xq_gemm.hip && make -C imagefolder_amd/csrc EXTRA=-DXQ_EXPERIMENTAL -j8     # the default library leaves them out
     XQ_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gemm_experimental_gpu.py -q
 
 Every variant must reproduce the default kernel's output BIT for bit (same work items, same MFMA order per accumulator: only address

@@ -194,8 +194,8 @@ def main():
                 del ref
                 continue
             for vname, bits in VARIANTS:
-                if a.variants and vname.split()[0].rstrip(":") not in a.variants:
-                    continue
+                if (a.variants and vname.split()[0].rstrip(":") not in a.variants) or (not a.variants and bits):
+                    continue          # the priority variants need a library built with EXTRA=-DXQ_EXPERIMENTAL: only on request
 
                 def plain(fn=fn, bits=bits):
                     od.GEMM_SCHEDULE = PLAIN | bits | a.extra_bits

@@ -1,5 +1,8 @@
 #!/bin/bash
 # First GPU call of round 4 (~3 GPU-minutes): validates and prices the A/B kernels written blind at the end of round 3.
+# BEFORE the call, in the container (the built .so travels with the snapshot):
+#     touch imagefolder_amd/csrc/xq_gemm.hip && make -C imagefolder_amd/csrc EXTRA=-DXQ_EXPERIMENTAL -j8
+# and AFTER it, unless the variant is adopted:  touch imagefolder_amd/csrc/xq_gemm.hip && make -C imagefolder_amd/csrc -j8
 #   1. bit-identity of XQ_GEMM_SCALAR_BASE against the default persistent kernel (tests/test_gemm_experimental_gpu.py)
 #   2. cycles per phase (XQ_GEMM_TRACE_SUMS) of the default and the scalar-base kernel on qkv / fc2, NT / NN / TN
 #   3. kernel times: default vs scalar base vs scalar base + start skew (XQ_GEMM_SKEW = 1024-cycle units per class)
