@@ -576,51 +576,11 @@ __global__ __launch_bounds__(GT) void gemm_ring_kernel(const GemmArgs g) {
 //   vmcnt                         : stores of the epilogue may still be outstanding in the next item's first phases; they only
 //                                   make the counted waits stricter (more operations pending than the count assumes)
 // =====================================================================================================================
-struct PItem {
-    long m0, n0, k0;
-    int KT;
-    int slab;            // 0: bf16 epilogue into C; 1: fp32 slab
-    long slab_idx;
-};
-
-__device__ __forceinline__ void decode_item(const GemmArgs &g, long p, PItem &it) {
-    long tile, split, nsplit;
-    if (p < g.main_items) { tile = p; split = 0; nsplit = 1; it.slab = 0; it.slab_idx = 0; }
-    else {
-        const long q = p - g.main_items;
-        nsplit = g.tail_splits;
-        long tl;
-        if (g.split_major) { split = q / g.tail_tiles; tl = q - split * g.tail_tiles; }
-        else { tl = q / nsplit; split = q - tl * nsplit; }
-        tile = g.main_items + tl;
-        it.slab = 1;
-        it.slab_idx = tl * nsplit + split;       // slab layout [tile][split] whatever the execution order (slab_reduce_kernel)
-    }
-    it.m0 = (tile / g.tiles_n) * gm::BM;
-    it.n0 = (tile % g.tiles_n) * 256;
-    const long base = g.kt_full / nsplit, rem = g.kt_full % nsplit;
-    it.k0 = (split * base + (split < rem ? split : rem)) * gm::BKT;
-    it.KT = (int)(base + (split < rem ? 1 : 0));
-}
-
-// XQ_GEMM_SCALAR_BASE: the whole-tile items of one workgroup are `grid` tiles apart; (row, col) of the next one by scalar adds.
-// decode_item's 64-bit divisions are ~700 scalar instructions = the 1.6 - 2.3 k-cycle stall of the load phase once per item
-// (profiles/r03_gemm_where_the_cycles_go.md).  Precondition: the item before (p - grid) was a whole-tile item decoded into (row, col).
-__device__ __forceinline__ void next_item_walk(const GemmArgs &g, long p, int &row, int &col, PItem &it) {
-    if (p < g.main_items) {
-        col += g.step_c;
-        row += g.step_r;
-        if (col >= g.tiles_n) { col -= g.tiles_n; ++row; }
-        it.m0 = (long)row * gm::BM;
-        it.n0 = (long)col * 256;
-        it.k0 = 0;
-        it.KT = g.kt_full;
-        it.slab = 0;
-        it.slab_idx = 0;
-    } else {
-        decode_item(g, p, it);
-    }
-}
+// work items of the persistent schedule: gm::Item / gm::decode_item / gm::next_item_walk in xq_gemm_map.hpp (host + device: the CPU test
+// tests/test_gemm_map_cpu.py replays every workgroup's item list through them)
+typedef gm::Item PItem;
+using gm::decode_item;
+using gm::next_item_walk;
 
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }

@@ -100,4 +100,57 @@ GM_HD long xcd_order(long id, long total) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
 }
 
+// ---- work items of the persistent schedule (gemm_pring_kernel) ----------------------------------------------------------------------
+// Position p of the item list: p < main_items is the whole output tile p (bf16 epilogue); the tail_tiles tiles behind them are cut into
+// tail_splits K ranges each, one item per range (fp32 slab [tile][split]), executed tile-major or split-major.  G = any struct with the
+// fields main_items, tail_tiles, tail_splits, split_major, tiles_n, kt_full (csrc/xq_gemm.hip GemmArgs; the CPU test's own struct).
+struct Item {
+    long m0, n0, k0;     // output row / column of the tile, first reduction index of the item's K range
+    int KT;              // K tiles of the item
+    int slab;            // 0: bf16 epilogue into C; 1: fp32 slab
+    long slab_idx;
+};
+
+template <class G>
+GM_HD void decode_item(const G &g, long p, Item &it) {
+    long tile, split, nsplit;
+    if (p < g.main_items) { tile = p; split = 0; nsplit = 1; it.slab = 0; it.slab_idx = 0; }
+    else {
+        const long q = p - g.main_items;
+        nsplit = g.tail_splits;
+        long tl;
+        if (g.split_major) { split = q / g.tail_tiles; tl = q - split * g.tail_tiles; }
+        else { tl = q / nsplit; split = q - tl * nsplit; }
+        tile = g.main_items + tl;
+        it.slab = 1;
+        it.slab_idx = tl * nsplit + split;       // slab layout [tile][split] whatever the execution order (slab_reduce_kernel)
+    }
+    it.m0 = (tile / g.tiles_n) * BM;
+    it.n0 = (tile % g.tiles_n) * 256;
+    const long base = g.kt_full / nsplit, rem = g.kt_full % nsplit;
+    it.k0 = (split * base + (split < rem ? split : rem)) * BKT;
+    it.KT = (int)(base + (split < rem ? 1 : 0));
+}
+
+// XQ_GEMM_SCALAR_BASE: the whole-tile items of one workgroup are `grid` tiles apart; (row, col) of the next one by scalar adds
+// (G additionally has step_r = grid / tiles_n, step_c = grid % tiles_n).  decode_item's 64-bit divisions are ~700 scalar instructions =
+// the 1.6 - 2.3 k-cycle stall of the load phase once per item (profiles/r03_gemm_where_the_cycles_go.md).
+// Precondition: the item before (p - grid) was a whole-tile item whose tile coordinates are (row, col).
+template <class G>
+GM_HD void next_item_walk(const G &g, long p, int &row, int &col, Item &it) {
+    if (p < g.main_items) {
+        col += g.step_c;
+        row += g.step_r;
+        if (col >= g.tiles_n) { col -= g.tiles_n; ++row; }
+        it.m0 = (long)row * BM;
+        it.n0 = (long)col * 256;
+        it.k0 = 0;
+        it.KT = g.kt_full;
+        it.slab = 0;
+        it.slab_idx = 0;
+    } else {
+        decode_item(g, p, it);
+    }
+}
+
 }  // namespace gm

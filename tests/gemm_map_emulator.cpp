@@ -5,7 +5,8 @@
 //     element (L % 4) of the 4-element rows addressed by lanes (L / 4) + 4 j, j = 0..3 (profiles/r01_ds_read_tr_probe.txt);
 //   * v_mfma_f32_32x32x16_bf16 D = A.B + C: operand lane l holds row/column (l & 31), k = 8 (l >> 5) + 0..7; D register r of
 //     lane l is D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31]  (cdna_hip_programming.md §3).
-// It also counts LDS bank conflicts of every fragment read with the gfx950 lane grouping (MI355X_MICROARCH.md §LDS).
+// It also counts LDS bank conflicts of every fragment read with the gfx950 lane grouping (MI355X_MICROARCH.md §LDS), and replays the
+// item lists of the persistent schedule (check_item_lists below).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -162,6 +163,77 @@ static void run(int BN, unsigned seed) {
     std::printf("AK=%d BK=%d BN=%d: %s; bank-conflict cycles: b128 %ld, tr %ld\n", AK, BK, BN, g_fail ? "FAIL" : "ok", g_conf_b128, g_conf_tr);
 }
 
+// ---- work items of the persistent schedule --------------------------------------------------------------------------------------------
+// Replays every workgroup's item list (positions cp, cp + G, ... with cp = xcd_order(block, G)) for the plans csrc/xq_gemm.hip makes
+// (plan_persistent is restated here: whole tiles for the full rounds of CUs, the remainder cut along K; weight gradient: every tile cut),
+// and checks (1) every (tile, K tile) of the product is covered exactly once, slabs are distinct; (2) the scalar tile walk of the
+// XQ_GEMM_SCALAR_BASE kernels (next_item_walk) yields field for field what decode_item yields, for the compute AND the staging cursor.
+struct Plan {
+    long main_items;
+    int tail_tiles, tail_splits, split_major, tiles_n, kt_full, step_r, step_c;
+};
+
+static void check_plan(long tiles_m, int tiles_n, int kt_full, long cus, bool weight_grad) {
+    const long tiles = tiles_m * tiles_n;
+    Plan g{tiles, 0, 1, 0, tiles_n, kt_full, 0, 0};
+    if (weight_grad) {
+        long s = cus / tiles; if (s > kt_full / 2) s = kt_full / 2; if (s < 1) s = 1;
+        g.main_items = 0; g.tail_tiles = (int)tiles; g.tail_splits = (int)s; g.split_major = 1;
+    } else {
+        const long rem = tiles % cus;
+        if (tiles > cus && rem > 0 && rem <= cus / 4 && kt_full >= 4) {
+            long S = cus / rem; if (S > kt_full / 2) S = kt_full / 2;
+            if (S >= 2) { g.main_items = tiles - rem; g.tail_tiles = (int)rem; g.tail_splits = (int)S; }
+        }
+    }
+    const long items = g.main_items + (long)g.tail_tiles * g.tail_splits;
+    const long G = items < cus ? items : cus;
+    g.step_r = (int)(G / tiles_n);
+    g.step_c = (int)(G % tiles_n);
+    std::vector<int> cover((size_t)tiles * kt_full, 0);
+    std::set<long> slabs;
+    int bad = 0;
+    for (long b = 0; b < G; ++b) {
+        long cp = xcd_order(b, G);
+        if (cp >= items) continue;
+        Item ref, walk;
+        decode_item(g, cp, ref);
+        int row = (int)(ref.m0 / BM), col = (int)(ref.n0 / 256);
+        walk = ref;
+        for (;;) {
+            if (walk.m0 != ref.m0 || walk.n0 != ref.n0 || walk.k0 != ref.k0 || walk.KT != ref.KT || walk.slab != ref.slab || walk.slab_idx != ref.slab_idx) {
+                if (bad++ < 3) std::printf("item walk differs at p=%ld (tiles %ld x %d, kt %d, G %ld): m0 %ld/%ld n0 %ld/%ld k0 %ld/%ld KT %d/%d\n", cp, tiles_m, tiles_n,
+                                           kt_full, G, walk.m0, ref.m0, walk.n0, ref.n0, walk.k0, ref.k0, walk.KT, ref.KT);
+            }
+            const long tile = (ref.m0 / BM) * tiles_n + ref.n0 / 256;
+            if (ref.KT < (ref.slab ? 1 : 2) || ref.k0 % BKT || tile < 0 || tile >= tiles) { bad++; std::printf("bad item at p=%ld\n", cp); break; }
+            for (int t = 0; t < ref.KT; ++t) cover[(size_t)tile * kt_full + ref.k0 / BKT + t]++;
+            if (ref.slab && !slabs.insert(ref.slab_idx).second) { bad++; std::printf("slab %ld used twice\n", ref.slab_idx); }
+            cp += G;
+            if (cp >= items) break;
+            decode_item(g, cp, ref);
+            next_item_walk(g, cp, row, col, walk);
+        }
+    }
+    for (int c : cover) if (c != 1) { bad++; break; }
+    if (bad) { g_fail++; std::printf("item lists FAIL: tiles %ld x %d, kt %d, cus %ld, weight_grad %d (%d problems)\n", tiles_m, tiles_n, kt_full, cus, (int)weight_grad, bad); }
+}
+
+static void check_item_lists() {
+    int n = 0;
+    for (long cus : {256L, 304L, 8L})
+        for (long tiles_m : {1L, 2L, 3L, 29L, 88L, 129L, 257L})
+            for (int tiles_n : {1, 2, 3, 9, 12})
+                for (int kt : {2, 3, 4, 12, 36, 48}) {
+                    check_plan(tiles_m, tiles_n, kt, cus, false);
+                    ++n;
+                }
+    for (int tiles_n : {1, 3, 12})            // weight gradients: P x Q tiles, R / 64 K tiles
+        for (long tiles_m : {3L, 9L, 12L})
+            for (int kt : {2, 5, 401, 1026}) { check_plan(tiles_m, tiles_n, kt, 256, true); ++n; }
+    std::printf("item lists: %d plans replayed (coverage exactly once; scalar tile walk == decode_item)%s\n", n, g_fail ? " — FAIL" : "");
+}
+
 int main() {
     for (int BN : {256, 128}) {
         run<KMAJOR, KMAJOR>(BN, 1);
@@ -178,6 +250,7 @@ int main() {
         }
         for (int c : seen) if (c != 1) { g_fail++; std::printf("xcd_order(total=%ld) is not a bijection\n", total); break; }
     }
+    check_item_lists();
     std::printf(g_fail ? "FAILED\n" : "ALL OK\n");
     return g_fail ? 1 : 0;
 }
