@@ -45,3 +45,34 @@ def test_every_hot_kernel_has_a_body(tmp_path):
                 seen.add(key)
                 assert size >= least, f"{name}: {size} bytes of code — the kernel body was optimised away?"
     assert seen == set(EXPECT), f"kernels not found in the build: {sorted(set(EXPECT) - seen)}"
+
+
+def test_k_loop_of_the_persistent_gemm_kernels_is_clean(tmp_path):
+    """tools/isa_loop_stats.py on the built object: the K loop of every persistent two-phase GEMM kernel issues exactly 32 MFMAs and 8 LDS-DMA
+    instructions per K tile and wave, and holds no register-spill traffic (scratch_*, v_readlane / v_writelane) — spills belong to the cold
+    item-change path; one inside the loop would sit on the critical load phase (profiles/r03_gemm_where_the_cycles_go.md)."""
+    import importlib.util
+    obj = os.path.join(ROOT, "imagefolder_amd", "csrc", "_build", "xq_gemm.o")
+    if not os.path.exists(obj) or not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("no build tree / no LLVM tools here")
+    spec = importlib.util.spec_from_file_location("isa_loop_stats", os.path.join(ROOT, "tools", "isa_loop_stats.py"))
+    ils = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ils)
+    ks = ils.kernels(ils.disassemble(obj))
+    checked = 0
+    for name, ins in ks.items():
+        if "gemm_pring_kernelILi" not in name or "ELi2ELi0E" not in name:      # <AK, BK, ACT, PH = 2, VAR = 0>: the product kernels
+            continue
+        if "gemm_pring_kernelILi2E" in name:      # implicit-GEMM convolution: its gather arithmetic sits inside the loop, other shape of loop
+            continue
+        lp = ils.find_loop(ins)
+        assert lp is not None, f"no two-phase K loop found in {name}"
+        head, b0, b1, b2, b3, br = lp
+        body = ins[head:br + 1]
+        ops = [op for _, op, _ in body]
+        assert sum(o.startswith("v_mfma") for o in ops) == 32, name
+        assert sum(o.startswith("global_load_lds") for o in ops) == 8, name
+        assert not [o for o in ops if o.startswith("scratch_") or o in ("v_readlane_b32", "v_writelane_b32")], f"spill traffic inside the K loop of {name}"
+        assert sum(o == "s_barrier" for o in ops) == 4, name
+        checked += 1
+    assert checked >= 5, f"only {checked} persistent two-phase kernels found"

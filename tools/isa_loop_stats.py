@@ -68,7 +68,7 @@ def find_loop(ins):
         b0, b1, b2, b3 = bars[j:j + 4]
         if nm(b0, b1) == 16 and nm(b1, b2) == 0 and nm(b2, b3) == 16:
             # backward branch behind b3
-            for k in range(b3 + 1, min(b3 + 40, len(ins))):
+            for k in range(b3 + 1, min(b3 + 600, len(ins))):
                 addr, op, args = ins[k]
                 if op.startswith("s_cbranch") or op == "s_branch":
                     off = int(args.split()[0])
