@@ -679,6 +679,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     if constexpr (SB) { sa.make_scalar(); sb.make_scalar(); }
     long sp = cp;
     int s_kt = 0, s_KT = cit.KT, s_par = 0, r_par = 0;
+    if constexpr (SB) s_KT = __builtin_amdgcn_readfirstlane(s_KT);
     // past the last item the cursor keeps issuing the SAME number of LDS-DMA instructions per phase (re-reading its last K
     // tile into this wave's own epilogue staging area), so that the counted vmcnt(8) of the phases stays exact to the end
     // of the stream and one tile body serves every K tile
@@ -725,7 +726,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                         sb.retarget(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN); \
                         sa.make_scalar();                                              \
                         sb.make_scalar();                                              \
-                        s_KT = nx_.KT;                                                 \
+                        s_KT = __builtin_amdgcn_readfirstlane(nx_.KT);                 \
                         s_kt = 0;                                                      \
                     } else {                                                           \
                         s_dummy = 1;      /* the cursor stays on the last K tile */    \
