@@ -112,51 +112,14 @@ __device__ __forceinline__ bf16x4 tr4(const char *p) {
 // per-thread staging state of one operand: byte offsets (relative to the operand's tile base) of this lane's 16-byte chunk
 // in the two LDS-DMA instructions of each half piece
 // ---------------------------------------------------------------------------------------------------------------------
+// address arithmetic (tile base, per-lane offsets, scalar cursor): gm::StagerAddr in xq_gemm_map.hpp, shared with the CPU replay
 template <int KIND, bool IS_A>
-struct Stager {
-    unsigned off[2][2];     // [half][i]
-    const char *base;       // tile base at K tile 0 (wave-uniform)
-    long adv;               // bytes per K tile
-    bool interior;          // the tile `off` was computed for has all 256 rows / columns inside the matrix: no lane was clamped
+struct Stager : gm::StagerAddr<KIND, IS_A> {
+    using gm::StagerAddr<KIND, IS_A>::off;
+    using gm::StagerAddr<KIND, IS_A>::base;
+    using gm::StagerAddr<KIND, IS_A>::adv;
+    using gm::StagerAddr<KIND, IS_A>::cur;
     __device__ __forceinline__ void bind(const GemmArgs &) {}
-    // XQ_GEMM_SCALAR_BASE: next item.  Between two interior tiles the per-lane offsets do not change — only the tile base moves
-    __device__ __forceinline__ void retarget(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn) {
-        if (interior && rc_count - rc0 >= 256) {
-            if (KIND == gm::KMAJOR) base = mat + (rc0 * ld + k0) * 2;
-            else base = mat + (k0 * ld + rc0) * 2;
-        } else {
-            init(mat, ld, rc0, rc_count, k0, wave, lane, wtn, 2);
-        }
-    }
-    // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
-    __device__ __forceinline__ void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn,
-                                         int halves) {
-        const long avail = rc_count - rc0;          // valid rows / columns from the tile origin
-        interior = avail >= 256 && halves == 2;
-        if (KIND == gm::KMAJOR) {
-            base = mat + (rc0 * ld + k0) * 2;
-            adv = gm::BKT * 2;
-        } else {
-            base = mat + (k0 * ld + rc0) * 2;
-            adv = (long)gm::BKT * ld * 2;
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (h >= halves) { off[h][i] = 0; continue; }
-                const gm::StageSrc s = gm::stage_src<KIND, IS_A>(h, wave, i, lane, wtn);
-                if (KIND == gm::KMAJOR) {
-                    long rc = s.rc;
-                    if (rc > avail - 1) rc = avail - 1;
-                    off[h][i] = (unsigned)((rc * ld + s.k) * 2);
-                } else {
-                    long rc = s.rc;
-                    if (rc > avail - 8) rc = avail - 8;     // 8 consecutive columns (dimension is a multiple of 8)
-                    off[h][i] = (unsigned)(((long)s.k * ld + rc) * 2);
-                }
-            }
-    }
     // issue the two LDS-DMA instructions of piece `half` of K tile `kt` into LDS `dst` (wave-uniform piece base)
     __device__ __forceinline__ void issue(int half, long kt, char *dst, int wave) const {
         const char *b = base + kt * adv;
@@ -166,15 +129,6 @@ struct Stager {
     }
     // XQ_GEMM_SCALAR_BASE (A/B, not yet the default): the tile pointer of the K tile being staged lives in scalar registers and moves by
     // a scalar add per K tile — no v_lshl_add_u64 + 2 x v_readfirstlane per piece in the load phase (profiles/r03_gemm_where_the_cycles_go.md)
-    const char *cur;
-    __device__ __forceinline__ void make_scalar() {
-        const unsigned long long b = (unsigned long long)base, a = (unsigned long long)adv;
-        const unsigned blo = __builtin_amdgcn_readfirstlane((unsigned)b), bhi = __builtin_amdgcn_readfirstlane((unsigned)(b >> 32));
-        const unsigned alo = __builtin_amdgcn_readfirstlane((unsigned)a), ahi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        cur = (const char *)(((unsigned long long)bhi << 32) | blo);
-        adv = (long)(((unsigned long long)ahi << 32) | alo);
-    }
-    __device__ __forceinline__ void step() { cur += adv; }
     __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const {
 #pragma unroll
         for (int i = 0; i < 2; ++i)

@@ -100,6 +100,75 @@ GM_HD long xcd_order(long id, long total) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + id / 8;
 }
 
+// ---- staging addresses ------------------------------------------------------------------------------------------------------------------
+// Per-thread staging state of one operand: byte offsets (relative to the operand's tile base) of this lane's 16-byte chunk in the two
+// LDS-DMA instructions of each half piece, the tile base and its advance per K tile.  csrc/xq_gemm.hip derives its Stager (which adds the
+// LDS-DMA issue) from it; tests/gemm_map_emulator.cpp replays whole item streams through it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GM_RFL(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define GM_RFL(x) (x)
+#endif
+template <int KIND, bool IS_A>
+struct StagerAddr {
+    unsigned off[2][2];     // [half][i]
+    const char *base;       // tile base at K tile 0 (wave-uniform)
+    long adv;               // bytes per K tile
+    bool interior;          // the tile `off` was computed for has all 256 rows / columns inside the matrix: no lane was clamped
+    // XQ_GEMM_SCALAR_BASE: next item.  Between two interior tiles the per-lane offsets do not change — only the tile base moves
+    GM_HD void retarget(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn) {
+        if (interior && rc_count - rc0 >= 256) {
+            if (KIND == KMAJOR) base = mat + (rc0 * ld + k0) * 2;
+            else base = mat + (k0 * ld + rc0) * 2;
+        } else {
+            init(mat, ld, rc0, rc_count, k0, wave, lane, wtn, 2);
+        }
+    }
+    // rows/cols beyond `limit` (elements of the non-reduction axis inside this tile) are clamped (their outputs are never stored)
+    GM_HD void init(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn, int halves) {
+        const long avail = rc_count - rc0;          // valid rows / columns from the tile origin
+        interior = avail >= 256 && halves == 2;
+        if (KIND == KMAJOR) {
+            base = mat + (rc0 * ld + k0) * 2;
+            adv = BKT * 2;
+        } else {
+            base = mat + (k0 * ld + rc0) * 2;
+            adv = (long)BKT * ld * 2;
+        }
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+        for (int h = 0; h < 2; ++h)
+#if defined(__HIPCC__)
+#pragma unroll
+#endif
+            for (int i = 0; i < 2; ++i) {
+                if (h >= halves) { off[h][i] = 0; continue; }
+                const StageSrc s = stage_src<KIND, IS_A>(h, wave, i, lane, wtn);
+                if (KIND == KMAJOR) {
+                    long rc = s.rc;
+                    if (rc > avail - 1) rc = avail - 1;
+                    off[h][i] = (unsigned)((rc * ld + s.k) * 2);
+                } else {
+                    long rc = s.rc;
+                    if (rc > avail - 8) rc = avail - 8;     // 8 consecutive columns (dimension is a multiple of 8)
+                    off[h][i] = (unsigned)(((long)s.k * ld + rc) * 2);
+                }
+            }
+    }
+    // XQ_GEMM_SCALAR_BASE: the tile pointer of the K tile being staged, wave-uniform by construction (kept in scalar registers), moved by a
+    // scalar add per K tile
+    const char *cur;
+    GM_HD void make_scalar() {
+        const unsigned long long b = (unsigned long long)base, a = (unsigned long long)adv;
+        const unsigned blo = GM_RFL((unsigned)b), bhi = GM_RFL((unsigned)(b >> 32));
+        const unsigned alo = GM_RFL((unsigned)a), ahi = GM_RFL((unsigned)(a >> 32));
+        cur = (const char *)(((unsigned long long)bhi << 32) | blo);
+        adv = (long)(((unsigned long long)ahi << 32) | alo);
+    }
+    GM_HD void step() { cur += adv; }
+};
+
 // ---- work items of the persistent schedule (gemm_pring_kernel) ----------------------------------------------------------------------
 // Position p of the item list: p < main_items is the whole output tile p (bf16 epilogue); the tail_tiles tiles behind them are cut into
 // tail_splits K ranges each, one item per range (fp32 slab [tile][split]), executed tile-major or split-major.  G = any struct with the

@@ -219,6 +219,113 @@ static void check_plan(long tiles_m, int tiles_n, int kt_full, long cus, bool we
     if (bad) { g_fail++; std::printf("item lists FAIL: tiles %ld x %d, kt %d, cus %ld, weight_grad %d (%d problems)\n", tiles_m, tiles_n, kt_full, cus, (int)weight_grad, bad); }
 }
 
+// ---- staging address streams ------------------------------------------------------------------------------------------------------------
+// The XQ_GEMM_SCALAR_BASE kernels (scalar tile cursor moved by adds, tile walk, per-lane offsets kept between interior tiles) must stage
+// exactly the bytes the default kernel stages (base + kt * adv + off, decode_item + init per item — the path validated on the GPU): for
+// every workgroup of a plan, for a sample of lanes, the two address streams are compared K tile by K tile, both operands, all four
+// LDS-DMA instructions of a tile.  The control flow restates PR_ADVANCE of csrc/xq_gemm.hip; the arithmetic is gm::StagerAddr itself.
+template <int AK, int BK>
+static void check_streams(long M, long N, long Kred, long cus, bool weight_grad) {
+    const long tiles_m = (M + 255) / 256, tiles = tiles_m * ((N + 255) / 256);
+    const int tiles_n = (int)((N + 255) / 256), kt_full = (int)(Kred / 64);
+    Plan g{tiles, 0, 1, 0, tiles_n, kt_full, 0, 0};
+    if (weight_grad) {
+        long sp = cus / tiles; if (sp > kt_full / 2) sp = kt_full / 2; if (sp < 1) sp = 1;
+        g.main_items = 0; g.tail_tiles = (int)tiles; g.tail_splits = (int)sp; g.split_major = 1;
+    } else {
+        const long rem = tiles % cus;
+        if (tiles > cus && rem > 0 && rem <= cus / 4 && kt_full >= 4) {
+            long S = cus / rem; if (S > kt_full / 2) S = kt_full / 2;
+            if (S >= 2) { g.main_items = tiles - rem; g.tail_tiles = (int)rem; g.tail_splits = (int)S; }
+        }
+    }
+    const long items = g.main_items + (long)g.tail_tiles * g.tail_splits;
+    const long G = items < cus ? items : cus;
+    g.step_r = (int)(G / tiles_n);
+    g.step_c = (int)(G % tiles_n);
+    // operands: A [M rows][lda] or [Kred][lda = M] ; addresses only, never dereferenced
+    const char *A = (const char *)0x100000000ULL, *B = (const char *)0x900000000ULL;
+    const long lda = (AK == KMAJOR) ? Kred : M, ldb = (BK == KMAJOR) ? Kred : N;
+    long compared = 0;
+    int bad = 0;
+    for (long b = 0; b < G; b += (G > 40 ? 7 : 1)) {
+        const long cp0 = xcd_order(b, G);
+        if (cp0 >= items) continue;
+        for (int wave : {0, 3, 5, 7})
+            for (int lane : {0, 9, 31, 32, 47, 63}) {
+                // default kernel
+                std::vector<unsigned long long> ref;
+                for (long p = cp0; p < items; p += G) {
+                    Item it;
+                    decode_item(g, p, it);
+                    StagerAddr<AK, true> sa;
+                    StagerAddr<BK, false> sb;
+                    sa.init(A, lda, it.m0, M, it.k0, wave, lane, 64, 2);
+                    sb.init(B, ldb, it.n0, N, it.k0, wave, lane, 64, 2);
+                    for (int kt = 0; kt < it.KT; ++kt)
+                        for (int h = 0; h < 2; ++h)
+                            for (int i = 0; i < 2; ++i) {
+                                ref.push_back((unsigned long long)(sa.base + kt * sa.adv + sa.off[h][i]));
+                                ref.push_back((unsigned long long)(sb.base + kt * sb.adv + sb.off[h][i]));
+                            }
+                }
+                // scalar-base kernel: cursor + walk + retarget
+                std::vector<unsigned long long> got;
+                {
+                    Item it;
+                    long sp = cp0;
+                    decode_item(g, sp, it);
+                    int row = (int)(it.m0 / BM), col = (int)(it.n0 / 256);
+                    StagerAddr<AK, true> sa;
+                    StagerAddr<BK, false> sb;
+                    sa.init(A, lda, it.m0, M, it.k0, wave, lane, 64, 2);
+                    sb.init(B, ldb, it.n0, N, it.k0, wave, lane, 64, 2);
+                    sa.make_scalar();
+                    sb.make_scalar();
+                    int s_kt = 0, s_KT = it.KT, s_dummy = 0;
+                    while (!s_dummy) {
+                        for (int h = 0; h < 2; ++h)
+                            for (int i = 0; i < 2; ++i) {
+                                got.push_back((unsigned long long)(sa.cur + sa.off[h][i]));
+                                got.push_back((unsigned long long)(sb.cur + sb.off[h][i]));
+                            }
+                        // PR_ADVANCE, SB branch
+                        if (++s_kt == s_KT) {
+                            sp += G;
+                            if (sp < items) {
+                                Item nx;
+                                next_item_walk(g, sp, row, col, nx);
+                                sa.retarget(A, lda, nx.m0, M, nx.k0, wave, lane, 64);
+                                sb.retarget(B, ldb, nx.n0, N, nx.k0, wave, lane, 64);
+                                sa.make_scalar();
+                                sb.make_scalar();
+                                s_KT = nx.KT;
+                                s_kt = 0;
+                            } else {
+                                s_dummy = 1;
+                            }
+                        } else {
+                            sa.step();
+                            sb.step();
+                        }
+                    }
+                }
+                if (got != ref) {
+                    if (bad++ < 3) {
+                        size_t k = 0;
+                        while (k < got.size() && k < ref.size() && got[k] == ref[k]) ++k;
+                        std::printf("address streams differ: block %ld wave %d lane %d at entry %zu of %zu / %zu (AK %d BK %d M %ld N %ld K %ld)\n", b, wave, lane, k,
+                                    got.size(), ref.size(), AK, BK, M, N, Kred);
+                    }
+                }
+                compared += (long)ref.size();
+            }
+    }
+    if (bad) g_fail++;
+    std::printf("staging streams AK=%d BK=%d M=%ld N=%ld K=%ld%s: %ld addresses compared, %s\n", AK, BK, M, N, Kred, weight_grad ? " (weight gradient)" : "", compared,
+                bad ? "FAIL" : "ok");
+}
+
 static void check_item_lists() {
     int n = 0;
     for (long cus : {256L, 304L, 8L})
@@ -251,6 +358,17 @@ int main() {
         for (int c : seen) if (c != 1) { g_fail++; std::printf("xcd_order(total=%ld) is not a bijection\n", total); break; }
     }
     check_item_lists();
+    // bench shapes (ragged last row tile: 65 664 = 256.5 x 256), a ragged column tile (N = 1152), K-split tails (22 300 x 768: 88 x 3 = 264 tiles)
+    check_streams<KMAJOR, KMAJOR>(65664, 2304, 768, 256, false);
+    check_streams<KMAJOR, KMAJOR>(65664, 768, 3072, 256, false);
+    check_streams<KMAJOR, KMAJOR>(22300, 768, 768, 256, false);
+    check_streams<KMAJOR, KMAJOR>(788, 1152, 384, 256, false);
+    check_streams<KMAJOR, KSTRIDED>(65664, 768, 2304, 256, false);
+    check_streams<KMAJOR, KSTRIDED>(22300, 768, 768, 256, false);
+    check_streams<KMAJOR, KSTRIDED>(2052, 3072, 768, 256, false);
+    check_streams<KSTRIDED, KSTRIDED>(2304, 768, 65664, 256, true);
+    check_streams<KSTRIDED, KSTRIDED>(768, 3072, 65664, 256, true);
+    check_streams<KSTRIDED, KSTRIDED>(1152, 384, 788 / 64 * 64, 256, true);
     std::printf(g_fail ? "FAILED\n" : "ALL OK\n");
     return g_fail ? 1 : 0;
 }
