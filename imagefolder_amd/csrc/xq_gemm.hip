@@ -129,6 +129,13 @@ struct Stager : gm::StagerAddr<KIND, IS_A> {
     }
     // XQ_GEMM_SCALAR_BASE (A/B, not yet the default): the tile pointer of the K tile being staged lives in scalar registers and moves by
     // a scalar add per K tile — no v_lshl_add_u64 + 2 x v_readfirstlane per piece in the load phase (profiles/r03_gemm_where_the_cycles_go.md)
+    // one of the two instructions (XQ_GEMM_INTERLEAVE: LDS-DMA instructions alternate with fragment reads)
+    __device__ __forceinline__ void issue_one(int half, int i, long kt, char *dst, int wave) const {
+        __builtin_amdgcn_global_load_lds((gbl_void *)(base + kt * adv + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+    }
+    __device__ __forceinline__ void issue_cur_one(int half, int i, char *dst, int wave) const {
+        __builtin_amdgcn_global_load_lds((gbl_void *)(cur + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
+    }
     __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -551,6 +558,12 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     // every item of the workgroup except each item's first; the traced workgroup writes the six numbers at the end of the kernel.
     constexpr bool SUMS = (VAR & 8) != 0;
     constexpr bool SB = (VAR & 16) != 0;      // XQ_GEMM_SCALAR_BASE
+    // VAR bit 32 (XQ_GEMM_INTERLEAVE): the phase's four LDS-DMA instructions alternate with its fragment reads instead of following them.
+    // A wave's LDS-DMA issue is paced by the CU's one vector-memory address path (~75 cycles per instruction with four waves of a row
+    // issuing at once, profiles/r03_gemm_where_the_cycles_go.md) while its ds_reads go down the LDS path: in sequence the two add up to
+    // the load phase, interleaved the reads issue in the DMA instructions' shadow.  Same instructions, same counted waits; staging a
+    // piece earlier inside its phase is safe (its slot's last read returned two barriers earlier, see the hazard notes below).
+    constexpr bool IL = (VAR & 32) != 0;
     unsigned long long q_s = 0, q_a = 0, q_p = 0, q_e = 0;
     unsigned q_s_prev = 0, q_n = 0, q_phases = 0, q_items = 0, q_load = 0, q_bar1 = 0, q_mfma = 0, q_bar2 = 0;
 #define PR_Q(X)                                                   \
@@ -665,6 +678,20 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             else sa.issue(1, s_kt, PR_SDST(3), wave);                 \
         }                                                             \
     } while (0)
+#define PR_STAGE1(Q, I)                                                        \
+    do {                                                                       \
+        if constexpr (SB) {                                                    \
+            if ((Q) == 0) sa.issue_cur_one(0, (I), PR_SDST(0), wave);          \
+            else if ((Q) == 1) sb.issue_cur_one(0, (I), PR_SDST(1), wave);     \
+            else if ((Q) == 2) sb.issue_cur_one(1, (I), PR_SDST(2), wave);     \
+            else sa.issue_cur_one(1, (I), PR_SDST(3), wave);                   \
+        } else {                                                               \
+            if ((Q) == 0) sa.issue_one(0, (I), s_kt, PR_SDST(0), wave);        \
+            else if ((Q) == 1) sb.issue_one(0, (I), s_kt, PR_SDST(1), wave);   \
+            else if ((Q) == 2) sb.issue_one(1, (I), s_kt, PR_SDST(2), wave);   \
+            else sa.issue_one(1, (I), s_kt, PR_SDST(3), wave);                 \
+        }                                                                      \
+    } while (0)
     // next K tile of the stream; entering the next item retargets the stagers (once per item)
 #define PR_ADVANCE()                                                                   \
     do {                                                                               \
@@ -713,6 +740,8 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         af[0][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, 0, s_, lane);                  \
         af[1][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, 1, s_, lane);                  \
     }
+#define PR_READ_A_F(Q, F) \
+    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) af[F][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, (F), s_, lane);
 #define PR_READ_B(DST, Q) \
     _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) DST[s_] = read_frag<BK, false>(PR_RSLOT(Q), wc, 0, s_, lane);
 #define PR_PIN(X) asm volatile("" : "+v"(X))
@@ -830,6 +859,49 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         r_par ^= 1;                                                           \
     } while (0)
 
+    // XQ_GEMM_INTERLEAVE: the same K tile with the LDS-DMA instructions between the fragment reads (clock sums only, no per-phase records)
+#define PR_TILE2I()                                                           \
+    do {                                                                      \
+        PR_Q(q_s);                                                            \
+        PR_STAGE1(2, 0);                                                      \
+        PR_READ_B(bl, 1)                                                      \
+        PR_STAGE1(2, 1);                                                      \
+        PR_READ_B(br, 2)                                                      \
+        PR_STAGE1(3, 0);                                                      \
+        PR_READ_A_F(0, 0)                                                     \
+        PR_STAGE1(3, 1);                                                      \
+        PR_READ_A_F(0, 1)                                                     \
+        GR_LGKM0();                                                           \
+        PR_Q_ACC();                                                           \
+        GR_VMCNT(8);                                                          \
+        PR_Q(q_a);                                                            \
+        GR_BARRIER();                                                         \
+        PR_Q(q_p);                                                            \
+        PR_MFMA(0, 0, bl);                                                    \
+        PR_MFMA(0, 1, br);                                                    \
+        PR_Q(q_e);                                                            \
+        GR_BARRIER();                                                         \
+        PR_Q(q_s);                                                            \
+        PR_READ_A_F(3, 0)                                                     \
+        PR_ADVANCE();                                                         \
+        PR_STAGE1(0, 0);                                                      \
+        PR_READ_A_F(3, 1)                                                     \
+        PR_STAGE1(0, 1);                                                      \
+        PR_STAGE1(1, 0);                                                      \
+        PR_STAGE1(1, 1);                                                      \
+        GR_LGKM0();                                                           \
+        PR_Q_ACC();                                                           \
+        GR_VMCNT(6);                                                          \
+        PR_Q(q_a);                                                            \
+        GR_BARRIER();                                                         \
+        PR_Q(q_p);                                                            \
+        PR_MFMA(2, 1, br);                                                    \
+        PR_MFMA(2, 0, bl);                                                    \
+        PR_Q(q_e);                                                            \
+        GR_BARRIER();                                                         \
+        r_par ^= 1;                                                           \
+    } while (0)
+
     // prologue: K tile 0 of the first item completely, A-top + B-left of its K tile 1
     PR_STAGE(0);
     PR_STAGE(1);
@@ -852,7 +924,10 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         const bool has_next = cp + G < items;
         if (wr == 1) GR_BARRIER();
         if (PH == 2) {
-            if constexpr (SB) {      // trip count in a scalar register: no VALU compare + VCC branch per K tile
+            if constexpr (IL) {
+                const int kt_n = __builtin_amdgcn_readfirstlane(cit.KT);
+                for (int kt = 0; kt < kt_n; ++kt) PR_TILE2I();
+            } else if constexpr (SB) {      // trip count in a scalar register: no VALU compare + VCC branch per K tile
                 const int kt_n = __builtin_amdgcn_readfirstlane(cit.KT);
                 for (int kt = 0; kt < kt_n; ++kt) PR_TILE2();
             } else {
@@ -1007,6 +1082,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #undef PR_T_KEEP
 #undef PR_TILE
 #undef PR_TILE2
+#undef PR_TILE2I
+#undef PR_STAGE1
+#undef PR_READ_A_F
 #undef GR_LGKM0
 #undef PR_MFMA
 #undef PR_PIN
@@ -1170,7 +1248,7 @@ void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t
                 XQ_VAR_CASE(1) XQ_VAR_CASE(8)
 #ifdef XQ_EXPERIMENTAL      // make EXTRA=-DXQ_EXPERIMENTAL: the priority A/B kernels (measured in round 3: no effect) and the scalar-base
                             // kernels, which have not run on hardware yet, stay out of the default library
-                XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(16) XQ_VAR_CASE(17) XQ_VAR_CASE(24)
+                XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(16) XQ_VAR_CASE(17) XQ_VAR_CASE(24) XQ_VAR_CASE(32) XQ_VAR_CASE(40) XQ_VAR_CASE(48) XQ_VAR_CASE(56)
 #endif
                 default: break;
             }
@@ -1278,11 +1356,11 @@ unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
 int bind_trace(GemmArgs &g, int impl, const char *fn) {
 #ifndef XQ_EXPERIMENTAL
-    if (impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO))
+    if (impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_INTERLEAVE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO))
         return xq_set_error(XQ_EINVAL, "%s: impl bits 0x%x need a library built with -DXQ_EXPERIMENTAL (make -C imagefolder_amd/csrc EXTRA=-DXQ_EXPERIMENTAL)", fn,
-                            impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO));
+                            impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_INTERLEAVE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO));
 #endif
-    g.variant = ((impl & XQ_GEMM_TRACE_SUMS) ? 8 : 0) | ((impl & XQ_GEMM_SCALAR_BASE) ? 16 : 0);
+    g.variant = ((impl & XQ_GEMM_TRACE_SUMS) ? 8 : 0) | ((impl & XQ_GEMM_SCALAR_BASE) ? 16 : 0) | ((impl & XQ_GEMM_INTERLEAVE) ? 32 : 0);
     if (impl & XQ_GEMM_SCALAR_BASE) {
         static const int skew = [] { const char *e = std::getenv("XQ_GEMM_SKEW"); const int v = e ? std::atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
         g.skew = skew;

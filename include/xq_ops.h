@@ -408,6 +408,9 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_SCALAR_BASE 0x80000     /* OR-ed into impl (NT / NN / TN, persistent two-phase).  EXPERIMENTAL, not in the default build (XQ_EINVAL unless
                                            the library was made with EXTRA=-DXQ_EXPERIMENTAL): the staging cursor's tile pointers in scalar registers,
                                            advanced by a scalar add per K tile; whole-tile items walked by scalar adds instead of 64-bit divisions */
+#define XQ_GEMM_INTERLEAVE 0x100000     /* EXPERIMENTAL build only (may be combined with XQ_GEMM_SCALAR_BASE / _TRACE_SUMS): the four LDS-DMA instructions of a phase
+                                           alternate with its fragment reads instead of following them (the DMA issue is paced by the CU's vector-memory
+                                           address path, the reads go down the LDS path: in sequence they add up to the load phase) */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2

@@ -1,11 +1,11 @@
 """A/B variants of the persistent GEMM kernel that have NOT been validated on hardware yet (written at the end of round 3 without GPU
-time left; include/xq_ops.h XQ_GEMM_SCALAR_BASE).  Off by default so that an unvalidated kernel cannot stop the suite:
+time left; include/xq_ops.h XQ_GEMM_SCALAR_BASE, XQ_GEMM_INTERLEAVE).  Off by default so that an unvalidated kernel cannot stop the suite:
 
     touch imagefolder_amd/csrc/xq_gemm.hip && make -C imagefolder_amd/csrc EXTRA=-DXQ_EXPERIMENTAL -j8     # the default library leaves them out
     XQ_TEST_EXPERIMENTAL=1 python -m pytest tests/test_gemm_experimental_gpu.py -q
 
 Every variant must reproduce the default kernel's output BIT for bit (same work items, same MFMA order per accumulator: only address
-arithmetic moves from vector to scalar instructions), over repeated launches on the bench shapes and on the ragged / K-split shapes."""
+arithmetic moves from vector to scalar instructions, or the LDS-DMA instructions move between the fragment reads), over repeated launches on the bench shapes and on the ragged / K-split shapes."""
 import os
 
 import pytest
@@ -14,7 +14,7 @@ import torch
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("XQ_TEST_EXPERIMENTAL", "0") != "1", reason="unvalidated A/B kernels: set XQ_TEST_EXPERIMENTAL=1")]
 
 PERSISTENT_TWO_PHASE = 3 | 0x1000
-VARIANTS = {"scalar_base": 0x80000}
+VARIANTS = {"scalar_base": 0x80000, "interleave": 0x100000, "scalar_base_interleave": 0x180000}
 # bench shapes + ragged rows / K-split tail tiles / more tiles than CUs (tests/test_gemm_gpu.py NT_SHAPES)
 SHAPES = [(65664, 2304, 768), (65664, 768, 3072), (65664, 3072, 768), (22300, 768, 768), (2052, 2304, 768), (300, 256, 128), (51400, 768, 128), (788, 1152, 384)]
 
