@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: GPU test suite, default bench line, rocprofv3 kernel trace of the same command, PMC traffic passes.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_check.sh <tag> [parts]'
-# parts: any of  tests bench trace pmc shapes sections configs cnntrace gemmtests gemmab   (default: the first five)
+# parts: any of  tests bench trace pmc shapes sections configs cnntrace gemmtests gemmab gemmclock   (default: the first five)
 TAG=${1:-check}; export XQ_TAG=$TAG
 PARTS=${2:-"tests bench trace pmc shapes"}
 export TMPDIR=/tmp
@@ -49,6 +49,11 @@ if has gemmab; then
   # weight-gradient item order A/B: 3 = persistent (split-major, default), 0x403 = persistent with the old tile-major order
   timeout 300 python tools/bench_gemm.py --rows 65664 --scheds 3 0x403 --only tn --out $OUT/gemm_tn_order.txt > /dev/null 2> $OUT/gemmab.err
   cat $OUT/gemm_tn_order.txt
+fi
+if has gemmclock; then
+  # in-kernel shader-clock sums of the persistent GEMM kernel: cycles per phase (load / barrier wait / MFMA / barrier wait) per shape and op
+  timeout 120 python tools/gemm_timeline.py --layers qkv proj fc1 fc2 --ops nt nn tn --sums --out $OUT/gemm_phase_sums.txt > $OUT/gemm_phase_sums.log 2>&1
+  echo "gemmclock rc=$?"; grep -E "^## |K tile period" $OUT/gemm_phase_sums.txt | cut -c1-160
 fi
 if has configs; then
   for CFG in VP2-16384 MSVR10P2-4096 RobustTok; do
