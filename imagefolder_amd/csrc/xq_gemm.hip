@@ -11,12 +11,14 @@
 // registers, no ds_write pass) in 16 KiB pieces laid out for conflict-free fragment reads (xq_gemm_map.hpp); K-strided operands
 // are read with the gfx950 transpose read ds_read_b64_tr_b16, so no operand is ever transposed in memory.
 //
-// Two schedules:
+// Three schedules:
 //   gemm_simple_kernel : 2 LDS buffers, one vmcnt(0) + barrier per K tile; any BN; the reference schedule of the tests.
 //   gemm_ring_kernel   : BN = 256.  8-slot piece ring, one piece (2 LDS-DMA instructions per wave) issued per phase, 6 pieces
 //                        ahead of the reads, counted s_waitcnt vmcnt(8) (never 0 in the loop), 4 phases of 8 MFMAs per K tile
 //                        and wave; the two wave rows run one barrier interval apart, so that on every SIMD one wave is in its
 //                        MFMA segment while the other issues its LDS reads / DMA (cdna_hip_programming.md §5 "8-phase").
+//   gemm_pring_kernel  : the product schedule.  The same ring kept streaming across a per-CU list of work items, two phases of 16
+//                        MFMAs per K tile, operand tile pointers in scalar registers.
 // Epilogue: accumulators (+ bias) -> bf16 through a wave-private LDS region -> full-row 16-byte stores; TN: fp32 float4 stores
 // into the split's slab, summed by splitk_reduce_kernel (which also folds the < 64-row remainder of R).
 #include "xq_common.hpp"
@@ -27,10 +29,6 @@
 
 #include <hip/hip_bf16.h>
 
-#include <cstdlib>
-#include <map>
-#include <mutex>
-#include <tuple>
 
 using namespace xq;
 
@@ -78,18 +76,11 @@ struct GemmArgs {
     int nt_store;           // non-temporal bf16 output stores (default; XQ_GEMM_PLAIN_STORE turns them off): the 128 KiB a CU
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
-    int phases;             // phases per K tile of the persistent kernel: 2 (16 MFMAs each), 4 (8 MFMAs each: the round-2 schedule) or
-                            // 0 = default (two; or timed per shape under XQ_GEMM_TUNE=1: pick_phases below).  Bit-identical results.
-                            // XQ_GEMM_TWO_PHASE / XQ_GEMM_FOUR_PHASE force one.
     int tile_major_debug;   // XQ_GEMM_TILE_MAJOR: keep the weight gradient's items tile-major (A/B timing of the order below)
-    unsigned long long *trace;   // XQ_GEMM_TRACE (diagnostics): s_memtime stamps of the phases of workgroup trace_block's first item,
+    unsigned long long *trace;   // XQ_GEMM_TRACE_SUMS (diagnostics): where workgroup trace_block writes its summed phase clocks,
     int trace_cap, trace_block;  // [8 waves][trace_cap] (layout: xq_gemm_trace_bind in include/xq_ops.h); null = off
-    int trace_item;              // which item of that workgroup's list is recorded (0 = first)
-    int variant;                 // VAR bits of gemm_pring_kernel (XQ_GEMM_NO_SEGMENT_PRIO / _ROW1_PRIO / _TRACE_SUMS / _SCALAR_BASE)
     int step_r, step_c;          // grid / tiles_n, grid % tiles_n: how the (row, column) tile of a workgroup's next whole-tile item follows
-                                 // from its current one (XQ_GEMM_SCALAR_BASE builds walk the tiles with scalar adds instead of dividing)
-    int skew;                    // XQ_GEMM_SCALAR_BASE builds only (experiment, environment XQ_GEMM_SKEW): workgroups start (row tile & 3) * skew
-                                 // * 1024 cycles apart, so that their epilogues do not store at the same moment
+                                 // from its current one (the persistent kernel walks its tiles with scalar adds instead of dividing)
     int split_major;        // order of the K-split items of the persistent schedule.  1 (weight gradient): split-major — the items
                             // of one reduction range sit next to each other, so an XCD (contiguous run of items, xcd_order) streams
                             // ONE range of g / x rows through its L2 for all of that range's output tiles; tile-major order (0, the
@@ -127,15 +118,8 @@ struct Stager : gm::StagerAddr<KIND, IS_A> {
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((gbl_void *)(b + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
     }
-    // XQ_GEMM_SCALAR_BASE (A/B, not yet the default): the tile pointer of the K tile being staged lives in scalar registers and moves by
-    // a scalar add per K tile — no v_lshl_add_u64 + 2 x v_readfirstlane per piece in the load phase (profiles/r03_gemm_where_the_cycles_go.md)
-    // one of the two instructions (XQ_GEMM_INTERLEAVE: LDS-DMA instructions alternate with fragment reads)
-    __device__ __forceinline__ void issue_one(int half, int i, long kt, char *dst, int wave) const {
-        __builtin_amdgcn_global_load_lds((gbl_void *)(base + kt * adv + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
-    }
-    __device__ __forceinline__ void issue_cur_one(int half, int i, char *dst, int wave) const {
-        __builtin_amdgcn_global_load_lds((gbl_void *)(cur + off[half][i]), (lds_void *)(dst + (2 * wave + i) * 1024), 16, 0, 0);
-    }
+    // persistent schedule: the tile pointer of the K tile being staged lives in scalar registers (StagerAddr::cur) and moves by a scalar
+    // add per K tile — no v_lshl_add_u64 + 2 x v_readfirstlane per piece in the load phase (profiles/r03_gemm_where_the_cycles_go.md)
     __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -153,6 +137,7 @@ struct Stager<gm::KMAJOR_CONV, true> {
     const char *X;
     int Hi, Wi, Cin, stride, pad, up, transposed, Hl, Wl;
     long kt0;                     // first K tile of this work item
+    long ktc;                     // persistent schedule: K tile (relative to kt0) the staging cursor stands on
     int pix0[2][2];               // [half][i]: pixel index of (b, 0, 0)  (B * Hi * Wi < 2^31, checked by the launcher)
     int oyx[2][2];                // (oy << 16) | ox; -1: row beyond M
     unsigned kbyte[2];            // [i]: byte offset of the lane's chunk inside the 64-wide K slice (independent of the half)
@@ -162,8 +147,15 @@ struct Stager<gm::KMAJOR_CONV, true> {
         ho_ = g.cv_Ho; wo_ = g.cv_Wo;
     }
     int ho_, wo_;
+    __device__ __forceinline__ void retarget(const char *m, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn) {
+        init(m, ld, rc0, rc_count, k0, wave, lane, wtn, 2);
+    }
+    __device__ __forceinline__ void make_scalar() {}
+    __device__ __forceinline__ void step() { ++ktc; }
+    __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const { issue(half, ktc, dst, wave); }
     __device__ __forceinline__ void init(const char *, long, long rc0, long rc_count, long k0, int wave, int lane, int wtn, int) {
         kt0 = k0 / gm::BKT;
+        ktc = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -546,24 +538,14 @@ using gm::next_item_walk;
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
-template <int AK, int BK, int ACT, int PH = 4, int VAR = 0>
+template <int AK, int BK, int ACT, bool SUMS = false>
 __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int WTN = 64;
-    // VAR bits (diagnostics / A-B, PH = 2): 1 = clock stamps (XQ_GEMM_TRACE), 2 = no s_setprio around the MFMA segments
-    // (XQ_GEMM_NO_SEGMENT_PRIO), 4 = wave row 1 at priority 1 for the whole kernel (XQ_GEMM_ROW1_PRIO; with bit 2)
-    constexpr int TRACE = VAR & 1;
-    // VAR bit 8 (XQ_GEMM_TRACE_SUMS): the low-perturbation form of the trace — four clock reads per phase (phase start, arrival at the
-    // first barrier, first barrier passed, arrival at the second barrier), differenced and summed in SGPRs (scalar ALU only: no VALU, no
-    // LDS, no extra s_waitcnt — the differences are taken right behind the phase's own lgkmcnt(0), one phase late), over every phase of
-    // every item of the workgroup except each item's first; the traced workgroup writes the six numbers at the end of the kernel.
-    constexpr bool SUMS = (VAR & 8) != 0;
-    constexpr bool SB = (VAR & 16) != 0;      // XQ_GEMM_SCALAR_BASE
-    // VAR bit 32 (XQ_GEMM_INTERLEAVE): the phase's four LDS-DMA instructions alternate with its fragment reads instead of following them.
-    // A wave's LDS-DMA issue is paced by the CU's one vector-memory address path (~75 cycles per instruction with four waves of a row
-    // issuing at once, profiles/r03_gemm_where_the_cycles_go.md) while its ds_reads go down the LDS path: in sequence the two add up to
-    // the load phase, interleaved the reads issue in the DMA instructions' shadow.  Same instructions, same counted waits; staging a
-    // piece earlier inside its phase is safe (its slot's last read returned two barriers earlier, see the hazard notes below).
-    constexpr bool IL = (VAR & 32) != 0;
+    // SUMS (diagnostics: XQ_GEMM_TRACE_SUMS + xq_gemm_trace_bind, tools/gemm_timeline.py): four shader-clock reads per phase (phase start,
+    // arrival at the first barrier, first barrier passed, arrival at the second barrier), differenced and summed in SGPRs (scalar ALU only:
+    // no VALU, no LDS, no extra s_waitcnt — the differences are taken right behind the phase's own lgkmcnt(0), one phase late) over every
+    // phase of every item of the workgroup except each item's first; the traced workgroup writes the six numbers at the end of the kernel.
+    // Outputs are bit-identical to the plain kernel (tests/test_gemm_gpu.py).
     unsigned long long q_s = 0, q_a = 0, q_p = 0, q_e = 0;
     unsigned q_s_prev = 0, q_n = 0, q_phases = 0, q_items = 0, q_load = 0, q_bar1 = 0, q_mfma = 0, q_bar2 = 0;
 #define PR_Q(X)                                                   \
@@ -588,37 +570,6 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             ++q_n;                                                                       \
         }                                                                                \
     } while (0)
-    constexpr bool SEG_PRIO = !(VAR & 2);
-    constexpr bool ROW1_PRIO = (VAR & 4) != 0;
-    // TRACE = 1 (PH = 2 only; tools/gemm_timeline.py): every wave reads the shader clock at 9 points of each phase (0 phase start,
-    // 1 fragment reads issued, 2 trace record written, 3 LDS-DMA issued, 4 lgkmcnt(0) over, 5 vmcnt wait over = arrival at the first
-    // barrier, 6 first barrier passed, 7 eight of the 16 MFMAs issued, 8 all 16 issued = arrival at the second barrier); the waves of one
-    // workgroup keep the stamps of the recorded item's first 28 phases (LDS, upper half of the wave's epilogue staging area; the record
-    // is written between the fragment reads and the LDS-DMA issue — a DS write behind the wave's own LDS-DMA waits for that DMA to land,
-    // profiles/r03_gemm_phase_timeline_*.txt — so a record holds points 0-1 of its phase and points 2-8 of the phase before) and copy
-    // them out before that item's epilogue.  All workgroups execute the reads, so the traced one runs like its neighbours.
-    unsigned long long ts[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const bool tr_on = TRACE && g.trace != nullptr && (int)blockIdx.x == g.trace_block;
-    int tr_n = 0;
-    int tr_cur = 0;          // index of the current item in this workgroup's list; item g.trace_item is the recorded one
-#define PR_T(I)                                                   \
-    do {                                                          \
-        if (TRACE) {                                              \
-            __builtin_amdgcn_sched_barrier(0);                    \
-            ts[I] = __builtin_amdgcn_s_memtime();                 \
-            __builtin_amdgcn_sched_barrier(0);                    \
-        }                                                         \
-    } while (0)
-#define PR_T_KEEP()                                                                                              \
-    do {                                                                                                         \
-        if (TRACE) {                                                                                             \
-            if (tr_on && tr_cur == g.trace_item && tr_n < 28 && lane == 0) {                                     \
-                _Pragma("unroll") for (int i_ = 0; i_ < 9; ++i_)                                                 \
-                    *reinterpret_cast<unsigned long long *>(region + 2048 + (tr_n * 9 + i_) * 8) = ts[i_];       \
-            }                                                                                                    \
-            ++tr_n;                                                                                              \
-        }                                                                                                        \
-    } while (0)
     extern __shared__ __attribute__((aligned(16))) char smem[];     // 8 ring slots + 8 x 4 KiB epilogue staging
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -629,26 +580,26 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     if (cp >= items) return;
     PItem cit;
     decode_item(g, cp, cit);
-    int c_row = 0, c_col = 0, s_row = 0, s_col = 0;      // SB: tile coordinates of the compute / staging cursor's whole-tile item
-    if constexpr ((VAR & 16) != 0) {
-        c_row = __builtin_amdgcn_readfirstlane((int)(cit.m0 / gm::BM));
-        c_col = __builtin_amdgcn_readfirstlane((int)(cit.n0 / 256));
-        s_row = c_row;
-        s_col = c_col;
-    }
+    // tile coordinates of the compute / staging cursor's whole-tile item, in scalar registers: a workgroup's whole-tile items are G tiles
+    // apart, so the next one follows by scalar adds (next_item_walk) instead of decode_item's 64-bit divisions
+    int c_row = __builtin_amdgcn_readfirstlane((int)(cit.m0 / gm::BM));
+    int c_col = __builtin_amdgcn_readfirstlane((int)(cit.n0 / 256));
+    int s_row = c_row, s_col = c_col;
 
-    // staging cursor
+    // staging cursor: the tile pointers of the K tile being staged live in scalar registers and move by one scalar add per K tile;
+    // between two interior tiles the per-lane offsets are kept (Stager::retarget) — round 4: +5..17 % on every ViT-B shape over the
+    // per-piece v_lshl_add_u64 + v_readfirstlane form (profiles/r04_gemm_scalar_base.txt)
     Stager<AK, true> sa;
     Stager<BK, false> sb;
     sa.bind(g);
     sa.init(g.A, g.lda, cit.m0, g.M, cit.k0, wave, lane, WTN, 2);
     sb.init(g.B, g.ldb, cit.n0, g.N, cit.k0, wave, lane, WTN, 2);
-    if constexpr (SB) { sa.make_scalar(); sb.make_scalar(); }
+    sa.make_scalar();
+    sb.make_scalar();
     long sp = cp;
-    int s_kt = 0, s_KT = cit.KT, s_par = 0, r_par = 0;
-    if constexpr (SB) s_KT = __builtin_amdgcn_readfirstlane(s_KT);
+    int s_kt = 0, s_KT = __builtin_amdgcn_readfirstlane(cit.KT), s_par = 0, r_par = 0;
     // past the last item the cursor keeps issuing the SAME number of LDS-DMA instructions per phase (re-reading its last K
-    // tile into this wave's own epilogue staging area), so that the counted vmcnt(8) of the phases stays exact to the end
+    // tile into this wave's own epilogue staging area), so that the counted vmcnt of the phases stays exact to the end
     // of the stream and one tile body serves every K tile
     int s_dummy = 0;
     char *const region = smem + 8 * gm::PIECE_BYTES + wave * 4096;
@@ -662,76 +613,40 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 
 #define PR_SSLOT(Q) (smem + ((s_par << 2) + (Q)) * gm::PIECE_BYTES)
 #define PR_RSLOT(Q) (smem + ((r_par << 2) + (Q)) * gm::PIECE_BYTES)
-    // (dummy mode: destination = region - wave * 2048, so that issue()'s (2 wave + i) * 1024 lands inside this wave's area)
+    // (dummy mode: destination = region - wave * 2048, so that issue_cur()'s (2 wave + i) * 1024 lands inside this wave's area)
 #define PR_SDST(Q) (s_dummy ? region - wave * 2048 : PR_SSLOT(Q))
-#define PR_STAGE(Q)                                                   \
-    do {                                                              \
-        if constexpr (SB) {                                           \
-            if ((Q) == 0) sa.issue_cur(0, PR_SDST(0), wave);          \
-            else if ((Q) == 1) sb.issue_cur(0, PR_SDST(1), wave);     \
-            else if ((Q) == 2) sb.issue_cur(1, PR_SDST(2), wave);     \
-            else sa.issue_cur(1, PR_SDST(3), wave);                   \
-        } else {                                                      \
-            if ((Q) == 0) sa.issue(0, s_kt, PR_SDST(0), wave);        \
-            else if ((Q) == 1) sb.issue(0, s_kt, PR_SDST(1), wave);   \
-            else if ((Q) == 2) sb.issue(1, s_kt, PR_SDST(2), wave);   \
-            else sa.issue(1, s_kt, PR_SDST(3), wave);                 \
-        }                                                             \
-    } while (0)
-#define PR_STAGE1(Q, I)                                                        \
-    do {                                                                       \
-        if constexpr (SB) {                                                    \
-            if ((Q) == 0) sa.issue_cur_one(0, (I), PR_SDST(0), wave);          \
-            else if ((Q) == 1) sb.issue_cur_one(0, (I), PR_SDST(1), wave);     \
-            else if ((Q) == 2) sb.issue_cur_one(1, (I), PR_SDST(2), wave);     \
-            else sa.issue_cur_one(1, (I), PR_SDST(3), wave);                   \
-        } else {                                                               \
-            if ((Q) == 0) sa.issue_one(0, (I), s_kt, PR_SDST(0), wave);        \
-            else if ((Q) == 1) sb.issue_one(0, (I), s_kt, PR_SDST(1), wave);   \
-            else if ((Q) == 2) sb.issue_one(1, (I), s_kt, PR_SDST(2), wave);   \
-            else sa.issue_one(1, (I), s_kt, PR_SDST(3), wave);                 \
-        }                                                                      \
+#define PR_STAGE(Q)                                               \
+    do {                                                          \
+        if ((Q) == 0) sa.issue_cur(0, PR_SDST(0), wave);          \
+        else if ((Q) == 1) sb.issue_cur(0, PR_SDST(1), wave);     \
+        else if ((Q) == 2) sb.issue_cur(1, PR_SDST(2), wave);     \
+        else sa.issue_cur(1, PR_SDST(3), wave);                   \
     } while (0)
     // next K tile of the stream; entering the next item retargets the stagers (once per item)
-#define PR_ADVANCE()                                                                   \
-    do {                                                                               \
-        s_par ^= 1;                                                                    \
-        if constexpr (SB) {                                                            \
-            if (!s_dummy) {                                                            \
-                if (++s_kt == s_KT) {                                                  \
-                    sp += G;                                                           \
-                    if (sp < items) {                                                  \
-                        PItem nx_;                                                     \
-                        next_item_walk(g, sp, s_row, s_col, nx_);                      \
-                        sa.retarget(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN); \
-                        sb.retarget(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN); \
-                        sa.make_scalar();                                              \
-                        sb.make_scalar();                                              \
-                        s_KT = __builtin_amdgcn_readfirstlane(nx_.KT);                 \
-                        s_kt = 0;                                                      \
-                    } else {                                                           \
-                        s_dummy = 1;      /* the cursor stays on the last K tile */    \
-                        s_kt = s_KT - 1;                                               \
-                    }                                                                  \
-                } else {                                                               \
-                    sa.step();                                                         \
-                    sb.step();                                                         \
-                }                                                                      \
-            }                                                                          \
-        } else if (!s_dummy && ++s_kt == s_KT) {                                       \
-            sp += G;                                                                   \
-            if (sp < items) {                                                          \
-                PItem nx_;                                                             \
-                decode_item(g, sp, nx_);                                               \
-                sa.init(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN, 2);          \
-                sb.init(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN, 2);          \
-                s_KT = nx_.KT;                                                         \
-                s_kt = 0;                                                              \
-            } else {                                                                   \
-                s_dummy = 1;                                                           \
-                s_kt = s_KT - 1;                                                       \
-            }                                                                          \
-        }                                                                              \
+#define PR_ADVANCE()                                                               \
+    do {                                                                           \
+        s_par ^= 1;                                                                \
+        if (!s_dummy) {                                                            \
+            if (++s_kt == s_KT) {                                                  \
+                sp += G;                                                           \
+                if (sp < items) {                                                  \
+                    PItem nx_;                                                     \
+                    next_item_walk(g, sp, s_row, s_col, nx_);                      \
+                    sa.retarget(g.A, g.lda, nx_.m0, g.M, nx_.k0, wave, lane, WTN); \
+                    sb.retarget(g.B, g.ldb, nx_.n0, g.N, nx_.k0, wave, lane, WTN); \
+                    sa.make_scalar();                                              \
+                    sb.make_scalar();                                              \
+                    s_KT = __builtin_amdgcn_readfirstlane(nx_.KT);                 \
+                    s_kt = 0;                                                      \
+                } else {                                                           \
+                    s_dummy = 1;      /* the cursor stays on the last K tile */    \
+                    s_kt = s_KT - 1;                                               \
+                }                                                                  \
+            } else {                                                               \
+                sa.step();                                                         \
+                sb.step();                                                         \
+            }                                                                      \
+        }                                                                          \
     } while (0)
 
     bf16x8 af[2][4], bl[4], br[4];
@@ -740,64 +655,36 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
         af[0][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, 0, s_, lane);                  \
         af[1][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, 1, s_, lane);                  \
     }
-#define PR_READ_A_F(Q, F) \
-    _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) af[F][s_] = read_frag<AK, true>(PR_RSLOT(Q), wr, (F), s_, lane);
 #define PR_READ_B(DST, Q) \
     _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) DST[s_] = read_frag<BK, false>(PR_RSLOT(Q), wc, 0, s_, lane);
+    // MFMAs are register-only: neither the "memory" clobber of the barrier nor sched_barrier keeps instruction selection from moving
+    // them into another phase.  The empty volatile asm statements pin the two accumulators of the group on both sides (volatile asm
+    // statements, the barriers included, keep their program order).
 #define PR_PIN(X) asm volatile("" : "+v"(X))
 #define PR_MFMA(FI0, FJ, BFR)                                                                                          \
     do {                                                                                                               \
         PR_PIN(acc[FI0][FJ]);                                                                                          \
         PR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
-        if (SEG_PRIO) __builtin_amdgcn_s_setprio(1);                                                                   \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
         _Pragma("unroll") for (int s_ = 0; s_ < 4; ++s_) {                                                             \
             acc[FI0][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[0][s_], acc[FI0][FJ], 0, 0, 0);         \
             acc[FI0 + 1][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BFR[s_], af[1][s_], acc[FI0 + 1][FJ], 0, 0, 0); \
         }                                                                                                              \
         PR_PIN(acc[FI0][FJ]);                                                                                          \
         PR_PIN(acc[FI0 + 1][FJ]);                                                                                      \
-        if (SEG_PRIO) __builtin_amdgcn_s_setprio(0);                                                                   \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
-    // one K tile (phases as in gemm_ring_kernel): always one piece staged per phase, always vmcnt(8)
-#define PR_TILE()                                                             \
-    do {                                                                      \
-        PR_READ_B(bl, 1)                                                      \
-        PR_READ_A(0)                                                          \
-        PR_STAGE(2);                                                          \
-        GR_VMCNT(8);                                                          \
-        GR_BARRIER();                                                         \
-        PR_MFMA(0, 0, bl);                                                    \
-        GR_BARRIER();                                                         \
-        PR_READ_B(br, 2)                                                      \
-        PR_STAGE(3);                                                          \
-        GR_VMCNT(8);                                                          \
-        GR_BARRIER();                                                         \
-        PR_MFMA(0, 1, br);                                                    \
-        GR_BARRIER();                                                         \
-        PR_READ_A(3)                                                          \
-        PR_ADVANCE();                                                         \
-        PR_STAGE(0);                                                          \
-        GR_VMCNT(8);                                                          \
-        GR_BARRIER();                                                         \
-        PR_MFMA(2, 1, br);                                                    \
-        GR_BARRIER();                                                         \
-        PR_STAGE(1);                                                          \
-        GR_VMCNT(8);                                                          \
-        GR_BARRIER();                                                         \
-        PR_MFMA(2, 0, bl);                                                    \
-        GR_BARRIER();                                                         \
-        r_par ^= 1;                                                           \
-    } while (0)
-    // PH = 2 (the default since round 3; PH = 4 above stays behind XQ_GEMM_FOUR_PHASE): the same stream regrouped into two phases of
-    // 16 MFMAs per K tile — half the barriers, and the 16 + 8 fragment reads of a phase get 512 instead of 256 matrix-pipe cycles of
-    // the other wave row to land under.  Bit-identical results (same MFMA order per accumulator; tests/test_gemm_gpu.py race screen).
-    // Hazards for two pieces per phase (HW barrier numbering: wave row 1 runs one barrier interval behind row 0):
+    // One K tile = two phases of 16 MFMAs per wave, each [fragment reads, 4 LDS-DMA instructions, counted waits] barrier [16 MFMAs]
+    // barrier; the two wave rows run one barrier apart, so that on every SIMD one wave loads while the other multiplies.  Piece
+    // x = 4 t + q of K tile t: q = 0 A-top, 1 B-left, 2 B-right, 3 A-bottom; LDS slot x & 7.
+    // Hazards (HW barrier numbering: wave row 1 runs one barrier interval behind row 0):
     //   RAW  phase A reads pieces (t,1) (t,2) (t,0): in flight after phase B(t-1) staged (t+1,0) (t+1,1) are, oldest first,
     //        (t,0..3) (t+1,0) (t+1,1) = 12 instructions -> vmcnt(6) there retires (t,0) (t,1) (t,2);  phase B reads (t,3): in flight
     //        after phase A(t) staged (t+1,2) (t+1,3) are (t,3) (t+1,0..3) = 10 -> vmcnt(8) retires (t,3);  prologue: vmcnt(6)
     //   WAR  slot of (t+1,3) = slot of (t-1,3), last read at the head of phase B(t-1) by wave row 0 and one barrier later by row 1:
     //        the explicit lgkmcnt(0) in front of every phase's first barrier retires a wave's reads before it signals, so a piece
     //        is restaged at least two barriers after its last read has RETURNED (cdna_hip_programming.md, 8-phase template rule)
+    //   stores of an epilogue may still be outstanding in the next item's first phases; they only make the counted waits stricter
 #define GR_LGKM0()                                                            \
     do {                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                    \
@@ -805,90 +692,27 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     } while (0)
 #define PR_TILE2()                                                            \
     do {                                                                      \
-        PR_T(0);                                                              \
         PR_Q(q_s);                                                            \
         PR_READ_B(bl, 1)                                                      \
         PR_READ_B(br, 2)                                                      \
         PR_READ_A(0)                                                          \
-        PR_T(1);                                                              \
-        PR_T_KEEP();                                                          \
-        PR_T(2);                                                              \
         PR_STAGE(2);                                                          \
         PR_STAGE(3);                                                          \
-        PR_T(3);                                                              \
         GR_LGKM0();                                                           \
         PR_Q_ACC();                                                           \
-        PR_T(4);                                                              \
         GR_VMCNT(8);                                                          \
-        PR_T(5);                                                              \
         PR_Q(q_a);                                                            \
         GR_BARRIER();                                                         \
-        PR_T(6);                                                              \
         PR_Q(q_p);                                                            \
         PR_MFMA(0, 0, bl);                                                    \
-        PR_T(7);                                                              \
         PR_MFMA(0, 1, br);                                                    \
-        PR_T(8);                                                              \
         PR_Q(q_e);                                                            \
         GR_BARRIER();                                                         \
-        PR_T(0);                                                              \
         PR_Q(q_s);                                                            \
         PR_READ_A(3)                                                          \
-        PR_T(1);                                                              \
-        PR_T_KEEP();                                                          \
-        PR_T(2);                                                              \
         PR_ADVANCE();                                                         \
         PR_STAGE(0);                                                          \
         PR_STAGE(1);                                                          \
-        PR_T(3);                                                              \
-        GR_LGKM0();                                                           \
-        PR_Q_ACC();                                                           \
-        PR_T(4);                                                              \
-        GR_VMCNT(6);                                                          \
-        PR_T(5);                                                              \
-        PR_Q(q_a);                                                            \
-        GR_BARRIER();                                                         \
-        PR_T(6);                                                              \
-        PR_Q(q_p);                                                            \
-        PR_MFMA(2, 1, br);                                                    \
-        PR_T(7);                                                              \
-        PR_MFMA(2, 0, bl);                                                    \
-        PR_T(8);                                                              \
-        PR_Q(q_e);                                                            \
-        GR_BARRIER();                                                         \
-        r_par ^= 1;                                                           \
-    } while (0)
-
-    // XQ_GEMM_INTERLEAVE: the same K tile with the LDS-DMA instructions between the fragment reads (clock sums only, no per-phase records)
-#define PR_TILE2I()                                                           \
-    do {                                                                      \
-        PR_Q(q_s);                                                            \
-        PR_STAGE1(2, 0);                                                      \
-        PR_READ_B(bl, 1)                                                      \
-        PR_STAGE1(2, 1);                                                      \
-        PR_READ_B(br, 2)                                                      \
-        PR_STAGE1(3, 0);                                                      \
-        PR_READ_A_F(0, 0)                                                     \
-        PR_STAGE1(3, 1);                                                      \
-        PR_READ_A_F(0, 1)                                                     \
-        GR_LGKM0();                                                           \
-        PR_Q_ACC();                                                           \
-        GR_VMCNT(8);                                                          \
-        PR_Q(q_a);                                                            \
-        GR_BARRIER();                                                         \
-        PR_Q(q_p);                                                            \
-        PR_MFMA(0, 0, bl);                                                    \
-        PR_MFMA(0, 1, br);                                                    \
-        PR_Q(q_e);                                                            \
-        GR_BARRIER();                                                         \
-        PR_Q(q_s);                                                            \
-        PR_READ_A_F(3, 0)                                                     \
-        PR_ADVANCE();                                                         \
-        PR_STAGE1(0, 0);                                                      \
-        PR_READ_A_F(3, 1)                                                     \
-        PR_STAGE1(0, 1);                                                      \
-        PR_STAGE1(1, 0);                                                      \
-        PR_STAGE1(1, 1);                                                      \
         GR_LGKM0();                                                           \
         PR_Q_ACC();                                                           \
         GR_VMCNT(6);                                                          \
@@ -910,45 +734,19 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     PR_ADVANCE();
     PR_STAGE(0);
     PR_STAGE(1);
-    if (PH == 2) GR_VMCNT(6); else GR_VMCNT(8);
+    GR_VMCNT(6);
     GR_BARRIER();
 
     const int h = lane >> 5;
-    if constexpr (SB) {
-        // the first K tiles are on their way (prologue above); hold this workgroup back by its class
-        const int hold = __builtin_amdgcn_readfirstlane((int)((cit.m0 >> 8) & 3)) * g.skew;
-        for (int i = 0; i < hold; ++i) __builtin_amdgcn_s_sleep(16);
-    }
-    if (ROW1_PRIO && wr == 1) __builtin_amdgcn_s_setprio(1);
     for (;;) {
         const bool has_next = cp + G < items;
         if (wr == 1) GR_BARRIER();
-        if (PH == 2) {
-            if constexpr (IL) {
-                const int kt_n = __builtin_amdgcn_readfirstlane(cit.KT);
-                for (int kt = 0; kt < kt_n; ++kt) PR_TILE2I();
-            } else if constexpr (SB) {      // trip count in a scalar register: no VALU compare + VCC branch per K tile
-                const int kt_n = __builtin_amdgcn_readfirstlane(cit.KT);
-                for (int kt = 0; kt < kt_n; ++kt) PR_TILE2();
-            } else {
-                for (int kt = 0; kt < cit.KT; ++kt) PR_TILE2();
-            }
+        {      // trip count in a scalar register: no VALU compare + VCC branch per K tile
+            const int kt_n = __builtin_amdgcn_readfirstlane(cit.KT);
+            for (int kt = 0; kt < kt_n; ++kt) PR_TILE2();
         }
-        else { for (int kt = 0; kt < cit.KT; ++kt) PR_TILE(); }
         if (wr == 0) GR_BARRIER();
         if (!has_next) GR_VMCNT(0);      // the dummy pieces target `region`
-        if (TRACE) {
-            if (tr_on && tr_cur == 0 && lane == 0) g.trace[(long)wave * g.trace_cap + 1] = __builtin_amdgcn_s_memtime();
-            if (tr_on && tr_cur == g.trace_item && lane == 0) {
-                unsigned long long *out = g.trace + (long)wave * g.trace_cap;
-                const int n = tr_n < 28 ? tr_n : 28;      // phases
-                out[0] = (unsigned long long)n;
-                out[3] = (unsigned long long)cit.KT;
-                for (int i = 0; i < n * 9 && 4 + i < g.trace_cap; ++i)
-                    out[4 + i] = *reinterpret_cast<const unsigned long long *>(region + 2048 + i * 8);
-            }
-        }
-
         // ---- epilogue of this item (the next item's first pieces are landing meanwhile) ----
         if (cit.slab) {
             float *S = g.slabs + (size_t)cit.slab_idx * 65536;
@@ -1057,17 +855,11 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                 }
             }
         }
-        if (TRACE) {
-            if (tr_on && tr_cur == 0 && lane == 0) g.trace[(long)wave * g.trace_cap + 2] = __builtin_amdgcn_s_memtime();
-            ++tr_cur;
-            tr_n = 0;
-        }
         if (SUMS) { q_n = 0; ++q_items; }      // the first phase of the next item is not differenced against this item's last
         if (!has_next) break;
         PR_ZERO()
         cp += G;
-        if constexpr (SB) next_item_walk(g, cp, c_row, c_col, cit);
-        else decode_item(g, cp, cit);
+        next_item_walk(g, cp, c_row, c_col, cit);
     }
     if (SUMS) {
         if (g.trace != nullptr && (int)blockIdx.x == g.trace_block && lane == 0) {
@@ -1078,13 +870,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     }
 #undef PR_Q
 #undef PR_Q_ACC
-#undef PR_T
-#undef PR_T_KEEP
-#undef PR_TILE
 #undef PR_TILE2
-#undef PR_TILE2I
-#undef PR_STAGE1
-#undef PR_READ_A_F
 #undef GR_LGKM0
 #undef PR_MFMA
 #undef PR_PIN
@@ -1217,83 +1003,19 @@ PPlan plan_persistent(long tiles, int kt_full, bool weight_grad) {
     return p;
 }
 
-// ---- schedule selection ------------------------------------------------------------------------------------------------------
-// Two- and four-phase persistent kernels compute the same sums in the same order (bit-identical outputs).  Round-3 measurements on
-// the ViT-B shapes (profiles/r03_gemm_schedules_v3.txt): two phases are never slower — weight gradients +10..15 %, data gradients
-// 0..+4 %, forward 0..+2 % — so two phases are the default.  (Two earlier A/B runs had suggested shape-dependent winners; that was
-// the first-measured-row penalty of the bench harness, not the schedule.)  XQ_GEMM_TUNE=1 in the environment makes the first call of
-// a (kernel, M, N, K) outside a stream capture time both — one warm-up launch and two timed launches each, HIP events on the caller's
-// stream, outputs rewritten with the same values — and cache the winner for the life of the process: for shapes nobody measured.
-typedef std::tuple<int, int, int, int, long, long, long, long> TuneKey;    // AK, BK, ACT, conv mode, M, N, K, grid
-std::mutex g_tune_mu;
-std::map<TuneKey, int> g_tune_db;
-
-bool tuning_enabled() {
-    static const bool on = [] { const char *e = std::getenv("XQ_GEMM_TUNE"); return e && e[0] == '1'; }();
-    return on;
-}
-
+// the persistent kernel, or (XQ_GEMM_TRACE_SUMS with a bound trace buffer; plain NT / NN / TN only) its clock-summing twin
 template <int AK, int BK, int ACT>
-void launch_pring(const GemmArgs &g, int phases, long grid, int lds, hipStream_t s) {
-    if (g.trace || g.variant) {      // diagnostics / A-B (XQ_GEMM_TRACE, XQ_GEMM_NO_SEGMENT_PRIO, XQ_GEMM_ROW1_PRIO): two phases, plain NT / NN / TN only
-        if (ACT == ACT_NONE && AK != gm::KMAJOR_CONV) {
-            constexpr int A2 = AK == gm::KMAJOR_CONV ? (int)gm::KMAJOR : AK;
-            const int var = g.variant | ((g.trace && !(g.variant & 8)) ? 1 : 0);
-#define XQ_VAR_CASE(V)                                                                                                           \
-    case V:                                                                                                                      \
-        if (set_lds<gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>>(lds)) return;                                                     \
-        hipLaunchKernelGGL((gemm_pring_kernel<A2, BK, ACT_NONE, 2, V>), dim3((unsigned)grid), dim3(GT), lds, s, g);              \
-        return;
-            switch (var) {
-                XQ_VAR_CASE(1) XQ_VAR_CASE(8)
-#ifdef XQ_EXPERIMENTAL      // make EXTRA=-DXQ_EXPERIMENTAL: the priority A/B kernels (measured in round 3: no effect) and the scalar-base
-                            // kernels, which have not run on hardware yet, stay out of the default library
-                XQ_VAR_CASE(2) XQ_VAR_CASE(6) XQ_VAR_CASE(16) XQ_VAR_CASE(17) XQ_VAR_CASE(24) XQ_VAR_CASE(32) XQ_VAR_CASE(40) XQ_VAR_CASE(48) XQ_VAR_CASE(56)
-#endif
-                default: break;
-            }
-#undef XQ_VAR_CASE
+int launch_pring(const GemmArgs &g, long grid, int lds, hipStream_t s) {
+    if constexpr (ACT == ACT_NONE && AK != gm::KMAJOR_CONV) {
+        if (g.trace) {
+            if (set_lds<gemm_pring_kernel<AK, BK, ACT_NONE, true>>(lds)) return -1;
+            hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT_NONE, true>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+            return 0;
         }
     }
-    if (phases == 4) hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 4>), dim3((unsigned)grid), dim3(GT), lds, s, g);
-    else hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT, 2>), dim3((unsigned)grid), dim3(GT), lds, s, g);
-}
-
-template <int AK, int BK, int ACT>
-int pick_phases(const GemmArgs &g, long grid, int lds, hipStream_t s) {
-    if (g.phases == 2 || g.phases == 4) return g.phases;
-    if (!tuning_enabled()) return 2;
-    const TuneKey key(AK, BK, ACT, AK == gm::KMAJOR_CONV ? (g.cv_stride * 4 + g.cv_up * 2 + g.cv_transposed) * 4096 + g.cv_Cin : 0, g.M, g.N,
-                      (long)g.kt_full * gm::BKT, grid);
-    {
-        std::lock_guard<std::mutex> lk(g_tune_mu);
-        auto it = g_tune_db.find(key);
-        if (it != g_tune_db.end()) return it->second;
-    }
-    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
-        (void)hipGetLastError();
-        return 2;
-    }
-    hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); return 2; }
-    float best_ms = 0.f;
-    int best = 2;
-    for (int ph : {2, 4}) {
-        launch_pring<AK, BK, ACT>(g, ph, grid, lds, s);
-        (void)hipEventRecord(e0, s);
-        launch_pring<AK, BK, ACT>(g, ph, grid, lds, s);
-        launch_pring<AK, BK, ACT>(g, ph, grid, lds, s);
-        (void)hipEventRecord(e1, s);
-        float ms = 0.f;
-        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) { (void)hipGetLastError(); best = 2; break; }
-        if (ph == 2 || ms < best_ms) { best_ms = ms; best = ph; }
-    }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    std::lock_guard<std::mutex> lk(g_tune_mu);
-    g_tune_db[key] = best;
-    return best;
+    if (set_lds<gemm_pring_kernel<AK, BK, ACT>>(lds)) return -1;
+    hipLaunchKernelGGL((gemm_pring_kernel<AK, BK, ACT>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+    return 0;
 }
 
 template <int AK, int BK, int EPI, int ACT = ACT_NONE>
@@ -1323,9 +1045,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         g.step_r = (int)(grid / g.tiles_n);
         g.step_c = (int)(grid % g.tiles_n);
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
-        if (set_lds<gemm_pring_kernel<AK, BK, ACT, 2>>(lds) || set_lds<gemm_pring_kernel<AK, BK, ACT, 4>>(lds))
-            return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-        launch_pring<AK, BK, ACT>(g, pick_phases<AK, BK, ACT>(g, grid, lds, s), grid, lds, s);
+        if (launch_pring<AK, BK, ACT>(g, grid, lds, s)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
         if (EPI == EPI_BF16 && pl.tail_tiles)
             hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
                                pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
@@ -1351,23 +1071,11 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
     return xq_check_launch(fn);
 }
 
-// XQ_GEMM_TRACE target (xq_gemm_trace_bind)
+// XQ_GEMM_TRACE_SUMS target (xq_gemm_trace_bind)
 unsigned long long *g_trace_buf = nullptr;
 int g_trace_cap = 0, g_trace_block = 0;
-int bind_trace(GemmArgs &g, int impl, const char *fn) {
-#ifndef XQ_EXPERIMENTAL
-    if (impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_INTERLEAVE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO))
-        return xq_set_error(XQ_EINVAL, "%s: impl bits 0x%x need a library built with -DXQ_EXPERIMENTAL (make -C imagefolder_amd/csrc EXTRA=-DXQ_EXPERIMENTAL)", fn,
-                            impl & (XQ_GEMM_SCALAR_BASE | XQ_GEMM_INTERLEAVE | XQ_GEMM_NO_SEGMENT_PRIO | XQ_GEMM_ROW1_PRIO));
-#endif
-    g.variant = ((impl & XQ_GEMM_TRACE_SUMS) ? 8 : 0) | ((impl & XQ_GEMM_SCALAR_BASE) ? 16 : 0) | ((impl & XQ_GEMM_INTERLEAVE) ? 32 : 0);
-    if (impl & XQ_GEMM_SCALAR_BASE) {
-        static const int skew = [] { const char *e = std::getenv("XQ_GEMM_SKEW"); const int v = e ? std::atoi(e) : 0; return v < 0 ? 0 : (v > 64 ? 64 : v); }();
-        g.skew = skew;
-    }
-    if (!g.variant) g.variant = (impl & XQ_GEMM_ROW1_PRIO) ? 6 : (impl & XQ_GEMM_NO_SEGMENT_PRIO) ? 2 : 0;
-    if ((impl & (XQ_GEMM_TRACE | XQ_GEMM_TRACE_SUMS)) && g_trace_buf && g_trace_cap >= 16) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block & 0xffff; g.trace_item = g_trace_block >> 16; }
-    return XQ_OK;
+void bind_trace(GemmArgs &g, int impl) {
+    if ((impl & XQ_GEMM_TRACE_SUMS) && g_trace_buf && g_trace_cap >= 16) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block; }
 }
 
 int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
@@ -1415,8 +1123,7 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     GemmArgs g{};
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
-    if (int rc = bind_trace(g, impl, fn)) return rc;
+    bind_trace(g, impl);
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
@@ -1434,8 +1141,7 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
-    if (int rc = bind_trace(g, impl, fn)) return rc;
+    bind_trace(g, impl);
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
@@ -1454,12 +1160,11 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     hipStream_t s = (hipStream_t)stream;
     const int BN = pick_bn(Q, impl);
     const int tile_major_debug = (impl & XQ_GEMM_TILE_MAJOR) ? 1 : 0;
-    const int phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
     const int impl_bits = impl;
     impl &= 0xff;
     const long kt_all = R / 64;
     GemmArgs g{};
-    if (int rc = bind_trace(g, impl_bits, fn)) return rc;
+    bind_trace(g, impl_bits);
     g.A = (const char *)g_y; g.B = (const char *)x; g.C = (char *)ws;
     g.M = P; g.N = Q; g.lda = P; g.ldb = Q; g.ldc = Q;
     g.tiles_m = (int)((P + 255) / 256); g.tiles_n = (int)((Q + BN - 1) / BN);
@@ -1472,7 +1177,6 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
         if (impl == XQ_GEMM_AUTO) impl = BN == 256 ? XQ_GEMM_PERSISTENT : XQ_GEMM_SIMPLE;
         compact = impl == XQ_GEMM_PERSISTENT;
         g.tile_major_debug = tile_major_debug;
-        g.phases = phases;
         if (!compact && (ws_bytes < (size_t)splits * P * Q * 4 || !ws)) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
         const int rc = launch_gemm<gm::KSTRIDED, gm::KSTRIDED, EPI_F32_SLAB>(g, BN, impl, ws, ws_bytes, s, fn, 2.0 * P * Q * (double)(kt_all * 64));
         if (rc) return rc;
@@ -1539,10 +1243,8 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     if ((long)B * Hi * Wi >= 0x7fffffffL || Ho > 32767 || Wo > 32767) return xq_set_error(XQ_EINVAL, "%s: image too large for 32-bit pixel indices", fn);
     const long M = (long)B * Ho * Wo, K = 9L * Cin;
     const int BN = pick_bn(Cout, impl);
-    const int phases = (impl & XQ_GEMM_FOUR_PHASE) ? 4 : (impl & XQ_GEMM_TWO_PHASE) ? 2 : 0;
     impl &= 0xff;
     GemmArgs g{};
-    g.phases = phases;
     g.nt_store = 1;
     g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;
     g.M = M; g.N = Cout; g.lda = K; g.ldb = K; g.ldc = Cout;

@@ -115,7 +115,7 @@ struct StagerAddr {
     const char *base;       // tile base at K tile 0 (wave-uniform)
     long adv;               // bytes per K tile
     bool interior;          // the tile `off` was computed for has all 256 rows / columns inside the matrix: no lane was clamped
-    // XQ_GEMM_SCALAR_BASE: next item.  Between two interior tiles the per-lane offsets do not change — only the tile base moves
+    // persistent schedule: next item.  Between two interior tiles the per-lane offsets do not change — only the tile base moves
     GM_HD void retarget(const char *mat, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn) {
         if (interior && rc_count - rc0 >= 256) {
             if (KIND == KMAJOR) base = mat + (rc0 * ld + k0) * 2;
@@ -156,7 +156,7 @@ struct StagerAddr {
                 }
             }
     }
-    // XQ_GEMM_SCALAR_BASE: the tile pointer of the K tile being staged, wave-uniform by construction (kept in scalar registers), moved by a
+    // persistent schedule: the tile pointer of the K tile being staged, wave-uniform by construction (kept in scalar registers), moved by a
     // scalar add per K tile
     const char *cur;
     GM_HD void make_scalar() {
@@ -201,7 +201,7 @@ GM_HD void decode_item(const G &g, long p, Item &it) {
     it.KT = (int)(base + (split < rem ? 1 : 0));
 }
 
-// XQ_GEMM_SCALAR_BASE: the whole-tile items of one workgroup are `grid` tiles apart; (row, col) of the next one by scalar adds
+// persistent schedule: the whole-tile items of one workgroup are `grid` tiles apart; (row, col) of the next one by scalar adds
 // (G additionally has step_r = grid / tiles_n, step_c = grid % tiles_n).  decode_item's 64-bit divisions are ~700 scalar instructions =
 // the 1.6 - 2.3 k-cycle stall of the load phase once per item (profiles/r03_gemm_where_the_cycles_go.md).
 // Precondition: the item before (p - grid) was a whole-tile item whose tile coordinates are (row, col).

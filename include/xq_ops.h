@@ -393,35 +393,18 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_DEBUG_NO_STORE 0x200 /* OR-ed into impl (NT, persistent schedule): skip the output stores — timing experiments, result unusable */
 #define XQ_GEMM_TILE_MAJOR 0x400 /* OR-ed into impl (TN, persistent schedule): execute the K-split items tile-major instead of split-major (A/B timing) */
 #define XQ_GEMM_PLAIN_STORE 0x800 /* OR-ed into impl (persistent schedule): plain instead of non-temporal output stores (A/B timing) */
-#define XQ_GEMM_TWO_PHASE 0x1000  /* OR-ed into impl (persistent schedule): force 2 phases of 16 MFMAs per K tile                                  */
-#define XQ_GEMM_FOUR_PHASE 0x4000 /* OR-ed into impl (persistent schedule): force 4 phases of 8 MFMAs per K tile (the round-2 schedule).  With neither
-                                     bit: two phases (measured never slower, profiles/r03_gemm_schedules_v3.txt); XQ_GEMM_TUNE=1 in the environment
-                                     times both on the first call of a shape and keeps the faster one.  Bit-identical results either way */
-#define XQ_GEMM_TRACE 0x8000      /* OR-ed into impl (NT / NN / TN, persistent schedule): run the two-phase kernel with shader-clock stamps into the
-                                     buffer bound by xq_gemm_trace_bind (diagnostics; results unchanged) */
-#define XQ_GEMM_NO_SEGMENT_PRIO 0x10000 /* EXPERIMENTAL build only (XQ_EINVAL otherwise): no s_setprio around the MFMA segments — measured in round 3: no effect */
-#define XQ_GEMM_ROW1_PRIO 0x20000       /* EXPERIMENTAL build only: ... and wave row 1 (waves 4-7) at priority 1 for the whole kernel instead — no effect either */
-#define XQ_GEMM_TRACE_SUMS 0x40000      /* OR-ed into impl with a trace buffer bound: the low-perturbation trace — per-phase clock differences summed in
-                                           scalar registers over the whole kernel; the traced workgroup's 8 waves write [8] = phases summed, [9] = sum of
-                                           (phase start -> arrival at the first barrier), [10] = (-> passed), [11] = (-> arrival at the second barrier =
-                                           the MFMA segment), [12] = (-> next phase start), [13] = items of the workgroup */
-#define XQ_GEMM_SCALAR_BASE 0x80000     /* OR-ed into impl (NT / NN / TN, persistent two-phase).  EXPERIMENTAL, not in the default build (XQ_EINVAL unless
-                                           the library was made with EXTRA=-DXQ_EXPERIMENTAL): the staging cursor's tile pointers in scalar registers,
-                                           advanced by a scalar add per K tile; whole-tile items walked by scalar adds instead of 64-bit divisions */
-#define XQ_GEMM_INTERLEAVE 0x100000     /* EXPERIMENTAL build only (may be combined with XQ_GEMM_SCALAR_BASE / _TRACE_SUMS): the four LDS-DMA instructions of a phase
-                                           alternate with its fragment reads instead of following them (the DMA issue is paced by the CU's vector-memory
-                                           address path, the reads go down the LDS path: in sequence they add up to the load phase) */
+#define XQ_GEMM_TRACE_SUMS 0x40000 /* OR-ed into impl (plain NT / NN / TN, persistent schedule) with a trace buffer bound (xq_gemm_trace_bind): run the
+                                      clock-summing twin of the persistent kernel (diagnostics; results unchanged) — per-phase shader-clock differences
+                                      summed in scalar registers over the whole kernel; the traced workgroup's 8 waves write [8] = phases summed,
+                                      [9] = sum of (phase start -> arrival at the first barrier), [10] = (-> passed), [11] = (-> arrival at the second
+                                      barrier = the MFMA segment), [12] = (-> next phase start), [13] = items of the workgroup */
 #define XQ_GEMM_OP_NT 0
 #define XQ_GEMM_OP_NN 1
 #define XQ_GEMM_OP_TN 2
 #define XQ_PROF_GEMM 4       /* gemm_*_kernel: 2*M*N*K flops per launch (xq_prof_collect_kind)                               */
-/* diagnostics (no reference counterpart): where the stamps of XQ_GEMM_TRACE launches go.  buf = device memory, uint64 [8 waves][cap_per_wave];
- * the 8 waves of workgroup (`workgroup` & 0xffff) record item (`workgroup` >> 16) of their list: [0] = phases recorded (<= 28, two per K
- * tile), [1] = clock at the end of the K loop of the workgroup's FIRST item, [2] = clock at the end of that item's epilogue, [3] = K tiles
- * of the recorded item, [4 + 9 p + i] = clock at point i of record p: i = 0 phase p start, 1 fragment reads issued (record written here);
- * i = 2..8 belong to phase p - 1: record written, LDS-DMA issued, lgkmcnt(0) over, vmcnt wait over (= arrival at its first barrier),
- * first barrier passed, eight / all sixteen MFMAs issued (= arrival at the second barrier).  buf = NULL unbinds.
- * tools/gemm_timeline.py prints the timeline. */
+/* diagnostics (no reference counterpart): where the clock sums of XQ_GEMM_TRACE_SUMS launches go.  buf = device memory, uint64
+ * [8 waves][cap_per_wave >= 16]; the 8 waves of workgroup `workgroup` write entries [8..13] (see XQ_GEMM_TRACE_SUMS).  buf = NULL unbinds.
+ * tools/gemm_timeline.py prints the table. */
 int xq_gemm_trace_bind(void *buf, int cap_per_wave, int workgroup);
 /* bytes of workspace for op (XQ_GEMM_OP_*) at output rows M, columns N, reduction depth K (TN: M = P, N = Q, K = R);
  * NT / NN run without one (workspace NULL: no K-split of the tail tiles). */

@@ -167,7 +167,7 @@ static void run(int BN, unsigned seed) {
 // Replays every workgroup's item list (positions cp, cp + G, ... with cp = xcd_order(block, G)) for the plans csrc/xq_gemm.hip makes
 // (plan_persistent is restated here: whole tiles for the full rounds of CUs, the remainder cut along K; weight gradient: every tile cut),
 // and checks (1) every (tile, K tile) of the product is covered exactly once, slabs are distinct; (2) the scalar tile walk of the
-// XQ_GEMM_SCALAR_BASE kernels (next_item_walk) yields field for field what decode_item yields, for the compute AND the staging cursor.
+// persistent kernel (next_item_walk) yields field for field what decode_item yields, for the compute AND the staging cursor.
 struct Plan {
     long main_items;
     int tail_tiles, tail_splits, split_major, tiles_n, kt_full, step_r, step_c;
@@ -220,7 +220,7 @@ static void check_plan(long tiles_m, int tiles_n, int kt_full, long cus, bool we
 }
 
 // ---- staging address streams ------------------------------------------------------------------------------------------------------------
-// The XQ_GEMM_SCALAR_BASE kernels (scalar tile cursor moved by adds, tile walk, per-lane offsets kept between interior tiles) must stage
+// The persistent kernel (scalar tile cursor moved by adds, tile walk, per-lane offsets kept between interior tiles) must stage
 // exactly the bytes the default kernel stages (base + kt * adv + off, decode_item + init per item — the path validated on the GPU): for
 // every workgroup of a plan, for a sample of lanes, the two address streams are compared K tile by K tile, both operands, all four
 // LDS-DMA instructions of a tile.  The control flow restates PR_ADVANCE of csrc/xq_gemm.hip; the arithmetic is gm::StagerAddr itself.
@@ -269,7 +269,7 @@ static void check_streams(long M, long N, long Kred, long cus, bool weight_grad)
                                 ref.push_back((unsigned long long)(sb.base + kt * sb.adv + sb.off[h][i]));
                             }
                 }
-                // scalar-base kernel: cursor + walk + retarget
+                // persistent kernel: cursor + walk + retarget
                 std::vector<unsigned long long> got;
                 {
                     Item it;

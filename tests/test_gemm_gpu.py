@@ -10,9 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SIMPLE, RING, PERSISTENT = 1, 2, 3
-# include/xq_ops.h: XQ_GEMM_TWO_PHASE / XQ_GEMM_FOUR_PHASE force a schedule (PERSISTENT alone = the default, two phases)
-TWO_PHASE, FOUR_PHASE = PERSISTENT | 0x1000, PERSISTENT | 0x4000
+SIMPLE, RING, PERSISTENT = 1, 2, 3      # include/xq_ops.h XQ_GEMM_*
 
 
 def _ops():
@@ -40,7 +38,7 @@ NT_SHAPES = [(256, 256, 128), (300, 256, 128), (1, 256, 64), (513, 768, 768), (2
              (22300, 768, 768), (22272, 768, 256), (51400, 768, 128)]
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT, TWO_PHASE, FOUR_PHASE])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_gemm_nt(M, N, K, impl):
     od = _ops()
@@ -60,7 +58,7 @@ def test_gemm_nt(M, N, K, impl):
     _check_bf16(y, ref + bias, absprod + bias.abs())
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT, TWO_PHASE, FOUR_PHASE])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
 @pytest.mark.parametrize("M,N,K", NT_SHAPES)
 def test_gemm_nn(M, N, K, impl):
     """g_x[M][N] = g[M][K] @ W[K][N] (W = forward weight [out = K][in = N])"""
@@ -81,7 +79,7 @@ TN_SHAPES = [(256, 256, 256), (2052, 2304, 768), (2052, 768, 768), (2056, 768, 3
              (788, 384, 1536), (788, 1152, 384), (4104, 768, 768), (640, 200, 192), (0, 64, 64)]
 
 
-@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT, TWO_PHASE, FOUR_PHASE])
+@pytest.mark.parametrize("impl", [SIMPLE, RING, PERSISTENT])
 @pytest.mark.parametrize("R,P,Q", TN_SHAPES)
 def test_gemm_tn(R, P, Q, impl):
     od = _ops()
@@ -137,12 +135,12 @@ def test_gemm_ring_equals_simple_and_is_repeatable(op):
 
 
 @pytest.mark.parametrize("op", ["nt", "nn", "tn"])
-@pytest.mark.parametrize("M,N,K", [(22300, 768, 768), (65664, 2304, 768), (65664, 768, 3072)])
-def test_two_phase_schedule_is_bit_identical_to_the_four_phase_one(op, M, N, K):
-    """Race screen of the two-phase (16 MFMAs per phase) persistent schedule: the same work items, the same MFMA order
-    per accumulator as the round-2 four-phase schedule -> every output BIT-identical, over 24 back-to-back launches on a busy chip
-    and on the bench shapes (an LDS piece read before its DMA landed, or restaged before its last read returned, shows up as a
-    wrong tile that comes and goes)."""
+@pytest.mark.parametrize("M,N,K", [(22300, 768, 768), (65664, 2304, 768), (65664, 768, 3072), (65664, 3072, 768), (300, 256, 128), (51400, 768, 128)])
+def test_persistent_schedule_race_screen(op, M, N, K):
+    """Race screen of the persistent schedule (two phases of 16 MFMAs per K tile, scalar staging cursor) on a busy chip and on the bench
+    shapes: 24 back-to-back launches are BIT-identical (an LDS piece read before its DMA landed, or restaged before its last read returned,
+    shows up as a wrong tile that comes and goes), and they equal the one-workgroup-per-tile ring schedule bit for bit wherever the two cut
+    the reduction the same way (NT / NN without K-split tail tiles: same MFMA order per accumulator), else up to the fp32 summation order."""
     od = _ops()
     if op == "tn":
         a, b = _rand((M, N), 7), _rand((M, K), 8)
@@ -155,25 +153,33 @@ def test_two_phase_schedule_is_bit_identical_to_the_four_phase_one(op, M, N, K):
         bias = torch.randn(N, device="cuda")
         run = lambda: od.gemm_nt(a, b, bias)
     try:
-        od.GEMM_SCHEDULE = FOUR_PHASE
+        od.GEMM_SCHEDULE = RING
         base = run()
-        od.GEMM_SCHEDULE = TWO_PHASE
+        od.GEMM_SCHEDULE = PERSISTENT
         outs = [run() for _ in range(24)]
-        od.GEMM_SCHEDULE = PERSISTENT          # the library's default
+        od.GEMM_SCHEDULE = 0                  # the library's default
         outs += [run() for _ in range(3)]
     finally:
         od.GEMM_SCHEDULE = 0
     torch.cuda.synchronize()
     for i, o in enumerate(outs):
-        assert torch.equal(o, base), f"launch {i} differs from the four-phase result in {(o != base).sum().item()} entries"
+        assert torch.equal(o, outs[0]), f"launch {i} differs from launch 0 in {(o != outs[0]).sum().item()} entries"
+    tiles = -(-M // 256) * -(-N // 256) if op != "tn" else 0
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    rem = tiles % cus
+    whole_tiles_only = op != "tn" and not (tiles > cus and 0 < rem <= cus // 4 and K // 64 >= 4)
+    if whole_tiles_only:
+        assert torch.equal(outs[0], base), f"{(outs[0] != base).sum().item()} entries differ from the ring schedule"
+    else:
+        scale = base.float().abs().max().item()
+        assert (outs[0].float() - base.float()).abs().max().item() <= 2.0 ** -7 * scale
 
 
 @pytest.mark.parametrize("op", ["nt", "nn", "tn"])
-def test_clock_traces_do_not_change_the_result_and_tell_a_consistent_story(op):
-    """XQ_GEMM_TRACE / XQ_GEMM_TRACE_SUMS (include/xq_ops.h; tools/gemm_timeline.py): the instrumented builds of the persistent two-phase
-    kernel write the same bytes as the plain one; the per-phase records are monotone in time; the summed phase segments say 16 MFMAs
-    take >= 512 cycles and a K tile lasts at least the 2048 cycles its 2 x 32 MFMAs per SIMD need."""
-    import numpy as np
+def test_clock_sums_do_not_change_the_result_and_tell_a_consistent_story(op):
+    """XQ_GEMM_TRACE_SUMS (include/xq_ops.h; tools/gemm_timeline.py): the clock-summing twin of the persistent kernel writes the same bytes
+    as the plain one; the summed phase segments say 16 MFMAs take >= 512 cycles and a K tile lasts at least the 2048 cycles its 2 x 32
+    MFMAs per SIMD need."""
     from imagefolder_amd import _lib
     od = _ops()
     M, N, K = 65664, 2304, 768
@@ -187,32 +193,21 @@ def test_clock_traces_do_not_change_the_result_and_tell_a_consistent_story(op):
         a, b = _rand((M, K), 7), _rand((N, K), 8, 0.05)
         bias = torch.randn(N, device="cuda")
         run = lambda: od.gemm_nt(a, b, bias)
-    cap = 512
+    cap = 16
     buf = torch.zeros(8, cap, dtype=torch.int64, device="cuda")
     try:
-        od.GEMM_SCHEDULE = TWO_PHASE
+        od.GEMM_SCHEDULE = PERSISTENT
         base = run()
         assert _lib.lib().xq_gemm_trace_bind(buf.data_ptr(), cap, 37) == 0
-        od.GEMM_SCHEDULE = TWO_PHASE | 0x8000
-        traced = run()
-        torch.cuda.synchronize()
-        rec = buf.cpu().numpy().copy()
-        buf.zero_()
-        od.GEMM_SCHEDULE = TWO_PHASE | 0x40000
+        od.GEMM_SCHEDULE = PERSISTENT | 0x40000
         summed = run()
         torch.cuda.synchronize()
         sums = buf.cpu().numpy().copy()
     finally:
         od.GEMM_SCHEDULE = 0
         _lib.lib().xq_gemm_trace_bind(None, 0, 0)
-    assert torch.equal(traced, base) and torch.equal(summed, base)
+    assert torch.equal(summed, base)
     for w in range(8):
-        n = int(rec[w, 0])
-        assert 10 <= n <= 28 and rec[w, 3] >= 2
-        r = rec[w, 4:4 + 9 * n].reshape(n, 9)
-        assert (np.diff(r[:, 0]) > 0).all()                     # phase starts move forward
-        assert (r[:, 1] > r[:, 0]).all()                        # reads are issued after the phase started
-        assert (np.diff(r[1:, 2:], axis=1) > 0).all()           # points 2..8 of the phase before, in order
         phases, load, bar1, mfma, bar2 = (int(sums[w, 8 + i]) for i in range(5))
         assert phases >= 20 and sums[w, 13] >= 1
         assert mfma / phases >= 512 and (load + bar1 + mfma + bar2) / phases >= 1024

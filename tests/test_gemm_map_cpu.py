@@ -2,8 +2,8 @@
 calls) replayed by tests/gemm_map_emulator.cpp: one K tile through LDS-DMA image -> fragment reads -> MFMA lane layout -> epilogue
 staging for every operand-layout / tile-width combination against a plain matrix product, LDS bank conflicts of every fragment read,
 bijectivity of the XCD tile order, and every workgroup's item list of the persistent schedule (each (tile, K tile) exactly once; the
-scalar tile walk of the XQ_GEMM_SCALAR_BASE kernels == decode_item), and the staging address streams of the scalar-base kernels against the
-default kernel's (gm::StagerAddr is the device code's own arithmetic)."""
+scalar tile walk of the persistent kernel == decode_item), and the staging address streams of its scalar cursor (retarget / step) against
+the per-K-tile form base + kt * adv of the ring kernel (gm::StagerAddr is the device code's own arithmetic)."""
 import os
 import shutil
 import subprocess
@@ -23,4 +23,4 @@ def test_gemm_maps_and_item_lists_replay_on_the_cpu(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("ALL OK"), out.stdout[-2000:]
     assert out.stdout.count(": ok;") == 6 and "item lists:" in out.stdout
     assert "bank-conflict cycles: b128 0, tr 0" in out.stdout
-    assert out.stdout.count("addresses compared, ok") == 10      # staging address streams: scalar-base kernel == default kernel
+    assert out.stdout.count("addresses compared, ok") == 10      # staging address streams: scalar cursor == base + kt * adv

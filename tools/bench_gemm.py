@@ -58,7 +58,7 @@ def main():
                     ("gx   library mm", lambda: torch.mm(g, w)),
                     ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
                 ]
-                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent (default: two phases)", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)", 0x1003: "persistent TWO-PHASE", 0x4003: "persistent FOUR-PHASE (round-2 schedule)"}.get(int(x, 0), x)) for x in a.scheds]:
+                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)"}.get(int(x, 0), x)) for x in a.scheds]:
                     def mk(f, sched=sched):
                         def run():
                             od.GEMM_SCHEDULE = sched

@@ -2,7 +2,7 @@
 and the two MFMA segments of one K tile.  The in-kernel clock measurements (profiles/r03_gemm_where_the_cycles_go.md) say the load phase
 is instruction-issue time, so these counts are the off-GPU proxy for a schedule change (they need no GPU: hipcc cross-compiles).
 
-    python tools/isa_loop_stats.py [--obj imagefolder_amd/csrc/_build/xq_gemm.o] [--match 'gemm_pring_kernelILi0ELi0ELi0ELi2ELi']
+    python tools/isa_loop_stats.py [--obj imagefolder_amd/csrc/_build/xq_gemm.o] [--match 'gemm_pring_kernelILi0ELi0ELi0ELb0E']
 
 A K loop is recognised as four consecutive s_barrier with 16 v_mfma between the 1st / 2nd and the 3rd / 4th and none between the 2nd / 3rd,
 closed by a backward branch behind the 4th; its first load phase is what lies between the branch target and the 1st barrier.
@@ -89,11 +89,11 @@ def main():
     a = ap.parse_args()
     ks = kernels(disassemble(a.obj))
     cols = ["valu", "salu", "ds_read", "lds_dma", "waitcnt", "nop", "branch", "smem", "vmem", "ds_write", "other"]
-    print(f"{'kernel <AK, BK, ACT, PH, VAR>':34s}{'segment':>16s}" + "".join(f"{c:>9s}" for c in cols) + f"{'total':>8s}")
+    print(f"{'kernel <AK, BK, ACT, SUMS>':34s}{'segment':>16s}" + "".join(f"{c:>9s}" for c in cols) + f"{'total':>8s}")
     for name, ins in ks.items():
         if a.match not in name:
             continue
-        m = re.search(r"gemm_pring_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E", name)
+        m = re.search(r"gemm_pring_kernelILi(\d+)ELi(\d+)ELi(\d+)ELb(\d+)E", name)
         tag = "<" + ", ".join(m.groups()) + ">" if m else name[:30]
         lp = find_loop(ins)
         if lp is None:
