@@ -762,6 +762,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             }
         } else {
             const long ncol0 = cit.n0 + 64 * wc;
+            // bias and ReLU exist for the K-major B operand only (Linear forward, convolutions): the data gradients have neither, and
+            // their epilogues keep the 32 registers
+            constexpr bool HAS_BIAS = BK == gm::KMAJOR;
             float4 bv[2][4];
 #pragma unroll
             for (int fj = 0; fj < 2; ++fj)
@@ -769,7 +772,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                 for (int q = 0; q < 4; ++q) {
                     long n = ncol0 + 32 * fj + 8 * q + 4 * h;
                     if (n > g.N - 4) n = g.N - 4;
-                    bv[fj][q] = g.bias ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    bv[fj][q] = (HAS_BIAS && g.bias) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -793,9 +796,11 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         uint2 pk;
-                        float e0 = acc[fi][fj][4 * q + 0] + bv[fj][q].x, e1 = acc[fi][fj][4 * q + 1] + bv[fj][q].y;
-                        float e2 = acc[fi][fj][4 * q + 2] + bv[fj][q].z, e3 = acc[fi][fj][4 * q + 3] + bv[fj][q].w;
-                        if (g.relu) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                        float e0 = acc[fi][fj][4 * q + 0], e1 = acc[fi][fj][4 * q + 1], e2 = acc[fi][fj][4 * q + 2], e3 = acc[fi][fj][4 * q + 3];
+                        if (HAS_BIAS) {
+                            e0 += bv[fj][q].x; e1 += bv[fj][q].y; e2 += bv[fj][q].z; e3 += bv[fj][q].w;
+                            if (g.relu) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                        }
                         pk.x = pack_bf16(e0, e1);
                         pk.y = pack_bf16(e2, e3);
                         *reinterpret_cast<uint2 *>(region + gm::epi_write_off(0, fj, q, lane, WTN)) = pk;
@@ -890,7 +895,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
                                                           long M, long N, long ldc, const float *__restrict__ bias,
                                                           __hip_bfloat16 *__restrict__ out16, float *__restrict__ out32,
                                                           const __hip_bfloat16 *__restrict__ G, const __hip_bfloat16 *__restrict__ X,
-                                                          long r_begin, long r_end) {
+                                                          long r_begin, long r_end, __hip_bfloat16 *__restrict__ out16_act, int gelu_tanh) {
     const long t = blockIdx.x;
     const long tile = first_tile + t;
     const long m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
@@ -923,6 +928,68 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
         uint4 pk;
         pk.x = pack_bf16(v[0], v[1]); pk.y = pack_bf16(v[2], v[3]); pk.z = pack_bf16(v[4], v[5]); pk.w = pack_bf16(v[6], v[7]);
         *reinterpret_cast<uint4 *>(out16 + gr * ldc + gc) = pk;
+        if (out16_act) {      // ACT_GELU_FWD tail tiles: the activation of the bf16-ROUNDED pre-activation, as the whole-tile epilogue does
+            const unsigned u[4] = {pk.x, pk.y, pk.z, pk.w};
+            unsigned a[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const act_f2 x2 = {bf16_lo(u[e]), bf16_hi(u[e])};
+                const act_f2 y2 = gelu_tanh ? gelu_val2<true>(x2) : gelu_val2<false>(x2);
+                a[e] = pack_bf16(y2.x, y2.y);
+            }
+            *reinterpret_cast<uint4 *>(out16_act + gr * ldc + gc) = make_uint4(a[0], a[1], a[2], a[3]);
+        }
+    }
+}
+
+// ACT_GELU_BWD tail tiles: g_h = (sum of the splits' slabs, rounded to bf16) * gelu'(H), and the column sums of g_h over each 128-row
+// half of the tile -> colpart[2 * row_tile + half][N], exactly the rows the whole-tile epilogue writes for its tiles.
+// grid (tail tiles, 2 halves), 1024 threads: thread = (row lane 0..31, 8-column group 0..31), 4 rows each; fixed-order LDS reduction.
+__global__ __launch_bounds__(1024) void slab_reduce_gelu_bwd_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_n,
+                                                                    long M, long N, long ldc, const __hip_bfloat16 *__restrict__ H,
+                                                                    __hip_bfloat16 *__restrict__ out16, float *__restrict__ colpart, int gelu_tanh) {
+    __shared__ float red[32][257];
+    const long t = blockIdx.x;
+    const long tile = first_tile + t;
+    const long m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+    const int half = blockIdx.y, rl0 = threadIdx.x >> 5, cl = (threadIdx.x & 31) * 8;
+    const long gc = n0 + cl;
+    float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 4; ++i) {
+        const int rl = 128 * half + 32 * i + rl0;
+        const long gr = m0 + rl;
+        if (gr >= M || gc + 8 > N) continue;
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nsplit; ++k) {
+            const float *sp = slabs + ((size_t)(t * nsplit + k) * 256 + rl) * 256 + cl;
+            const float4 a = *reinterpret_cast<const float4 *>(sp), b = *reinterpret_cast<const float4 *>(sp + 4);
+            v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+            v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+        }
+        const uint4 hq = *reinterpret_cast<const uint4 *>(H + gr * ldc + gc);
+        const unsigned hu[4] = {hq.x, hq.y, hq.z, hq.w};
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned vr = pack_bf16(v[2 * e], v[2 * e + 1]);      // the whole-tile epilogue multiplies the bf16-rounded product too
+            const act_f2 h2 = {bf16_lo(hu[e]), bf16_hi(hu[e])};
+            const act_f2 d2 = act_f2{bf16_lo(vr), bf16_hi(vr)} * (gelu_tanh ? gelu_grad2<true>(h2) : gelu_grad2<false>(h2));
+            o[e] = pack_bf16(d2.x, d2.y);
+            cs[2 * e] += bf16_lo(o[e]);
+            cs[2 * e + 1] += bf16_hi(o[e]);
+        }
+        *reinterpret_cast<uint4 *>(out16 + gr * ldc + gc) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl0][cl + e] = cs[e];
+    __syncthreads();
+    if (colpart && threadIdx.x < 256) {
+        const long c = n0 + threadIdx.x;
+        if (c < N) {
+            float tsum = 0.f;
+            for (int r = 0; r < 32; ++r) tsum += red[r][threadIdx.x];
+            colpart[((m0 / 128) + half) * N + c] = tsum;
+        }
     }
 }
 
@@ -1030,7 +1097,6 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
     const int pslot = prof_begin(prof_kind, flops, s);
     if (impl == XQ_GEMM_PERSISTENT) {
         PPlan pl = plan_persistent(tiles, g.kt_full, EPI == EPI_F32_SLAB);
-        if (ACT != ACT_NONE) pl = PPlan{tiles, 0, 1, 0};   // the fused activation lives in the whole-tile epilogue
         if (pl.slab_bytes > ws_bytes || (pl.slab_bytes && !ws)) {
             if (EPI == EPI_F32_SLAB) return xq_set_error(XQ_ENOSPACE, "%s: workspace too small", fn);
             pl = PPlan{tiles, 0, 1, 0};      // no workspace: every tile whole
@@ -1046,10 +1112,17 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         g.step_c = (int)(grid % g.tiles_n);
         const int lds = 8 * gm::PIECE_BYTES + 8 * 4096;
         if (launch_pring<AK, BK, ACT>(g, grid, lds, s)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-        if (EPI == EPI_BF16 && pl.tail_tiles)
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
-                               pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
-                               (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L);
+        // tail tiles: sum of the K-range slabs (+ bias / + the fused activation of the whole-tile epilogue)
+        if (EPI == EPI_BF16 && pl.tail_tiles) {
+            if (ACT == ACT_GELU_BWD)
+                hipLaunchKernelGGL(slab_reduce_gelu_bwd_kernel, dim3((unsigned)pl.tail_tiles, 2), dim3(1024), 0, s, (const float *)ws, pl.tail_splits,
+                                   pl.main_items, g.tiles_n, g.M, g.N, g.ldc, (const __hip_bfloat16 *)g.H, (__hip_bfloat16 *)g.C, g.colpart, g.gelu_tanh);
+            else
+                hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
+                                   pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
+                                   (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L,
+                                   ACT == ACT_GELU_FWD ? (__hip_bfloat16 *)g.C2 : (__hip_bfloat16 *)nullptr, g.gelu_tanh);
+        }
     } else {
         if (ACT != ACT_NONE) return xq_set_error(XQ_EINVAL, "%s: the fused activation needs the persistent schedule", fn);
         const long total = tiles * g.splits;
@@ -1185,7 +1258,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     if (compact) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)tiles, 32), dim3(256), 0, s, (const float *)ws, splits, 0L, g.tiles_n, (long)P,
                            (long)Q, (long)Q, (const float *)nullptr, (__hip_bfloat16 *)nullptr, g_w, (const __hip_bfloat16 *)g_y,
-                           (const __hip_bfloat16 *)x, done, (long)R);
+                           (const __hip_bfloat16 *)x, done, (long)R, (__hip_bfloat16 *)nullptr, 0);
     } else {
         const long quads = (P * Q) / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float *)ws, splits, (long)P,
@@ -1196,7 +1269,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
 
 // ---- fused MLP GEMMs (persistent schedule only: N >= 256, K >= 128) -----------------------------------------------------
 extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *h, void *h_act,
-                                    int approximate_tanh, xq_stream_t stream) {
+                                    int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
     const char *fn = "xq_gemm_bf16_nt_gelu";
     if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
@@ -1208,13 +1281,13 @@ extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *b
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
     g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
-    return launch_gemm<gm::KMAJOR, gm::KMAJOR, EPI_BF16, ACT_GELU_FWD>(g, 256, XQ_GEMM_PERSISTENT, nullptr, 0, (hipStream_t)stream, fn, 2.0 * M * N * K);
+    return launch_gemm<gm::KMAJOR, gm::KMAJOR, EPI_BF16, ACT_GELU_FWD>(g, 256, XQ_GEMM_PERSISTENT, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }
 
 extern "C" size_t xq_gemm_colpart_rows(int64_t M) { return M > 0 ? (size_t)(2 * ((M + 255) / 256)) : 0; }
 
 extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h,
-                                        float *colpart, int approximate_tanh, xq_stream_t stream) {
+                                        float *colpart, int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
     const char *fn = "xq_gemm_bf16_nn_gelu_bwd";
     if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
@@ -1226,7 +1299,7 @@ extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const vo
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
     g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
-    return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16, ACT_GELU_BWD>(g, 256, XQ_GEMM_PERSISTENT, nullptr, 0, (hipStream_t)stream, fn, 2.0 * M * N * K);
+    return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16, ACT_GELU_BWD>(g, 256, XQ_GEMM_PERSISTENT, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }
 
 // ---- 3x3 convolution as an implicit GEMM on the tile engine (NHWC bf16; Cin % 64 == 0, Cout % 8 == 0, Cout >= 64) -------------

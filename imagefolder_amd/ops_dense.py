@@ -375,9 +375,10 @@ class MlpFn(torch.autograd.Function):
         Hd = W1.shape[0]
         h = torch.empty(M, Hd, dtype=torch.bfloat16, device=a2.device)
         hg = torch.empty_like(h)
+        ws, nbytes = _gemm_ws(0, M, Hd, D, a2.device)
         with torch.cuda.device(a2.device):
             rc = _lib.lib().xq_gemm_bf16_nt_gelu(ptr(a2), ptr(W1), ptr(b1.detach().float().contiguous()), M, Hd, D, ptr(h), ptr(hg), int(bool(tanh)),
-                                                 _stream(a2))
+                                                 ptr(ws), nbytes, _stream(a2))
         check(rc, "xq_gemm_bf16_nt_gelu")
         f = gemm_nt(hg, W2, None if b2 is None else b2.detach().float().contiguous())
         ctx.save_for_backward(a2, W1, W2, h, hg)
@@ -395,8 +396,10 @@ class MlpFn(torch.autograd.Function):
         g_h = torch.empty_like(h)
         rows = _lib.lib().xq_gemm_colpart_rows(M)
         colpart = torch.empty(rows, Hd, dtype=torch.float32, device=h.device)
+        ws, nbytes = _gemm_ws(1, M, Hd, W2.shape[0], h.device)
         with torch.cuda.device(h.device):
-            rc = _lib.lib().xq_gemm_bf16_nn_gelu_bwd(ptr(g2), ptr(W2), ptr(h), M, Hd, W2.shape[0], ptr(g_h), ptr(colpart), int(tanh), _stream(h))
+            rc = _lib.lib().xq_gemm_bf16_nn_gelu_bwd(ptr(g2), ptr(W2), ptr(h), M, Hd, W2.shape[0], ptr(g_h), ptr(colpart), int(tanh), ptr(ws), nbytes,
+                                                     _stream(h))
         check(rc, "xq_gemm_bf16_nn_gelu_bwd")
         g_w2 = gemm_tn(g2, hg).to(wdtype) if ctx.needs_input_grad[3] else None
         g_b1 = None

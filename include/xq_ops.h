@@ -418,15 +418,19 @@ int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_
                     size_t workspace_bytes, int impl, xq_stream_t stream);
 /* fc1 of the transformer MLP with its GELU in the epilogue (timm Mlp.fc1 -> act, vision_transformer.py:295-339):
  * h[M][N] = x . w^T + bias (bf16, kept for the backward), h_act[M][N] = GELU(h) evaluated on the bf16-rounded h exactly as the
- * unfused Linear -> GELU pair does; approximate_tanh selects F.gelu(approximate='tanh').  N >= 256, K >= 128, K % 64 == 0. */
+ * unfused Linear -> GELU pair does; approximate_tanh selects F.gelu(approximate='tanh').  N >= 256, K >= 128, K % 64 == 0.
+ * workspace: xq_gemm_bf16_workspace_bytes(XQ_GEMM_OP_NT, M, N, K) bytes (the tiles beyond the last full round of CUs are cut along K
+ * into fp32 slabs whose sum gets the same bias + activation; without a workspace every tile runs whole: same values up to the fp32
+ * summation order, a partial last round). */
 int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *h, void *h_act,
-                         int approximate_tanh, xq_stream_t stream);
+                         int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 /* data gradient of fc2 with the GELU derivative in the epilogue: g_h[M][N] = (g_y[M][K] . w[K][N]) * GELU'(h[M][N]) (the product
  * rounded to bf16 before the multiplication, as the unfused pair does); colpart (nullable) fp32 [xq_gemm_colpart_rows(M)][N]
- * receives the column sums of g_h per 128-row block: their sum over the rows is the fc1 bias gradient. */
+ * receives the column sums of g_h per 128-row block: their sum over the rows is the fc1 bias gradient.  workspace:
+ * xq_gemm_bf16_workspace_bytes(XQ_GEMM_OP_NN, M, N, K) bytes, used as in xq_gemm_bf16_nt_gelu. */
 size_t xq_gemm_colpart_rows(int64_t M);
 int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h, float *colpart,
-                             int approximate_tanh, xq_stream_t stream);
+                             int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 /* 3x3 convolution on the GEMM tile engine (implicit GEMM: the A operand is gathered from the NHWC image tap by tap by the
  * LDS-DMA, out-of-image taps read a zero page; csrc/xq_gemm.hip Stager<KMAJOR_CONV>).  x [B][Hi][Wi][Cin] bf16, w_packed
  * [Cout][9 * Cin] bf16 as xq_conv3x3_pack_weights writes it, y [B][Ho][Wo][Cout] bf16 (+ bias, optional ReLU).

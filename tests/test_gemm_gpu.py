@@ -262,7 +262,9 @@ def test_gemm_wide_tiles_on_ragged_columns(M, N, K, impl):
 
 
 @pytest.mark.parametrize("tanh", [False, True])
-@pytest.mark.parametrize("B,N,D,Hd", [(2, 513, 768, 3072), (3, 197, 384, 1536), (1, 300, 256, 512)])
+# (8, 4192, 256, 512): 131 x 2 = 262 tiles on 256 CUs -> the six tiles beyond the full round are cut along K into fp32 slabs, and the
+# slab-sum kernels apply the activation / its derivative + the bias column sums (slab_reduce_kernel, slab_reduce_gelu_bwd_kernel)
+@pytest.mark.parametrize("B,N,D,Hd", [(2, 513, 768, 3072), (3, 197, 384, 1536), (1, 300, 256, 512), (8, 4192, 256, 512)])
 def test_fused_mlp_equals_the_unfused_functions(B, N, D, Hd, tanh):
     """MlpFn (GELU in the GEMM epilogues) vs LinearFn -> GeluFn -> LinearFn on the same GEMM kernels: the activation is
     evaluated on the same bf16-rounded values by the same device function, so outputs and gradients must agree to the
