@@ -142,6 +142,8 @@ def test_persistent_schedule_race_screen(op, M, N, K):
     shows up as a wrong tile that comes and goes), and they equal the one-workgroup-per-tile ring schedule bit for bit wherever the two cut
     the reduction the same way (NT / NN without K-split tail tiles: same MFMA order per accumulator), else up to the fp32 summation order."""
     od = _ops()
+    if op == "tn" and K % 256:
+        pytest.skip("ring schedules: 256-column tiles")
     if op == "tn":
         a, b = _rand((M, N), 7), _rand((M, K), 8)
         run = lambda: od.gemm_tn(a, b)

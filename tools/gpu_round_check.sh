@@ -52,7 +52,7 @@ if has gemmab; then
 fi
 if has gemmclock; then
   # in-kernel shader-clock sums of the persistent GEMM kernel: cycles per phase (load / barrier wait / MFMA / barrier wait) per shape and op
-  timeout 120 python tools/gemm_timeline.py --layers qkv proj fc1 fc2 --ops nt nn tn --sums --out $OUT/gemm_phase_sums.txt > $OUT/gemm_phase_sums.log 2>&1
+  timeout 120 python tools/gemm_timeline.py --layers qkv proj fc1 fc2 --ops nt nn tn --out $OUT/gemm_phase_sums.txt > $OUT/gemm_phase_sums.log 2>&1
   echo "gemmclock rc=$?"; grep -E "^## |K tile period" $OUT/gemm_phase_sums.txt | cut -c1-160
 fi
 if has configs; then
