@@ -87,12 +87,10 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: out[b, n, h, :] = softmax(q k^T * scale) v ; lse[b, h, n] = log sum exp (natural log, scaled scores)
-// block = `qpb` consecutive queries of one (b, h) on blockDim / 64 = 4..8 waves x 32 queries (attn_split below: N = 513 runs as
-// 3 blocks of 171 queries on 6 waves — round 3's fixed 128-query blocks needed a fifth block for the 513th token, i.e. five passes
-// over K / V per (batch, head) instead of three), loop over 64-key tiles: K and V row-major in LDS, 2 buffers.
+// block = 128 queries of one (b, h) (4 waves x 32), loop over 64-key tiles: K row-major + V transposed in LDS, 2 buffers.
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const short *__restrict__ qkv, int B, int N, int H, float c, short *__restrict__ out,
-                                                       float *__restrict__ lse, int nqb, int qpb) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const short *__restrict__ qkv, int B, int N, int H, float c, short *__restrict__ out,
+                                                       float *__restrict__ lse, int nqb) {
     __shared__ __attribute__((aligned(16))) short Ks[2][64 * AT_RP];
     __shared__ __attribute__((aligned(16))) short Vs[2][64 * AT_RP];
     int g, qb;
@@ -105,13 +103,11 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const short *__restric
     const short *base = qkv + (long)b * N * RS + h * 64;
     const short *kbase = base + H * 64, *vbase = base + 2 * H * 64;
 
-    // the block's 32-query groups rotate over the waves (= SIMDs) with the (batch, head) index, so that a partially filled last group
-    // does not always sit on the same SIMD
-    const int nw = blockDim.x >> 6;
-    const int wq = (wave + g) % nw;
-    const int q_end = (qb + 1) * qpb < N ? (qb + 1) * qpb : N;      // this block's queries: [qb * qpb, q_end)
-    const int qn = qb * qpb + wq * 32 + li;
-    const int qc = qn < q_end ? qn : q_end - 1;
+    // the block's four 32-query groups rotate over the waves (= SIMDs) with the (batch, head) index: N = 128 j + 1 (class
+    // token) leaves a block with ONE live group per (batch, head), which would otherwise always load SIMD 0
+    const int wq = (wave + g) & 3;
+    const int qn = qb * 128 + wq * 32 + li;
+    const int qc = qn < N ? qn : N - 1;
     bf16x8 qf0, qf1, qf2, qf3;
     {
         const short *qp = base + (long)qc * RS + 8 * hh;
@@ -121,30 +117,23 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const short *__restric
         qf3 = *reinterpret_cast<const bf16x8 *>(qp + 48);
     }
 
-    // staging: 16-byte chunks of K and V, key = tid/8 [+ blockDim/8 where that is still inside the 64-key tile], part = tid%8, row-major
-    const int kkey = tid >> 3, kpart = tid & 7, krp = blockDim.x >> 3;
-    const bool kpass2 = kkey + krp < 64;
-    const unsigned koff0 = (unsigned)(kkey * (int)RS + 8 * kpart), koff1 = koff0 + (unsigned)(krp * (int)RS);      // elements, inside one tile
+    // staging: 16-byte chunks of K and V, key = tid/8 [+32], part = tid%8, both row-major
+    const int kkey = tid >> 3, kpart = tid & 7;
     uint4 rk0, rk1, rv0, rv1;
 #define FW_LOAD(KV0)                                                                                                   \
-    {      /* uniform tile base + 32-bit per-thread offset; rows beyond N read the tile's first row and are zeroed */                \
-        const int k0_ = (KV0) + kkey, k1_ = k0_ + krp;                                                                 \
-        const bool o0_ = k0_ < N, o1_ = kpass2 && k1_ < N;                                                             \
-        const short *tk_ = kbase + (long)(KV0) * RS, *tv_ = vbase + (long)(KV0) * RS;                                  \
-        const unsigned f0_ = o0_ ? koff0 : 8u * kpart, f1_ = o1_ ? koff1 : 8u * kpart;                                 \
-        rk0 = load16_or_zero(tk_ + f0_, o0_);                                                                          \
-        rk1 = load16_or_zero(tk_ + f1_, o1_);                                                                          \
-        rv0 = load16_or_zero(tv_ + f0_, o0_);                                                                          \
-        rv1 = load16_or_zero(tv_ + f1_, o1_);                                                                          \
+    {                                                                                                                  \
+        const int k0_ = (KV0) + kkey, k1_ = k0_ + 32;                                                                  \
+        rk0 = load16_or_zero(kbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                              \
+        rk1 = load16_or_zero(kbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                              \
+        rv0 = load16_or_zero(vbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                              \
+        rv1 = load16_or_zero(vbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                              \
     }
 #define FW_STORE(BUF)                                                                                                  \
     {                                                                                                                  \
         *reinterpret_cast<uint4 *>(Ks[BUF] + kkey * AT_RP + 8 * kpart) = rk0;                                          \
+        *reinterpret_cast<uint4 *>(Ks[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rk1;                                   \
         *reinterpret_cast<uint4 *>(Vs[BUF] + kkey * AT_RP + 8 * kpart) = rv0;                                          \
-        if (kpass2) {                                                                                                  \
-            *reinterpret_cast<uint4 *>(Ks[BUF] + (kkey + krp) * AT_RP + 8 * kpart) = rk1;                              \
-            *reinterpret_cast<uint4 *>(Vs[BUF] + (kkey + krp) * AT_RP + 8 * kpart) = rv1;                              \
-        }                                                                                                              \
+        *reinterpret_cast<uint4 *>(Vs[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rv1;                                   \
     }
 
     f32x16 o0, o1;
@@ -155,7 +144,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const short *__restric
     // rare wave-uniform branch); the row sums come out of the matrix pipe (ones x P^T) instead of 32 VALU adds per tile.
     float m_run = -INFINITY, l_run = 0.0f;
     const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
-    const bool wave_live = qb * qpb + wq * 32 < q_end;   // waves whose 32 queries are all padding only help with staging
+    const bool wave_live = qb * 128 + wq * 32 < N;   // waves whose 32 queries are all padding only help with staging
 
     const int ntiles = (N + 63) / 64;
     FW_LOAD(0)
@@ -251,7 +240,7 @@ __global__ __launch_bounds__(512, 4) void attn_fwd_kernel(const short *__restric
 #undef FW_STORE
 
     const float inv = 1.0f / l_run;
-    if (qn < q_end) {
+    if (qn < N) {
         short *op = out + ((long)b * N + qn) * (H * 64) + h * 64 + 4 * hh;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -295,9 +284,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const short *__restrict
 // dQ: one query per lane (as the forward).  Per 64-key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP - delta) scale,
 // dQ^T += K^T dS^T.  LDS per buffer: K and V row-major (K^T fragments through transpose reads).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 3) void attn_bwd_dq_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
                                                           const float *__restrict__ lse, const float *__restrict__ delta, int B, int N, int H,
-                                                          float scale, short *__restrict__ dqkv, int nqb, int qpb) {
+                                                          float scale, short *__restrict__ dqkv, int nqb) {
     __shared__ __attribute__((aligned(16))) short Ks[2][64 * AT_RP];
     __shared__ __attribute__((aligned(16))) short Vs[2][64 * AT_RP];
     int g, qb;
@@ -311,11 +300,9 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dq_kernel(const short *__rest
     const short *kbase = base + H * 64, *vbase = base + 2 * H * 64;
     const float c = scale * 1.4426950408889634f;
 
-    const int nw = blockDim.x >> 6;
-    const int wq = (wave + g) % nw;      // query groups rotate over the SIMDs (see attn_fwd_kernel)
-    const int q_end = (qb + 1) * qpb < N ? (qb + 1) * qpb : N;
-    const int qn = qb * qpb + wq * 32 + li;
-    const int qc = qn < q_end ? qn : q_end - 1;
+    const int wq = (wave + g) & 3;      // query groups rotate over the SIMDs (see attn_fwd_kernel)
+    const int qn = qb * 128 + wq * 32 + li;
+    const int qc = qn < N ? qn : N - 1;
     bf16x8 qf0, qf1, qf2, qf3, df0, df1, df2, df3;
     {
         const short *qp = base + (long)qc * RS + 8 * hh;
@@ -332,36 +319,29 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dq_kernel(const short *__rest
     const float lse2 = lse[((long)b * H + h) * N + qc] * 1.4426950408889634f;
     const float dq_ = delta[((long)b * H + h) * N + qc];
 
-    const int kkey = tid >> 3, kpart = tid & 7, krp = blockDim.x >> 3;
-    const bool kpass2 = kkey + krp < 64;
-    const unsigned koff0 = (unsigned)(kkey * (int)RS + 8 * kpart), koff1 = koff0 + (unsigned)(krp * (int)RS);      // elements, inside one tile
+    const int kkey = tid >> 3, kpart = tid & 7;
     uint4 rk0, rk1, rv0, rv1;
 #define DQ_LOAD(KV0)                                                                                                   \
-    {      /* uniform tile base + 32-bit per-thread offset; rows beyond N read the tile's first row and are zeroed */                \
-        const int k0_ = (KV0) + kkey, k1_ = k0_ + krp;                                                                 \
-        const bool o0_ = k0_ < N, o1_ = kpass2 && k1_ < N;                                                             \
-        const short *tk_ = kbase + (long)(KV0) * RS, *tv_ = vbase + (long)(KV0) * RS;                                  \
-        const unsigned f0_ = o0_ ? koff0 : 8u * kpart, f1_ = o1_ ? koff1 : 8u * kpart;                                 \
-        rk0 = load16_or_zero(tk_ + f0_, o0_);                                                                          \
-        rk1 = load16_or_zero(tk_ + f1_, o1_);                                                                          \
-        rv0 = load16_or_zero(tv_ + f0_, o0_);                                                                          \
-        rv1 = load16_or_zero(tv_ + f1_, o1_);                                                                          \
+    {                                                                                                                  \
+        const int k0_ = (KV0) + kkey, k1_ = k0_ + 32;                                                                  \
+        rk0 = load16_or_zero(kbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                   \
+        rk1 = load16_or_zero(kbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                   \
+        rv0 = load16_or_zero(vbase + (long)(k0_ < N ? k0_ : 0) * RS + 8 * kpart, k0_ < N);                   \
+        rv1 = load16_or_zero(vbase + (long)(k1_ < N ? k1_ : 0) * RS + 8 * kpart, k1_ < N);                   \
     }
 #define DQ_STORE(BUF)                                                                                                  \
     {                                                                                                                  \
         *reinterpret_cast<uint4 *>(Ks[BUF] + kkey * AT_RP + 8 * kpart) = rk0;                                          \
+        *reinterpret_cast<uint4 *>(Ks[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rk1;                                   \
         *reinterpret_cast<uint4 *>(Vs[BUF] + kkey * AT_RP + 8 * kpart) = rv0;                                          \
-        if (kpass2) {                                                                                                  \
-            *reinterpret_cast<uint4 *>(Ks[BUF] + (kkey + krp) * AT_RP + 8 * kpart) = rk1;                              \
-            *reinterpret_cast<uint4 *>(Vs[BUF] + (kkey + krp) * AT_RP + 8 * kpart) = rv1;                              \
-        }                                                                                                              \
+        *reinterpret_cast<uint4 *>(Vs[BUF] + (kkey + 32) * AT_RP + 8 * kpart) = rv1;                                   \
     }
 
     f32x16 a0, a1;   // dQ^T, d rows 0..31 / 32..63
 #pragma unroll
     for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
 
-    const bool wave_live = qb * qpb + wq * 32 < q_end;   // waves whose 32 queries are all padding only help with staging
+    const bool wave_live = qb * 128 + wq * 32 < N;   // waves whose 32 queries are all padding only help with staging
     const int ntiles = (N + 63) / 64;
     DQ_LOAD(0)
     DQ_STORE(0)
@@ -421,7 +401,7 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dq_kernel(const short *__rest
 #undef DQ_LOAD
 #undef DQ_STORE
 
-    if (qn < q_end) {
+    if (qn < N) {
         short *op = dqkv + ((long)b * N + qn) * RS + h * 64 + 4 * hh;
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -438,9 +418,9 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dq_kernel(const short *__rest
 // P = exp2(S c - lse2), dS = P (dP - delta) scale, dV^T += dO^T P, dK^T += Q^T dS.
 // LDS per buffer: Q, dO row-major [32][72]; Q, dO transposed [64][36]; lse2, delta [32].
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 3) void attn_bwd_dkdv_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
+__global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
                                                             const float *__restrict__ lse, const float *__restrict__ delta, int B, int N, int H,
-                                                            float scale, short *__restrict__ dqkv, int nkb, int kpb) {
+                                                            float scale, short *__restrict__ dqkv, int nkb) {
     __shared__ __attribute__((aligned(16))) short Qs[2][32 * AT_RP];
     __shared__ __attribute__((aligned(16))) short Os[2][32 * AT_RP];
     __shared__ __attribute__((aligned(16))) float Ls[2][32];
@@ -458,14 +438,12 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dkdv_kernel(const short *__re
     const float *lseb = lse + ((long)b * H + h) * N, *delb = delta + ((long)b * H + h) * N;
     const float c = scale * 1.4426950408889634f;
 
-    const int nw = blockDim.x >> 6;
-    const int wk = (wave + g) % nw;      // key groups rotate over the SIMDs (see attn_fwd_kernel)
-    const int k_end = (kb + 1) * kpb < N ? (kb + 1) * kpb : N;      // this block's keys: [kb * kpb, k_end)
-    const int kn = kb * kpb + wk * 32 + li;
-    const bool wave_live = kb * kpb + wk * 32 < k_end;   // waves whose 32 keys are all padding only help with staging
+    const int wk = (wave + g) & 3;      // key groups rotate over the SIMDs (see attn_fwd_kernel)
+    const int kn = kb * 128 + wk * 32 + li;
+    const bool wave_live = kb * 128 + wk * 32 < N;   // waves whose 32 keys are all padding only help with staging
     bf16x8 kf0, kf1, kf2, kf3, vf0, vf1, vf2, vf3;
     {
-        const bool ok = kn < k_end;
+        const bool ok = kn < N;
         const short *kp = base + (long)(ok ? kn : 0) * RS + H * 64 + 8 * hh;
         const short *vp = kp + H * 64;
         kf0 = __builtin_bit_cast(bf16x8, load16_or_zero(kp, ok));
@@ -478,14 +456,12 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dkdv_kernel(const short *__re
         vf3 = __builtin_bit_cast(bf16x8, load16_or_zero(vp + 48, ok));
     }
 
-    // staging: one 16-byte chunk of Q and of dO per thread of the first four waves (query = tid/8, part = tid%8); threads 0..31 fetch lse,
-    // 32..63 delta
-    const int sq = (tid >> 3) & 31, sp = tid & 7;
-    const bool stager = tid < 256;
-    uint4 rq = make_uint4(0u, 0u, 0u, 0u), ro = make_uint4(0u, 0u, 0u, 0u);
+    // staging: one 16-byte chunk of Q and of dO per thread (query = tid/8, part = tid%8); threads 0..31 fetch lse, 32..63 delta
+    const int sq = tid >> 3, sp = tid & 7;
+    uint4 rq, ro;
     float rl = 0.0f;
 #define KV_LOAD(Q0)                                                                                                    \
-    if (stager) {                                                                                                      \
+    {                                                                                                                  \
         const int q_ = (Q0) + sq;                                                                                      \
         rq = load16_or_zero(base + (long)(q_ < N ? q_ : 0) * RS + 8 * sp, q_ < N);                          \
         ro = load16_or_zero(dob + (long)(q_ < N ? q_ : 0) * OSr + 8 * sp, q_ < N);                          \
@@ -495,7 +471,7 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dkdv_kernel(const short *__re
         }                                                                                                              \
     }
 #define KV_STORE(BUF)                                                                                                  \
-    if (stager) {                                                                                                      \
+    {                                                                                                                  \
         *reinterpret_cast<uint4 *>(Qs[BUF] + sq * AT_RP + 8 * sp) = rq;                                                \
         *reinterpret_cast<uint4 *>(Os[BUF] + sq * AT_RP + 8 * sp) = ro;                                                \
         if (tid < 32) Ls[BUF][li] = rl;                                                                                \
@@ -558,7 +534,7 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dkdv_kernel(const short *__re
 #undef KV_LOAD
 #undef KV_STORE
 
-    if (kn < k_end) {
+    if (kn < N) {
         short *kp = dqkv + ((long)b * N + kn) * RS + H * 64 + h * 64 + 4 * hh;
         short *vp = kp + H * 64;
 #pragma unroll
@@ -573,17 +549,6 @@ __global__ __launch_bounds__(512, 3) void attn_bwd_dkdv_kernel(const short *__re
     }
 }
 
-// how the N queries (keys in the dK/dV kernel) of one (batch, head) are cut into workgroups: the fewest blocks of <= 256 rows, every
-// block the same number of rows (+-1), 4..8 waves of 32 rows each.  N = 513 / 514: 3 blocks x 171 / 172 rows on 6 waves;
-// N = 257: 2 x 129 on 5 waves; N = 197: 1 x 197 on 7 waves.
-static void attn_split(int N, int &nblk, int &per, int &threads) {
-    nblk = (N + 255) / 256;
-    per = (N + nblk - 1) / nblk;
-    int nw = (per + 31) / 32;
-    if (nw < 4) nw = 4;
-    threads = 64 * nw;
-}
-
 static int attn_check(const char *fn, int B, int N, int H, int head_dim) {
     if (B < 0 || N < 1 || H < 1) return xq_set_error(XQ_EINVAL, "%s: bad sizes (N=%ld, H=%ld)", fn, (long)N, (long)H);
     if (head_dim != 64) return xq_set_error(XQ_EINVAL, "%s: head_dim must be 64 (got %ld)", fn, (long)head_dim);
@@ -595,12 +560,10 @@ extern "C" int xq_attn_forward(const void *qkv, int B, int N, int H, int head_di
     if (int rc = attn_check(fn, B, N, H, head_dim)) return rc;
     if (B == 0) return XQ_OK;
     if (!qkv || !out || !lse) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    int nqb, qpb, threads;
-    attn_split(N, nqb, qpb, threads);
-    const int G8 = (B * H + 7) / 8 * 8;
+    const int nqb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
     const int pslot = prof_begin(XQ_PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * 64.0, (hipStream_t)stream);
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(G8 * nqb)), dim3(threads), 0, (hipStream_t)stream, (const short *)qkv, B, N, H,
-                       scale * 1.4426950408889634f, (short *)out, lse, nqb, qpb);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(G8 * nqb)), dim3(256), 0, (hipStream_t)stream, (const short *)qkv, B, N, H,
+                       scale * 1.4426950408889634f, (short *)out, lse, nqb);
     prof_end(pslot, (hipStream_t)stream);
     return xq_check_launch(fn);
 }
@@ -616,13 +579,11 @@ extern "C" int xq_attn_backward(const void *qkv, const void *out, const void *do
     const int pslot = prof_begin(XQ_PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * 64.0, s);
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const short *)out, (const short *)dout, B, N, H,
                        delta);
-    int nb, per, threads;
-    attn_split(N, nb, per, threads);
-    const int G8 = (B * H + 7) / 8 * 8;
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(G8 * nb)), dim3(threads), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N,
-                       H, scale, (short *)dqkv, nb, per);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(G8 * nb)), dim3(threads), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N, H,
-                       scale, (short *)dqkv, nb, per);
+    const int nb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
+    hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N,
+                       H, scale, (short *)dqkv, nb);
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N, H,
+                       scale, (short *)dqkv, nb);
     prof_end(pslot, s);
     return xq_check_launch(fn);
 }

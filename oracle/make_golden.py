@@ -444,6 +444,108 @@ def gen_model_bf16(name, kw, seed):
     print("wrote", name + "_bf16", "rec range", float(rec.min()), float(rec.max()))
 
 
+def reference_vqloss(aug_prob=0.0):
+    """The reference's VQLoss (vq_loss.py:79-152) constructed offline: its three network dependencies are cut, nothing else —
+      * torchvision.models.vgg16 -> oracle/torchvision_shim.py (architecture restated, random init);
+      * LPIPS.load_from_pretrained (lpips.py:66-69: downloads vgg.pth) -> no-op;
+      * torch.hub.load_state_dict_from_url (discriminator_dino.py:178: the DINO-S checkpoint) -> empty state dict, and DinoDisc's default
+        device 'cuda' -> 'cpu' (its constructor moves the frozen trunk there, :196).
+    LPIPS / vgg16 wrapper / NetLinLayer / DinoDisc / DiffAug / VQLoss.forward run unmodified."""
+    import importlib
+    from oracle import torchvision_shim
+    load_reference()
+    rl = importlib.import_module("tokenizer.tokenizer_image.lpips")
+    rl.models = torchvision_shim.models
+    rl.LPIPS.load_from_pretrained = lambda self, name="vgg_lpips": None
+    dd = importlib.import_module("tokenizer.tokenizer_image.discriminator_dino")
+    d = list(dd.DinoDisc.__init__.__defaults__)
+    d[1] = "cpu"
+    dd.DinoDisc.__init__.__defaults__ = tuple(d)
+    rv = importlib.import_module("tokenizer.tokenizer_image.vq_loss")
+    saved = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: {}
+    try:
+        # xqgan_train.py:320-335 with the argparse defaults (:90 disc_weight 0.5) and the VQ-8192.yaml entries (lecam 0.001, adaptive weight)
+        L = rv.VQLoss(disc_start=0, disc_weight=0.5, disc_type="dinodisc", disc_loss="hinge", gen_adv_loss="hinge", image_size=256,
+                      perceptual_weight=1.0, reconstruction_weight=1.0, reconstruction_loss="l2", codebook_weight=1.0, lecam_loss_weight=0.001,
+                      disc_adaptive_weight=True, norm_type="bn", aug_prob=aug_prob)
+    finally:
+        torch.hub.load_state_dict_from_url = saved
+    return L, rv
+
+
+def gen_vqloss(name, B, seed):
+    """VQLoss as a whole (vq_loss.py:161-261, lpips.py:83-96,118-155, discriminator_dino.py:157-248): generator loss with the adaptive
+    weight, its gradient into the reconstruction and the decoder's last layer, then the discriminator loss (hinge + LeCAM) and the gradients
+    of the head parameters.  train() mode as xqgan_train.py:417, LPIPS's dropout layers in eval() (per-rank device RNG upstream), aug_prob = 0
+    (DiffAug has its own same-draws test)."""
+    from oracle.det_init import det_state_dict, vqloss_inputs
+    L, rv = reference_vqloss(aug_prob=0.0)
+    L.load_state_dict(det_state_dict(L.state_dict(), seed))
+    proxy = L.discriminator.dino_proxy[0]
+    proxy.load_state_dict({k[len("dino_proxy."):]: v for k, v in det_state_dict({"dino_proxy." + k: v for k, v in proxy.state_dict().items()}, seed).items()})
+    L.train()
+    L.perceptual_loss.eval()
+    imgs, pre, last0 = vqloss_inputs(B, seed)
+    pre = pre.requires_grad_(True)
+    last = torch.nn.Parameter(last0.clone())
+    cb = (torch.tensor(0.1), torch.tensor(0.02), torch.tensor(0.0), [1.0])
+    out = {}
+    rec = torch.nn.functional.conv2d(pre, last)
+    # the pieces, recorded one by one (same module state: the spectral-norm power iteration advances per discriminator forward, so the
+    # discriminator is evaluated exactly as often as one generator step + one discriminator step do: fake, [fake, real])
+    import copy
+    L2 = copy.deepcopy(L)          # for the separately recorded pieces: leaves L's spectral-norm vectors untouched
+    with torch.no_grad():
+        out["rec_loss"] = np.float64(L2.rec_loss(imgs, rec).item())
+        out["p_loss"] = np.float64(torch.mean(L2.perceptual_loss(imgs, rec)).item())
+    rec2 = torch.nn.functional.conv2d(pre, last)
+    nll = L2.rec_weight * L2.rec_loss(imgs, rec2) + L2.perceptual_weight * torch.mean(L2.perceptual_loss(imgs, rec2))
+    adv = L2.gen_adv_loss(L2.discriminator(L2.daug.aug(rec2, 0)))
+    out["adv_loss"] = np.float64(adv.item())
+    out["d_weight"] = np.float64(L2.calculate_adaptive_weight(nll, adv, last_layer=last).item())
+    # the generator step as the trainer runs it (xqgan_train.py:447-456)
+    loss = L(cb, None, None, 0.0, imgs, rec, optimizer_idx=0, global_step=5, last_layer=last, logger=None, log_every=1000000)
+    loss.backward()
+    out["gen_loss"] = np.float64(loss.item())
+    out["g_pre_sub"] = grad_subsample(pre.grad).numpy().copy()
+    out["g_pre_l2"] = np.float64(pre.grad.double().square().sum().sqrt())
+    out["g_last"] = last.grad.numpy().copy()
+    head_names = [n for n, p in L.discriminator.named_parameters() if p.requires_grad]
+    # upstream's generator backward deposits head gradients too; optimizer_disc.zero_grad() discards them (xqgan_train.py:465)
+    for p in L.discriminator.parameters():
+        p.grad = None
+    d = L(cb, None, None, 0.0, imgs, rec.detach(), optimizer_idx=1, global_step=5, logger=None, log_every=1000000)
+    d.backward()
+    out["disc_loss"] = np.float64(d.item())
+    out["lecam_real"] = np.float64(L.lecam_ema.logits_real_ema)
+    out["lecam_fake"] = np.float64(L.lecam_ema.logits_fake_ema)
+    params = dict(L.discriminator.named_parameters())
+    for n in head_names:
+        g = params[n].grad
+        out["gd:" + n] = grad_subsample(g).numpy().copy()
+        out["gd:" + n + ":l2"] = np.float64(g.double().square().sum().sqrt())
+    # conditioning of the recorded gradient: the discriminator path has kinks (LeakyReLU heads behind batch statistics) — relative input
+    # noise at the fp32 rounding level moves the REFERENCE's own d adv / d recons in jumps of ~0.15 %.  Recorded so that the tests' bounds
+    # on that gradient (and on the adaptive weight that is a ratio of its norms) are derived from a measurement, not chosen.
+    def adv_grad(noise, s):
+        Lc, _ = reference_vqloss(aug_prob=0.0)
+        Lc.load_state_dict(det_state_dict(Lc.state_dict(), seed))
+        pc = Lc.discriminator.dino_proxy[0]
+        pc.load_state_dict({k[len("dino_proxy."):]: v for k, v in det_state_dict({"dino_proxy." + k: v for k, v in pc.state_dict().items()}, seed).items()})
+        Lc.train()
+        r = rec.detach() * (1 + noise * torch.randn(rec.shape, generator=torch.Generator().manual_seed(s)))
+        r.requires_grad_(True)
+        return torch.autograd.grad(Lc.gen_adv_loss(Lc.discriminator(Lc.daug.aug(r, 0))), r)[0]
+    g0 = adv_grad(0.0, 0)
+    out["adv_grad_rel_change_under_noise"] = np.array([[n, float(((adv_grad(n, s) - g0).norm() / g0.norm()).item())]
+                                                       for n, s in ((1e-7, 1), (1e-7, 2), (1e-6, 3), (1e-6, 4), (1e-5, 5), (1e-5, 6))])
+    print("conditioning (input noise, relative change of d adv / d recons):", out["adv_grad_rel_change_under_noise"].tolist())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), B=np.int64(B), seed=np.int64(seed), head_names=np.array(head_names),
+                        meta=np.array(str(meta())), **out)
+    print("wrote", name, {k: float(v) for k, v in out.items() if np.ndim(v) == 0 and not k.startswith('gd:')})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
@@ -458,6 +560,10 @@ def main():
                                                  num_latent_tokens=256, product_quant=1, abs_pos_embed=True,
                                                  encoder_model="vit_base_patch14_dinov2.lvd142m",
                                                  decoder_model="vit_base_patch14_dinov2.lvd142m"), seed=32)
+        if only:
+            return
+    if only in ("vqloss", ""):
+        gen_vqloss("vqloss_dinodisc_b4", 4, seed=61)
         if only:
             return
     if only in ("lfq", ""):
