@@ -332,6 +332,7 @@ def main():
                     if t_eager_pre < 0.99 * t_replay:
                         graph_note = (f"off (auto: captured, but the eager step measured faster on this config: {t_eager_pre:.1f} vs "
                                       f"{t_replay:.1f} ms over 3 steps each)")
+                        captured.restore_host_rng()      # the eager steps timed below draw the dropout depths on the host again, as upstream
                         captured = None
             except Exception as e:  # noqa: BLE001
                 if args.graph == "on":

@@ -102,7 +102,11 @@ def _weight_2d(weight):
     base (the optimizer-maintained one for trainable parameters, ops_dense._w16) so that LinearFn does not re-cast fp32 -> bf16 on
     every call (quant_conv / post_quant_conv / patch embedding weights)."""
     w2 = weight.reshape(weight.shape[0], -1)
-    if weight.is_cuda and weight.dtype == torch.float32:
+    # only where the bf16 GEMM path will read it (bf16 autocast), or where a shadow exists anyway: the fp32 inference path and the
+    # flop-counting pass would otherwise pay a cast kernel + allocation per call for a trainable weight without an arena shadow
+    wants16 = torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+    has16 = getattr(weight, "_xq_w16", None) is not None or getattr(weight, "_xq_w16_frozen", None) is not None
+    if weight.is_cuda and weight.dtype == torch.float32 and (wants16 or has16):
         from .ops_dense import _w16
         w2._xq_w16 = _w16(weight).reshape(w2.shape)
         w2._xq_w16_version = w2._version          # a view shares its base's version counter

@@ -291,15 +291,16 @@ class ArenaOptimizer:
         unknown = sorted(set(st) - set(self._torch_index))
         if unknown:
             raise ValueError(f"optimizer state for parameter positions {unknown[:8]}... that are not trainable here")
-        missing = [ti for ti in self._torch_index if ti not in st]
-        if st and missing:
-            raise ValueError(f"optimizer state has no entry for trainable parameter positions {missing[:8]}...")
+        # torch.optim.AdamW creates state only for parameters that have received a gradient: a trainable parameter without an entry
+        # (never used upstream, or frozen when the checkpoint was written) starts from zero moments, as torch itself would load it
         steps = set()
         for ti, p, o in zip(self._torch_index, a.params, a.offsets):
             e = st.get(ti)
-            if e is None:
-                continue
             n = p.numel()
+            if e is None:
+                a.m[o:o + n].zero_()
+                a.v[o:o + n].zero_()
+                continue
             if tuple(e["exp_avg"].shape) != tuple(p.shape):
                 raise ValueError(f"optimizer state of parameter {ti}: shape {tuple(e['exp_avg'].shape)} vs {tuple(p.shape)}")
             a.m[o:o + n].copy_(e["exp_avg"].reshape(-1))
@@ -308,9 +309,6 @@ class ArenaOptimizer:
         if len(steps) > 1:
             raise ValueError("per-parameter step counts differ: not an AdamW state this optimizer can hold")
         a.step_count = steps.pop() if steps else 0
-        if not st:
-            a.m.zero_()
-            a.v.zero_()
         g = groups[0]
         self.lr, self.betas, self.eps, self.weight_decay = g["lr"], tuple(g["betas"]), g["eps"], g["weight_decay"]
         if "ema" in sd and a.ema is not None:
@@ -407,6 +405,7 @@ class TokenizerTrainStep:
 
     # -- one train step -----------------------------------------------------------------------------------------
     def step(self, imgs, epoch=0, alpha=0.0, beta=0.0, delta=100):
+        self.eager_steps = getattr(self, "eager_steps", 0) + 1      # what CapturedStep.replay checks (not the optimizer's step count)
         self.arena.release_grads()                 # backward nodes' gradient tensors are adopted, not added (FlatArena.collect)
         dev_type = imgs.device.type
         with torch.autocast(device_type=dev_type, dtype=self.amp_dtype, enabled=self.amp_dtype is not None):
@@ -465,6 +464,9 @@ class CapturedStep:
         if ts.reducer.active:
             raise RuntimeError("CapturedStep: the gradient all-reduce is not recorded; use TokenizerTrainStep.step with world > 1")
         multi_scale = len(getattr(ts.model, "v_patch_nums", [0])) > 1
+        # the device-RNG switch below stays on for the life of a SUCCESSFUL capture; a failed one puts the host RNG back (the eager steps
+        # that follow must draw the dropout depths as upstream does, xqgan_model.py:274)
+        self._prev_device_dropout_rng = getattr(ts.model, "device_dropout_rng", None)
         if multi_scale and float(getattr(ts.model, "codebook_drop", 0.0) or 0.0) > 0:
             # upstream draws the quantizer-dropout depths on the host every step (xqgan_model.py:274): a replay would freeze them.
             # The model draws them from the DEVICE generator instead (same distribution, advances per replay like DropPath's masks)
@@ -491,6 +493,9 @@ class CapturedStep:
         try:
             with torch.cuda.graph(self.graph):
                 self.loss = ts.step(self.static_imgs, epoch, alpha, beta, delta)
+        except BaseException:
+            self.restore_host_rng()
+            raise
         finally:
             # the capture pass ran the host bookkeeping once without executing anything (also when it raised half way): the step
             # counters go back, replay() advances them per step.  The arena EPOCHS stay advanced (and move once more): every cache
@@ -502,21 +507,25 @@ class CapturedStep:
                 disc.opt.arena.step_count, disc.global_step = d0
                 disc.opt.arena.epoch += 1
         self._disc = disc
-        self._expected_step = ts.arena.step_count      # host step count the next replay must find (see the class docstring)
+        self._eager_seen = ts.eager_steps      # eager steps of this TokenizerTrainStep at capture time (see the class docstring)
+
+    def restore_host_rng(self):
+        """Put the model's dropout-depth draws back on the host generator (a discarded or failed capture)."""
+        if self._prev_device_dropout_rng is not None and hasattr(self.ts.model, "device_dropout_rng"):
+            self.ts.model.device_dropout_rng = self._prev_device_dropout_rng
 
     def replay(self, imgs: Optional[torch.Tensor] = None):
-        if self.ts.arena.step_count != self._expected_step:
-            raise RuntimeError("CapturedStep.replay: eager steps were taken since the capture / the last replay "
-                               f"(step count {self.ts.arena.step_count}, expected {self._expected_step}); capture the step again")
+        if self.ts.eager_steps != self._eager_seen:
+            raise RuntimeError(f"CapturedStep.replay: {self.ts.eager_steps - self._eager_seen} eager step(s) were taken since the capture; "
+                               "capture the step again")
         if imgs is not None and imgs.data_ptr() != self.static_imgs.data_ptr():
             self.static_imgs.copy_(imgs, non_blocking=True)
-        # the device step counters follow the host ones (a loaded checkpoint between capture and replay): the graph adds 1
+        # the device step counters follow the host ones (ArenaOptimizer.load_state_dict between capture and replay moves them): the graph adds 1
         self.ts.opt._step_dev.fill_(float(self.ts.arena.step_count))
         if self._disc is not None:
             self._disc.opt._step_dev.fill_(float(self._disc.opt.arena.step_count))
         self.graph.replay()
         self.ts.arena.step_count += 1
-        self._expected_step += 1
         self.ts.arena.epoch += 1
         if self._disc is not None:
             self._disc.opt.arena.step_count += 1
