@@ -97,6 +97,29 @@ def to_uint8_like_reference(x: torch.Tensor) -> torch.Tensor:
     return torch.clamp(127.5 * x + 128.0, 0, 255).to(torch.uint8)
 
 
+@torch.no_grad()
+def reconstruct_for_fid(model, x: torch.Tensor, perturb=None, epoch: int = 0) -> torch.Tensor:
+    """The reconstruction the FID is taken of.
+      * rFID (perturb = None): `vq_model.img_to_reconstructed_img(x)`, the in-loop evaluation of xqgan_train.py:523-525;
+      * pFID (RobustTok, BASELINE config 5 "pFID eval on"; README.md:57-59): perturb = (alpha, beta, delta) — the image decoded from
+        PERTURBED latents.  The reference has no separate evaluator for it: the perturbation lives in VQModel.forward
+        (xqgan_model.py:292-297: add_perturbation on the first int(B * beta) samples of the batch, beta = 1 perturbs every sample), so the
+        pFID reconstruction is `vq_model(x, epoch, alpha, beta, delta)[0]` in eval mode (no DropPath, no quantizer dropout), clamped to
+        [-1, 1] like img_to_reconstructed_img (:399).  Only single-quantizer models perturb (product_quant == 1, as upstream)."""
+    if perturb is None:
+        return model.img_to_reconstructed_img(x)
+    alpha, beta, delta = perturb
+    if getattr(model, "product_quant", 1) != 1:
+        raise ValueError("pFID: VQModel.forward perturbs the latents of single-quantizer models only (xqgan_model.py:276-297)")
+    was_training = model.training
+    model.eval()
+    try:
+        dec = model(x, epoch, alpha, beta, delta)[0]
+    finally:
+        model.train(was_training)
+    return dec.float().clamp_(-1, 1)
+
+
 class ReconstructionFID:
     """rFID between the inputs and their reconstructions under a frozen feature network.
 
@@ -118,6 +141,11 @@ class ReconstructionFID:
         self.ref.update(self.feature_fn(gt))
         self.smp.update(self.feature_fn(sample))
         return self
+
+    @torch.no_grad()
+    def update_from_model(self, model, x: torch.Tensor, perturb=None, epoch: int = 0):
+        """rFID (perturb = None) or pFID (perturb = (alpha, beta, delta)) of `model` on the batch x: see reconstruct_for_fid"""
+        return self.update(x, reconstruct_for_fid(model, x, perturb, epoch))
 
     def compute(self, on_device: bool = False) -> float:
         self.ref.all_reduce(self.group)

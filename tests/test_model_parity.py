@@ -81,8 +81,9 @@ def test_gpu_fp32_indices_and_pixels_match_reference_cpu(oracle, name):
     assert np.abs(f.cpu().numpy() - g["f"]).max() <= 2e-4 * max(1.0, np.abs(g["f"]).max())
     E = m.quantize.embedding.weight.detach().cpu().numpy()
     # indices: exact, except tokens whose two candidate codes are an fp64-verified near tie ON THE REFERENCE latent
+    # (measured, rounds 1-3: 0 mismatches on both configs; the slack is two tokens, each of which must be such a tie)
     par = oracle.index_parity(g["f"], E, oracle.MODE_L2_NORMED, idx, g["idx"], tol=2e-4)
-    assert par["match_rate"] >= 0.98 and par["all_ties"], par
+    assert par["n_mismatch"] <= 2 and par["all_ties"], par
     # the HIP quantizer on the REFERENCE latent is bit-exact with the reference's indices
     from imagefolder_amd import ops
     idx_ref_latent = ops.assign(torch.from_numpy(g["f"]).cuda(), m.quantize.embedding.weight, ops.MODE_L2_NORMED).cpu().numpy()
@@ -91,8 +92,8 @@ def test_gpu_fp32_indices_and_pixels_match_reference_cpu(oracle, name):
     # pixels: <= 1e-4 wherever the 16x16-pixel patch's token (and, for the CNN, its receptive field) kept its code
     if par["n_mismatch"] == 0:
         assert np.abs(rec - g["rec"]).max() <= 1e-4
-    else:  # a flipped token changes its neighbourhood legitimately; the rest must still agree
-        assert np.mean(np.abs(rec - g["rec"]) <= 1e-4) >= 0.9
+    else:  # a flipped token (an fp64-verified tie, at most two) changes its neighbourhood legitimately; the rest must still agree
+        assert np.mean(np.abs(rec - g["rec"]) <= 1e-4) >= 0.97
 
 
 @pytest.mark.gpu
