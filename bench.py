@@ -38,6 +38,10 @@ import os
 import sys
 import time
 
+# before the HIP runtime comes up, under ANY launcher (self-spawn below, an external torchrun, the driver's torch.distributed.run line):
+# this pool's host driver supports dmabuf IPC only, and without it RCCL fails with `hipIpcGetMemHandle: invalid argument`
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import torch
 import torch.distributed as dist
 
@@ -73,6 +77,8 @@ def parse():
                         "recon = rec + codebook + semantic only")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-mfu", action="store_true", help="skip the FlopCounterMode pass (mfu = null)")
+    p.add_argument("--allow-library", action="store_true", help="do not raise when a dense op of the bf16 step falls back to a PyTorch-ROCm "
+                   "library op (default: nn_ops.STRICT_HIP on — such a fallback aborts the run instead of being timed)")
     p.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the links")
     p.add_argument("--graph", default="off", choices=["auto", "on", "off"],
                    help="off (default): the eager step — the program every N > 1 run executes, and since round 3 level with the replay "
@@ -164,6 +170,8 @@ def count_flops_per_image(args, dev, B_count=2):
     a2 = argparse.Namespace(**vars(args))
     a2.batch = B_count
     from tools.library_backend import library_dense_ops     # A/B harness: the library formulation the counter has formulas for
+    from imagefolder_amd import nn_ops as _nn_ops
+    _nn_ops.STRICT_HIP = False                               # this pass IS the library formulation (amp_dtype=None: fp32, no autocast)
     with library_dense_ops():
         torch.manual_seed(0)
         model, ts = build_train_step(a2, dev, 1, amp_dtype=None)
@@ -228,7 +236,6 @@ def _respawn_one_rank_per_gpu(args):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool's host driver (RCCL needs it)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     sys.stderr.write("bench.py: no WORLD_SIZE in the environment, spawning " + " ".join(cmd[1:8]) + " ...\n")
@@ -236,9 +243,33 @@ def _respawn_one_rank_per_gpu(args):
     os.execv(sys.executable, cmd)
 
 
+def _first_collective_with_watchdog(dev, rank, world, groups, seconds):
+    """One all-reduce per process group right after the rendezvous, under a host-side watchdog: a rank that cannot reach its peers (IPC
+    handles, a dead peer, a wrong GPU mapping) makes the job FAIL within `seconds` with a message on stderr instead of hanging the launcher
+    until the driver's own timeout — torch.distributed.run then tears the other ranks down."""
+    import threading
+    done = threading.Event()
+
+    def dog():
+        if not done.wait(seconds):
+            sys.stderr.write(f"[rank {rank}] bench.py: the first RCCL collective did not complete within {seconds} s "
+                             f"(world {world}, HSA_ENABLE_IPC_MODE_LEGACY={os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY')}); aborting this rank\n")
+            sys.stderr.flush()
+            os._exit(3)
+    threading.Thread(target=dog, daemon=True).start()
+    for gname, g in groups:
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t, group=g)
+        torch.cuda.synchronize(dev)
+        if int(t.item()) != world:
+            raise RuntimeError(f"first all-reduce on the {gname} group returned {t.item()}, expected {world}")
+    done.set()
+
+
 def main():
     args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # XQ_FORCE_RESPAWN=1: take the self-spawn path at --gpus 1 too (tests/test_train_arena_gpu.py drives it on the 1-GPU box)
+    if (args.gpus > 1 or os.environ.get("XQ_FORCE_RESPAWN", "0") == "1") and "WORLD_SIZE" not in os.environ:
         _respawn_one_rank_per_gpu(args)
     CFG.update(CONFIGS[args.config])
     if args.batch == CONFIGS["VQ-8192"]["B"] and args.config != "VQ-8192":
@@ -264,13 +295,19 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # RCCL
+        import datetime
+        dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=int(os.environ.get("XQ_DIST_TIMEOUT", "600"))))  # RCCL
         disc_group = dist.new_group()                    # own communicator + stream for the discriminator heads
+        _first_collective_with_watchdog(dev, rank, world, [("default", None), ("discriminator", disc_group)],
+                                        int(os.environ.get("XQ_FIRST_COLLECTIVE_TIMEOUT", "180")))
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.backends.cuda.matmul.allow_tf32 = True  # xqgan_train.py:6-7 (no-op on gfx950: no TF32 path)
 
     from imagefolder_amd import _lib, nn_ops
     lib = _lib.lib()
+    # assert-no-library mode: a dense op of the bf16 step that drops to hipBLASLt / MIOpen / ATen raises instead of being timed
+    # (--allow-library turns it off; the fp32 flop-counting pass at the end runs on the library by design and switches it off itself)
+    nn_ops.STRICT_HIP = not args.allow_library
     B = args.batch
     g = torch.Generator(device=dev).manual_seed(1234 + rank)  # per-rank synthetic data (xqgan_train.py:189)
 
@@ -535,4 +572,13 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException:      # a failing rank must end the JOB: traceback with the rank on stderr, non-zero exit, no destructor that
+        import traceback       # could wait for peers (torch.distributed.run tears the other ranks down when one exits non-zero)
+        sys.stderr.write(f"[rank {os.environ.get('RANK', '0')}] bench.py failed:\n" + traceback.format_exc())
+        sys.stderr.flush()
+        sys.stdout.flush()
+        os._exit(1)

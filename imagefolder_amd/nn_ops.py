@@ -17,9 +17,22 @@ import torch.nn.functional as F
 IMPL = {}
 
 
+# assert-no-library mode (XQ_STRICT_HIP=1 in the environment, or nn_ops.STRICT_HIP = True; bench.py and tests/test_configs_gpu.py switch it
+# on for the bf16 train step): a dense op of the bf16-autocast GPU path that drops to a PyTorch-ROCm library op RAISES instead of being
+# recorded — a future shape outside a kernel's contract cannot silently put hipBLASLt / MIOpen / ATen into a number quoted as hand-written.
+# fp32 GPU training (ATen by design, not a configuration of the reference) and CPU tensors are not affected.
+STRICT_HIP = __import__("os").environ.get("XQ_STRICT_HIP", "0") == "1"
+
+
+class LibraryFallbackError(RuntimeError):
+    pass
+
+
 def _lib_ran(name, what):
     """a library fallback executed: say so (on the GPU only — CPU runs are the host mirror, not the product path)"""
     IMPL[name] = what
+    if STRICT_HIP and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        raise LibraryFallbackError(f"nn_ops.{name}: {what} — a library op inside the bf16 train step (XQ_STRICT_HIP / nn_ops.STRICT_HIP is on)")
 
 # ViT blocks as fused HIP row kernels + attention kernels + the hand-written GEMMs (ops_dense.run_blocks) instead of per-op ATen calls
 FUSED_BLOCKS = True

@@ -8,8 +8,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("name,batch", [("VQ-8192", 8), ("VQ-4096-cnn", 2), ("VP2-16384", 10), ("MSVR10P2-4096", 10), ("RobustTok", 10),
                                         ("MSBR10P2-4096", 10)])
-def test_one_full_train_step(name, batch):
+def test_one_full_train_step(name, batch, monkeypatch):
     import bench
+    from imagefolder_amd import nn_ops
+    # assert-no-library mode: every dense op of the bf16 step of EVERY config runs on a hand-written kernel, or this test fails loudly
+    monkeypatch.setattr(nn_ops, "STRICT_HIP", True)
 
     class A:
         pass

@@ -75,6 +75,32 @@ def test_bench_runs_its_rccl_branch_at_world_size_1():
     assert res["value"] > 0
 
 
+def test_bench_self_spawn_launcher_runs_on_the_gpu_box():
+    """`python bench.py --gpus N` without a launcher re-executes itself as `python -m torch.distributed.run --nproc-per-node N ...`
+    (bench._respawn_one_rank_per_gpu: the path the driver's `bench.py --gpus 8` line takes).  XQ_FORCE_RESPAWN=1 takes that execv at
+    --gpus 1, XQ_FORCE_DIST=1 makes the spawned rank bring up RCCL (both communicators, the first-collective watchdog) — so launcher,
+    rendezvous on 127.0.0.1, HSA_ENABLE_IPC_MODE_LEGACY and the JSON line of rank 0 are exercised end to end on the 1-GPU box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")}
+    env.update(XQ_FORCE_RESPAWN="1", XQ_FORCE_DIST="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--no-cpu-baseline", "--no-mfu"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "spawning -m torch.distributed.run" in out.stderr
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["allreduce"]["backend"] == "rccl" and res["allreduce"]["exposed_ms_per_step"] is not None
+    assert res["value"] > 0
+
+
+def test_bench_rank_failure_ends_the_job_with_the_ranks_traceback():
+    """a rank that raises must end the job: non-zero exit code, `[rank r] bench.py failed:` + traceback on stderr (an 8-GPU driver run
+    then fails loudly instead of hanging in a collective nobody joins)."""
+    env = dict(os.environ, XQ_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29543", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--batch", "8",
+                          "--no-cpu-baseline", "--no-mfu"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert "[rank 0] bench.py failed:" in out.stderr and "WORLD_SIZE=1" in out.stderr
+
+
 def test_bench_recovers_from_a_failed_hipgraph_capture():
     """bench.py --graph auto: when the capture of the train step fails half way, the process re-executes itself with --graph off
     (the invalidated capture state would otherwise kill the eager step that follows) and still prints its JSON line.
