@@ -98,23 +98,30 @@ def to_uint8_like_reference(x: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def reconstruct_for_fid(model, x: torch.Tensor, perturb=None, epoch: int = 0) -> torch.Tensor:
+def reconstruct_for_fid(model, x: torch.Tensor, perturb=None) -> torch.Tensor:
     """The reconstruction the FID is taken of.
       * rFID (perturb = None): `vq_model.img_to_reconstructed_img(x)`, the in-loop evaluation of xqgan_train.py:523-525;
       * pFID (RobustTok, BASELINE config 5 "pFID eval on"; README.md:57-59): perturb = (alpha, beta, delta) — the image decoded from
-        PERTURBED latents.  The reference has no separate evaluator for it: the perturbation lives in VQModel.forward
-        (xqgan_model.py:292-297: add_perturbation on the first int(B * beta) samples of the batch, beta = 1 perturbs every sample), so the
-        pFID reconstruction is `vq_model(x, epoch, alpha, beta, delta)[0]` in eval mode (no DropPath, no quantizer dropout), clamped to
-        [-1, 1] like img_to_reconstructed_img (:399).  Only single-quantizer models perturb (product_quant == 1, as upstream)."""
+        PERTURBED latents.  The reference has no evaluator for it: the perturbation lives in the P = 1 branch of VQModel.forward
+        (xqgan_model.py:292-297) and that forward cannot run in eval() mode upstream (VectorQuantizer.forward leaves `codebook_usage`
+        unbound outside train(), :773-801).  This is that branch composed from the reference's INFERENCE entry points, in eval mode (no
+        DropPath, no usage statistics):  h = encode(x);  z_q = quantize.f_to_idxBl_or_fhat(h, to_fhat=True)[0];
+        z_p = add_perturbation(h, z_q, z_channels, codebook_norm, embedding, alpha, beta, delta)  (the first int(B * beta) samples of the
+        batch are perturbed, latent_perturbation.py:32: beta = 1 perturbs every sample);  decode(z_p).clamp(-1, 1) as :399."""
     if perturb is None:
         return model.img_to_reconstructed_img(x)
+    from .latent_perturbation import add_perturbation
     alpha, beta, delta = perturb
-    if getattr(model, "product_quant", 1) != 1:
-        raise ValueError("pFID: VQModel.forward perturbs the latents of single-quantizer models only (xqgan_model.py:276-297)")
+    if getattr(model, "product_quant", 1) != 1 or len(getattr(model, "v_patch_nums", [16])) != 1:
+        raise ValueError("pFID: VQModel.forward perturbs the latents of single-quantizer, single-scale models only (xqgan_model.py:276-297)")
     was_training = model.training
     model.eval()
     try:
-        dec = model(x, epoch, alpha, beta, delta)[0]
+        q = model.quantize
+        h = model.encode(x)
+        zq = q.f_to_idxBl_or_fhat(h, to_fhat=True, v_patch_nums=None)[0]
+        zp = add_perturbation(h.float(), zq.float(), q.z_channels, q.codebook_norm, q.embedding, alpha, beta, delta)
+        dec = model.decode(zp)
     finally:
         model.train(was_training)
     return dec.float().clamp_(-1, 1)
@@ -143,9 +150,9 @@ class ReconstructionFID:
         return self
 
     @torch.no_grad()
-    def update_from_model(self, model, x: torch.Tensor, perturb=None, epoch: int = 0):
+    def update_from_model(self, model, x: torch.Tensor, perturb=None):
         """rFID (perturb = None) or pFID (perturb = (alpha, beta, delta)) of `model` on the batch x: see reconstruct_for_fid"""
-        return self.update(x, reconstruct_for_fid(model, x, perturb, epoch))
+        return self.update(x, reconstruct_for_fid(model, x, perturb))
 
     def compute(self, on_device: bool = False) -> float:
         self.ref.all_reduce(self.group)

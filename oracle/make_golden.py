@@ -525,6 +525,35 @@ def gen_vqloss(name, B, seed):
         g = params[n].grad
         out["gd:" + n] = grad_subsample(g).numpy().copy()
         out["gd:" + n + ":l2"] = np.float64(g.double().square().sum().sqrt())
+    # the reference's OWN reduced-precision pass (torch.autocast('cpu', bfloat16) around both half-steps, as xqgan_train.py:447,466 wraps them
+    # in torch.cuda.amp.autocast): the yardstick for the MI355X bf16 training kernels — how far bf16 moves these quantities is a property of
+    # the function (a randomly initialised discriminator behind kinks), measured here instead of assumed
+    Lb, _ = reference_vqloss(aug_prob=0.0)
+    Lb.load_state_dict(det_state_dict(Lb.state_dict(), seed))
+    pb = Lb.discriminator.dino_proxy[0]
+    pb.load_state_dict({k[len("dino_proxy."):]: v for k, v in det_state_dict({"dino_proxy." + k: v for k, v in pb.state_dict().items()}, seed).items()})
+    Lb.train()
+    Lb.perceptual_loss.eval()
+    pre_b = pre.detach().clone().requires_grad_(True)
+    last_b = torch.nn.Parameter(last0.clone())
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        rec_b = torch.nn.functional.conv2d(pre_b, last_b)
+        loss_b = Lb(cb, None, None, 0.0, imgs, rec_b, optimizer_idx=0, global_step=5, last_layer=last_b, logger=None, log_every=1000000)
+    loss_b.backward()
+    out["bf16:gen_loss"] = np.float64(loss_b.item())
+    out["bf16:g_pre_sub"] = grad_subsample(pre_b.grad.float()).numpy().copy()
+    out["bf16:g_last"] = last_b.grad.float().numpy().copy()
+    for p in Lb.discriminator.parameters():
+        p.grad = None
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        d_b = Lb(cb, None, None, 0.0, imgs, rec_b.detach(), optimizer_idx=1, global_step=5, logger=None, log_every=1000000)
+    d_b.backward()
+    out["bf16:disc_loss"] = np.float64(d_b.item())
+    pbn = dict(Lb.discriminator.named_parameters())
+    for n in head_names:
+        out["bf16:gd:" + n] = grad_subsample(pbn[n].grad.float()).numpy().copy()
+    print("reference bf16 autocast: gen_loss", loss_b.item(), "disc_loss", d_b.item(), "| d loss / d pre rel. distance to fp32:",
+          float(np.linalg.norm(out["bf16:g_pre_sub"] - out["g_pre_sub"]) / np.linalg.norm(out["g_pre_sub"])))
     # conditioning of the recorded gradient: the discriminator path has kinks (LeakyReLU heads behind batch statistics) — relative input
     # noise at the fp32 rounding level moves the REFERENCE's own d adv / d recons in jumps of ~0.15 %.  Recorded so that the tests' bounds
     # on that gradient (and on the adaptive weight that is a ratio of its norms) are derived from a measurement, not chosen.

@@ -152,7 +152,8 @@ KW_ROBUST = dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], e
 
 def test_pfid_of_perturbed_latents_equals_reference_cpu_path(monkeypatch):
     """pFID (BASELINE config 5, RobustTok: "pFID eval on"; README.md:57-59): the FID of images decoded from PERTURBED latents —
-    rfid.reconstruct_for_fid(model, x, (alpha, beta, delta)) = VQModel.forward(...)[0] in eval mode (xqgan_model.py:292-297).
+    rfid.reconstruct_for_fid(model, x, (alpha, beta, delta)) = the P = 1 branch of VQModel.forward (xqgan_model.py:292-297) composed from the
+    inference entry points (the reference's forward itself cannot run in eval mode, :773-801).
     Reference CPU path = host mirror encoder / decoder + the C oracle's nearest code AND its add_perturbation restatement
     (latent_perturbation.py:4-35, pinned to the reference by the perturb_* goldens), both sides on the same rank draws
     (latent_perturbation.py:21-23 drawn once on the host and handed to both).  RobustTok's geometry (V = 4096, C = 64, l2-normed codes),
@@ -185,7 +186,7 @@ def test_pfid_of_perturbed_latents_equals_reference_cpu_path(monkeypatch):
             ridx = torch.randint(0, delta, (n_tok,), generator=g)                            # :22
             cur["rank"] = torch.where(prob > alpha, torch.zeros_like(ridx), ridx)            # :23
             idx, _ = xq_oracle.assign(f.numpy(), E, xq_oracle.MODE_L2_NORMED)
-            zq, _, _ = xq_oracle.vq_finish(f.numpy(), E, idx, normed=True, ste=True, want_hist=False)
+            zq, _, _ = xq_oracle.vq_finish(f.numpy(), E, idx, normed=True, ste=False, want_hist=False)
             zp, sel = xq_oracle.perturb_forward(f.numpy(), zq, E, True, int(bs * beta), cur["rank"].numpy())
             changed += int((sel != idx[:sel.size]).sum())
             rec_cpu = m_cpu.decode(torch.from_numpy(zp)).clamp_(-1, 1)

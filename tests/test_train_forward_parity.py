@@ -72,7 +72,8 @@ def test_train_mode_forward_matches_reference(name, monkeypatch):
     frac = float(np.mean(np.abs(diff) <= 1e-4))
     print(f"{name}: pixels within 1e-4: {100 * frac:.2f} %, max |diff| {np.abs(diff).max():.2e}; vq {float(vq):.6f} / {float(g['vq']):.6f}; "
           f"sem {float(sem):.6f} / {float(g['sem']):.6f}; usages {usages[:3]} / {g['usages'][:3]}")
-    assert frac >= 0.97, f"only {100 * frac:.1f} % of the pixels within 1e-4 (max {np.abs(diff).max():.3e})"
+    # measured (profiles/r04_parity_measured.txt): 100.00 % of the pixels within 1e-4 on all four configs, max |diff| 5.6e-6 .. 7.6e-6
+    assert frac >= 0.9999, f"only {100 * frac:.2f} % of the pixels within 1e-4 (max {np.abs(diff).max():.3e})"
     np.testing.assert_allclose(float(vq), float(g["vq"]), rtol=2e-3)
     np.testing.assert_allclose(float(commit), float(g["commit"]), rtol=2e-3)
     np.testing.assert_allclose(float(sem), float(g["sem"]), rtol=2e-3, atol=1e-5)

@@ -120,8 +120,32 @@ def test_vqloss_hip_fp32_equals_reference_golden():
 
 
 @pytest.mark.gpu
-def test_vqloss_hip_bf16_autocast_close_to_reference_golden():
-    """the training configuration (bf16 autocast: VGG trunk, DINO trunk and head GEMMs in bf16): losses to 2 %, gradients to 8 % relative L2
-    (the reference's own bf16-autocast backward sits at 1 - 4 % of its fp32 gradient on the tokenizer, profiles/r03_gradient_parity.txt)"""
+def test_vqloss_hip_bf16_autocast_no_further_from_fp32_than_the_reference_bf16_pass():
+    """the training configuration (bf16 autocast: VGG trunk, DINO trunk and head GEMMs in bf16).  A bf16 result cannot meet the fp32 bounds,
+    and how far bf16 moves these quantities is a property of the function — the adversarial gradient through a randomly initialised
+    discriminator behind LeakyReLU / hinge kinks moves by tens of per cent.  So the bound is DERIVED: the golden also holds what the
+    unmodified reference produces under torch.autocast('cpu', bfloat16) (oracle/make_golden.py gen_vqloss), and the MI355X bf16 path must
+    be at most 1.5x as far from the reference's fp32 result as the reference's own bf16 pass is (+ a small absolute floor)."""
     g, res = _run(torch.device("cuda"), True)
-    _compare(g, res, 2e-2, 8e-2, 8e-2, 8e-2)
+
+    def rel(got, ref):
+        return float((got - ref).norm() / ref.norm())
+    checks = []
+    ref32 = torch.from_numpy(g["g_pre_sub"])
+    checks.append(("d loss / d pre", rel(_sub(res["g_pre"]), ref32), rel(torch.from_numpy(g["bf16:g_pre_sub"]), ref32)))
+    ref32 = torch.from_numpy(g["g_last"])
+    checks.append(("d loss / d last_layer", rel(res["g_last"], ref32), rel(torch.from_numpy(g["bf16:g_last"]), ref32)))
+    for n in (str(x) for x in g["head_names"]):
+        ref32 = torch.from_numpy(g["gd:" + n])
+        if float(g[f"gd:{n}:l2"]) < 1e-6:      # conv biases in front of a batch norm: exactly-zero gradients
+            continue
+        checks.append((n, rel(_sub(res["gd"][n]), ref32), rel(torch.from_numpy(g["bf16:gd:" + n]), ref32)))
+    scale = max(abs(float(g["rec_loss"])), abs(float(g["gen_loss"])))
+    ours, theirs = abs(res["gen_loss"] - float(g["gen_loss"])) / scale, abs(float(g["bf16:gen_loss"]) - float(g["gen_loss"])) / scale
+    checks.append(("generator loss", ours, theirs))
+    ours = abs(res["disc_loss"] - float(g["disc_loss"])) / abs(float(g["disc_loss"]))
+    theirs = abs(float(g["bf16:disc_loss"]) - float(g["disc_loss"])) / abs(float(g["disc_loss"]))
+    checks.append(("discriminator loss", ours, theirs))
+    print("\n".join(f"{n:40s} MI355X bf16 {a:.3e}   reference bf16 {b:.3e}" for n, a, b in checks))
+    bad = [(n, a, b) for n, a, b in checks if a > 1.5 * b + 5e-3]
+    assert not bad, bad
