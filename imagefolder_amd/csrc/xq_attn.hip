@@ -23,8 +23,6 @@
 #include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
 
-#include <cstdlib>
-
 using namespace xq;
 
 typedef short bf16x8 __attribute__((ext_vector_type(8)));
@@ -252,339 +250,6 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const short *__restric
             *reinterpret_cast<uint2 *>(op + 32 + 8 * r4) = w1;
         }
         if (hh == 0) lse[((long)b * H + h) * N + qn] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// forward with K and V RESIDENT in LDS (round 4; N <= ~600: 2 x 544 rows x 128 B = 136 KiB of the CU's 160 KiB).
-// One workgroup of 8 waves per (batch, head).  The tiled kernel above re-stages K / V once per 128-query block through registers with a
-// barrier per 64-key tile and is bound by that hand-off (waves parked 43 % of their cycles, matrix pipe 27 % busy,
-// profiles/r03_attn_pmc_sq.txt); here K / V of the (batch, head) arrive ONCE by LDS-DMA (global_load_lds_dwordx4, XOR-swizzled on the
-// source address), a wave keeps TWO 32-query groups (64 queries) so that one group's softmax VALU work sits next to the other group's
-// MFMAs and every K / V fragment read from LDS serves both, and after the first few tiles (counted vmcnt + barrier while the stream is
-// still landing) the waves run without any synchronisation.  A trailing group of <= 4 queries (the class token: N = 512 + 1) is cut
-// along the KEYS over the 8 waves and merged through LDS instead of costing one wave a second full pass.
-//   LDS image: K row R (128 B): 16-byte chunk c at position c ^ ((R >> 1) & 7)      (conflict-free ds_read_b128, one key per lane)
-//              V row R (128 B): 16-byte chunk c at position c ^ (4 * ((R >> 1) & 1)) (conflict-free ds_read_b64_tr_b16)
-//              rows N .. NR-1 are zero (DMA from a zero page): P = 0 there must multiply finite V
-// ---------------------------------------------------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void at_lds_void;
-typedef __attribute__((address_space(1))) void at_gbl_void;
-__device__ __attribute__((aligned(64))) char attn_zero_page[64];
-
-#define AT_VMC(N_) case N_: asm volatile("s_waitcnt vmcnt(" #N_ ")" ::: "memory"); break;
-__device__ __forceinline__ void at_wait_vmcnt(int n) {      // n wave-uniform
-    switch (n) {
-        AT_VMC(0) AT_VMC(1) AT_VMC(2) AT_VMC(3) AT_VMC(4) AT_VMC(5) AT_VMC(6) AT_VMC(7) AT_VMC(8) AT_VMC(9) AT_VMC(10) AT_VMC(11) AT_VMC(12)
-        AT_VMC(13) AT_VMC(14) AT_VMC(15) AT_VMC(16) AT_VMC(17) AT_VMC(18) AT_VMC(19) AT_VMC(20)
-        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    }
-}
-#undef AT_VMC
-
-struct AtFwdGroup {
-    bf16x8 q0, q1, q2, q3;      // Q of this lane's query: the 8 head-dim entries 16 k + 8 hh + 0..7, k = 0..3
-    f32x16 o0, o1;              // O^T, head-dim rows 0..31 / 32..63 (register r <-> row (r & 3) + 8 (r >> 2) + 4 hh)
-    float m, l;                 // running reference exponent (log2 units), this lane half's partial row sum
-};
-
-// one 64-key tile (LDS rows kv0 .. kv0 + 63 at Kt / Vt) against NG query groups
-template <int NG>
-__device__ __forceinline__ void at_fwd_res_tile(const char *Kt, const char *Vt, const unsigned (&ko)[4], unsigned vo0, unsigned vo1, int kv0, int N,
-                                                float c, int hh, AtFwdGroup (&st)[NG]) {
-    const bool wide = kv0 + 32 < N;      // the second 32 keys of the tile hold at least one real key
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    bf16x8 ka[4], kb[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ka[k] = *reinterpret_cast<const bf16x8 *>(Kt + ko[k]);
-    if (wide) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) kb[k] = *reinterpret_cast<const bf16x8 *>(Kt + 4096 + ko[k]);
-    }
-    f32x16 s0[NG], s1[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        s0[g] = AT_MFMA(ka[0], st[g].q0, zero16);
-        s0[g] = AT_MFMA(ka[1], st[g].q1, s0[g]);
-        s0[g] = AT_MFMA(ka[2], st[g].q2, s0[g]);
-        s0[g] = AT_MFMA(ka[3], st[g].q3, s0[g]);
-        if (wide) {
-            s1[g] = AT_MFMA(kb[0], st[g].q0, zero16);
-            s1[g] = AT_MFMA(kb[1], st[g].q1, s1[g]);
-            s1[g] = AT_MFMA(kb[2], st[g].q2, s1[g]);
-            s1[g] = AT_MFMA(kb[3], st[g].q3, s1[g]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s1[g][r] = -INFINITY;
-        }
-    }
-    // V^T fragments of the tile: rows d (lane), key slots {4hh..4hh+3, 8+4hh..} of each 16-key step — the order P's registers hold.
-    // Read through inline asm: for the ds_read_tr INTRINSIC hipcc (ROCm 7.2) assumes an alias with the LDS-DMA still in flight and puts
-    // `s_waitcnt vmcnt(0)` in front of it — every tile of the first pass would drain the K / V stream (the same wait is what made the
-    // "interleaved" GEMM variant of round 3 lose 20-55 % on its transpose-read operands).  The tile's rows HAVE landed (counted vmcnt +
-    // barrier in the caller); the reads are waited for by the lgkmcnt(0) below, which carries the fragments as operands so that no MFMA
-    // using them can be scheduled above it.
-    bf16x4 vl0[4], vh0[4], vl1[4], vh1[4];
-    {
-        const unsigned va0 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char *)(Vt) + vo0;
-        const unsigned va1 = (unsigned)(unsigned long)(__attribute__((address_space(3))) const char *)(Vt) + vo1;
-#define AT_TRR(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:" #OFF : "=v"(DST) : "v"(ADDR))
-        AT_TRR(vl0[0], va0, 0);    AT_TRR(vh0[0], va0, 1024); AT_TRR(vl1[0], va1, 0);    AT_TRR(vh1[0], va1, 1024);
-        AT_TRR(vl0[1], va0, 2048); AT_TRR(vh0[1], va0, 3072); AT_TRR(vl1[1], va1, 2048); AT_TRR(vh1[1], va1, 3072);
-        if (wide) {
-            AT_TRR(vl0[2], va0, 4096); AT_TRR(vh0[2], va0, 5120); AT_TRR(vl1[2], va1, 4096); AT_TRR(vh1[2], va1, 5120);
-            AT_TRR(vl0[3], va0, 6144); AT_TRR(vh0[3], va0, 7168); AT_TRR(vl1[3], va1, 6144); AT_TRR(vh1[3], va1, 7168);
-        } else {
-#pragma unroll
-            for (int j = 2; j < 4; ++j) { vl0[j] = bf16x4{0, 0, 0, 0}; vh0[j] = vl0[j]; vl1[j] = vl0[j]; vh1[j] = vl0[j]; }
-        }
-#undef AT_TRR
-    }
-    bool v_waited = false;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        if (kv0 + 64 > N) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (key >= N) s0[g][r] = -INFINITY;
-                if (key + 32 >= N) s1[g][r] = -INFINITY;
-            }
-        }
-        float mx = max3(s0[g][0], s0[g][1], s0[g][2]);
-        mx = max3(mx, s0[g][3], s0[g][4]);
-        mx = max3(mx, s0[g][5], s0[g][6]);
-        mx = max3(mx, s0[g][7], s0[g][8]);
-        mx = max3(mx, s0[g][9], s0[g][10]);
-        mx = max3(mx, s0[g][11], s0[g][12]);
-        mx = max3(mx, s0[g][13], s0[g][14]);
-        mx = max3(mx, s0[g][15], s1[g][0]);
-        mx = max3(mx, s1[g][1], s1[g][2]);
-        mx = max3(mx, s1[g][3], s1[g][4]);
-        mx = max3(mx, s1[g][5], s1[g][6]);
-        mx = max3(mx, s1[g][7], s1[g][8]);
-        mx = max3(mx, s1[g][9], s1[g][10]);
-        mx = max3(mx, s1[g][11], s1[g][12]);
-        mx = max3(mx, s1[g][13], s1[g][14]);
-        mx = max3(mx, s1[g][15], s1[g][15]);
-        mx = max3(mx, __shfl_xor(mx, 32), mx);
-        const float cand = mx * c;
-        if (__any(cand > st[g].m + 8.0f)) {      // lazy rescale (see attn_fwd_kernel)
-            const float mn = fmaxf(st[g].m, cand);
-            const float alpha = __builtin_amdgcn_exp2f(st[g].m - mn);
-            st[g].m = mn;
-            st[g].l *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { st[g].o0[r] *= alpha; st[g].o1[r] *= alpha; }
-        }
-        const float mr = st[g].m;
-        fv2 acc2 = {0.f, 0.f};
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            s0[g][r] = __builtin_amdgcn_exp2f(fmaf(s0[g][r], c, -mr));
-            s0[g][r + 1] = __builtin_amdgcn_exp2f(fmaf(s0[g][r + 1], c, -mr));
-            acc2 += fv2{s0[g][r], s0[g][r + 1]};
-        }
-        const bf16x8 p00 = pack8(s0[g][0], s0[g][1], s0[g][2], s0[g][3], s0[g][4], s0[g][5], s0[g][6], s0[g][7]);
-        const bf16x8 p01 = pack8(s0[g][8], s0[g][9], s0[g][10], s0[g][11], s0[g][12], s0[g][13], s0[g][14], s0[g][15]);
-        if (!v_waited) {      // (compile-time after unrolling: the first group's products)
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(vl0[0]), "+v"(vh0[0]), "+v"(vl1[0]), "+v"(vh1[0]), "+v"(vl0[1]), "+v"(vh0[1]), "+v"(vl1[1]), "+v"(vh1[1]),
-                           "+v"(vl0[2]), "+v"(vh0[2]), "+v"(vl1[2]), "+v"(vh1[2]), "+v"(vl0[3]), "+v"(vh0[3]), "+v"(vl1[3]), "+v"(vh1[3]));
-            v_waited = true;
-        }
-        st[g].o0 = AT_MFMA(cat4(vl0[0], vh0[0]), p00, st[g].o0);
-        st[g].o1 = AT_MFMA(cat4(vl1[0], vh1[0]), p00, st[g].o1);
-        st[g].o0 = AT_MFMA(cat4(vl0[1], vh0[1]), p01, st[g].o0);
-        st[g].o1 = AT_MFMA(cat4(vl1[1], vh1[1]), p01, st[g].o1);
-        if (wide) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                s1[g][r] = __builtin_amdgcn_exp2f(fmaf(s1[g][r], c, -mr));
-                s1[g][r + 1] = __builtin_amdgcn_exp2f(fmaf(s1[g][r + 1], c, -mr));
-                acc2 += fv2{s1[g][r], s1[g][r + 1]};
-            }
-            const bf16x8 p10 = pack8(s1[g][0], s1[g][1], s1[g][2], s1[g][3], s1[g][4], s1[g][5], s1[g][6], s1[g][7]);
-            const bf16x8 p11 = pack8(s1[g][8], s1[g][9], s1[g][10], s1[g][11], s1[g][12], s1[g][13], s1[g][14], s1[g][15]);
-            st[g].o0 = AT_MFMA(cat4(vl0[2], vh0[2]), p10, st[g].o0);
-            st[g].o1 = AT_MFMA(cat4(vl1[2], vh1[2]), p10, st[g].o1);
-            st[g].o0 = AT_MFMA(cat4(vl0[3], vh0[3]), p11, st[g].o0);
-            st[g].o1 = AT_MFMA(cat4(vl1[3], vh1[3]), p11, st[g].o1);
-        }
-        st[g].l += acc2.x + acc2.y;      // this lane half's keys; the two halves are added once, at the end
-    }
-}
-
-__device__ __forceinline__ void at_load_q(AtFwdGroup &g, const short *base, long RS, int qc, int hh) {
-    const short *qp = base + (long)qc * RS + 8 * hh;
-    g.q0 = *reinterpret_cast<const bf16x8 *>(qp);
-    g.q1 = *reinterpret_cast<const bf16x8 *>(qp + 16);
-    g.q2 = *reinterpret_cast<const bf16x8 *>(qp + 32);
-    g.q3 = *reinterpret_cast<const bf16x8 *>(qp + 48);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { g.o0[r] = 0.0f; g.o1[r] = 0.0f; }
-    g.m = -INFINITY;
-    g.l = 0.0f;
-}
-
-__device__ __forceinline__ void at_store_o(const AtFwdGroup &g, float l_total, short *out, float *lse, int b, int h, int H, int N, int qn, int hh) {
-    const float inv = 1.0f / l_total;
-    short *op = out + ((long)b * N + qn) * (H * 64) + h * 64 + 4 * hh;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        uint2 w0 = make_uint2(pack_bf16(g.o0[4 * r4] * inv, g.o0[4 * r4 + 1] * inv), pack_bf16(g.o0[4 * r4 + 2] * inv, g.o0[4 * r4 + 3] * inv));
-        uint2 w1 = make_uint2(pack_bf16(g.o1[4 * r4] * inv, g.o1[4 * r4 + 1] * inv), pack_bf16(g.o1[4 * r4 + 2] * inv, g.o1[4 * r4 + 3] * inv));
-        *reinterpret_cast<uint2 *>(op + 8 * r4) = w0;
-        *reinterpret_cast<uint2 *>(op + 32 + 8 * r4) = w1;
-    }
-    if (hh == 0) lse[((long)b * H + h) * N + qn] = (g.m + __builtin_amdgcn_logf(l_total)) * 0.6931471805599453f;
-}
-
-// npf: 64-query pairs processed whole (pair p by wave p % 8); tail_r: 1..4 trailing queries (starting at 64 * npf) cut along the keys, or 0
-__global__ __launch_bounds__(512, 2) void attn_fwd_res_kernel(const short *__restrict__ qkv, int B, int N, int H, float c, short *__restrict__ out,
-                                                           float *__restrict__ lse, int NR, int npf, int tail_r) {
-    extern __shared__ __attribute__((aligned(16))) char at_smem[];      // K [NR][128 B] | V [NR][128 B] | merge [8][4][66] fp32
-    char *const Ks = at_smem, *const Vs = at_smem + (size_t)NR * 128;
-    float *const mg = reinterpret_cast<float *>(at_smem + (size_t)NR * 256);
-    const int g = blockIdx.x;
-    const int b = g / H, h = g - b * H;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, hh = lane >> 5;
-    const long RS = 3L * H * 64;
-    const short *base = qkv + (long)b * N * RS + h * 64;
-    const short *kbase = base + H * 64, *vbase = base + 2 * H * 64;
-    const int ntiles = (N + 63) / 64;
-
-    // per-lane LDS offsets of the fragment reads (see the layout above)
-    unsigned ko[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ko[k] = (unsigned)(li * 128 + (((2 * k + hh) ^ ((li >> 1) & 7)) << 4));
-    const int rr = 4 * hh + ((lane & 15) >> 2), colb = 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-    const unsigned vo0 = (unsigned)(rr * 128 + (((colb >> 3) ^ (4 * ((rr >> 1) & 1))) << 4) + (colb & 7) * 2), vo1 = vo0 ^ 64u;
-
-    // LDS-DMA of the K / V rows [8 i, 8 i + 8) by one wave instruction each; wave w stages instruction 8 t + w of every tile t
-    const int drow = lane >> 3, dcp = lane & 7;
-    auto stage = [&](int t) -> int {
-        const int row0 = 64 * t + 8 * wave;
-        if (row0 >= NR) return 0;
-        const int R = row0 + drow;
-        const bool ok = R < N;
-        const int ck = dcp ^ ((R >> 1) & 7), cv = dcp ^ (4 * ((R >> 1) & 1));
-        const char *sk = ok ? reinterpret_cast<const char *>(kbase + (long)R * RS + 8 * ck) : attn_zero_page;
-        const char *sv = ok ? reinterpret_cast<const char *>(vbase + (long)R * RS + 8 * cv) : attn_zero_page;
-        __builtin_amdgcn_global_load_lds((at_gbl_void *)sk, (at_lds_void *)(Ks + row0 * 128), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((at_gbl_void *)sv, (at_lds_void *)(Vs + row0 * 128), 16, 0, 0);
-        return 2;
-    };
-
-    AtFwdGroup st[2];
-    // tiles 0 and 1 first, then this wave's first Q fragments (ordinary loads: they return behind the DMA issued before them), one wait for
-    // both — hipcc drains the whole VM queue at the first use of an ordinary load's result, so nothing else may be in flight at that point
-    stage(0);
-    if (ntiles > 1) stage(1);
-    const int q_first = 64 * wave;
-    {
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int qn = q_first + 32 * gi + li;
-            at_load_q(st[gi], base, RS, qn < N ? qn : N - 1, hh);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int gi = 0; gi < 2; ++gi) asm volatile("" : "+v"(st[gi].q0), "+v"(st[gi].q1), "+v"(st[gi].q2), "+v"(st[gi].q3));
-    }
-    int in_flight = 0;
-    for (int t = 2; t < ntiles; ++t) in_flight += stage(t);
-    in_flight = __builtin_amdgcn_readfirstlane(in_flight);
-
-    // ---- whole pairs ------------------------------------------------------------------------------------------------------
-    constexpr int SYNC_TILES = 6;      // tiles waited for one by one (counted vmcnt + barrier); at tile SYNC_TILES the rest is drained
-    bool first_pass = true;
-    for (int p = wave; first_pass || p < npf; p += 8) {
-        const bool live = p < npf;
-        if (live && !first_pass) {
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const int qn = 64 * p + 32 * gi + li;
-                at_load_q(st[gi], base, RS, qn < N ? qn : N - 1, hh);
-            }
-            // waited for HERE, not at the first use inside the tile loop: a load pending on ANY path into that loop makes hipcc put a
-            // vmcnt(0) in front of the first MFMA of every tile — which, in the first pass, would drain the K / V stream at tile 0
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) asm volatile("" : "+v"(st[gi].q0), "+v"(st[gi].q1), "+v"(st[gi].q2), "+v"(st[gi].q3));
-        }
-        for (int t = 0; t < ntiles; ++t) {
-            if (first_pass) {      // every wave takes part, with or without a pair of its own
-                if (t < 2) {
-                    __builtin_amdgcn_s_barrier();
-                } else if (t < SYNC_TILES) {
-                    int left = in_flight - 2 * (t - 1);      // this wave's DMA instructions of tiles > t
-                    at_wait_vmcnt(left < 0 ? 0 : left);
-                    __builtin_amdgcn_s_barrier();
-                } else if (t == SYNC_TILES) {
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_s_barrier();
-                }
-            }
-            if (live) at_fwd_res_tile<2>(Ks + t * 8192, Vs + t * 8192, ko, vo0, vo1, 64 * t, N, c, hh, st);
-        }
-        if (first_pass && ntiles <= SYNC_TILES) {      // short sequences: everything has been waited for tile by tile except the drain
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (live) {
-#pragma unroll
-            for (int gi = 0; gi < 2; ++gi) {
-                const int qn = 64 * p + 32 * gi + li;
-                const float lt = st[gi].l + __shfl_xor(st[gi].l, 32);
-                if (qn < N && (tail_r == 0 || qn < 64 * npf)) at_store_o(st[gi], lt, out, lse, b, h, H, N, qn, hh);
-            }
-        }
-        first_pass = false;
-    }
-
-    // ---- trailing queries, cut along the keys: wave w takes tiles w, w + 8, ... ----------------------------------------------------------
-    if (tail_r > 0) {
-        AtFwdGroup tg[1];
-        const int q0 = 64 * npf;
-        const int qn = q0 + li;
-        at_load_q(tg[0], base, RS, qn < N ? qn : N - 1, hh);
-        for (int t = wave; t < ntiles; t += 8) at_fwd_res_tile<1>(Ks + t * 8192, Vs + t * 8192, ko, vo0, vo1, 64 * t, N, c, hh, tg);
-        const float lw = tg[0].l + __shfl_xor(tg[0].l, 32);
-        if (li < tail_r) {      // partial (m, l, O^T column) of query li from this wave's keys
-            float *rec = mg + ((wave * 4 + li) * 66);
-            if (hh == 0) { rec[0] = tg[0].m; rec[1] = lw; }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                rec[2 + d] = tg[0].o0[r];
-                rec[2 + 32 + d] = tg[0].o1[r];
-            }
-        }
-        __syncthreads();
-        if (wave == 0 && li < tail_r) {
-            float M = -INFINITY;
-            for (int w = 0; w < 8; ++w) M = fmaxf(M, mg[(w * 4 + li) * 66]);
-            float L = 0.0f;
-            f32x16 a0, a1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { a0[r] = 0.0f; a1[r] = 0.0f; }
-            for (int w = 0; w < 8; ++w) {
-                const float *rec = mg + (w * 4 + li) * 66;
-                const float sc = __builtin_amdgcn_exp2f(rec[0] - M);      // waves without a tile: m = -inf -> 0
-                L = fmaf(rec[1], sc, L);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int d = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    a0[r] = fmaf(rec[2 + d], sc, a0[r]);
-                    a1[r] = fmaf(rec[2 + 32 + d], sc, a1[r]);
-                }
-            }
-            AtFwdGroup fin;
-            fin.o0 = a0; fin.o1 = a1; fin.m = M; fin.l = L;
-            at_store_o(fin, L, out, lse, b, h, H, N, qn, hh);
-        }
     }
 }
 
@@ -897,26 +562,8 @@ extern "C" int xq_attn_forward(const void *qkv, int B, int N, int H, int head_di
     if (!qkv || !out || !lse) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     const int nqb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
     const int pslot = prof_begin(XQ_PROF_ATTN_FWD, 4.0 * B * H * (double)N * N * 64.0, (hipStream_t)stream);
-    // K / V resident in LDS where the sequence fits (rows rounded up to 32: the last 64-key tile reads at most its first half there)
-    const int NR = (N + 31) / 32 * 32;
-    const size_t res_lds = (size_t)NR * 256 + 8 * 4 * 66 * sizeof(float);
-    static const bool tiled_only = [] { const char *e = getenv("XQ_ATTN_TILED"); return e && e[0] == '1'; }();
-    if (N >= 192 && res_lds <= 160 * 1024 && !tiled_only) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(attn_fwd_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-            attr_done = true;
-        }
-        const int full = N / 64, rem = N % 64;
-        const bool split_tail = rem >= 1 && rem <= 4 && full >= 1;
-        const int npf = split_tail ? full : (N + 63) / 64, tail_r = split_tail ? rem : 0;
-        hipLaunchKernelGGL(attn_fwd_res_kernel, dim3((unsigned)(B * H)), dim3(512), res_lds, (hipStream_t)stream, (const short *)qkv, B, N, H,
-                           scale * 1.4426950408889634f, (short *)out, lse, NR, npf, tail_r);
-    } else {
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(G8 * nqb)), dim3(256), 0, (hipStream_t)stream, (const short *)qkv, B, N, H,
-                           scale * 1.4426950408889634f, (short *)out, lse, nqb);
-    }
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)(G8 * nqb)), dim3(256), 0, (hipStream_t)stream, (const short *)qkv, B, N, H,
+                       scale * 1.4426950408889634f, (short *)out, lse, nqb);
     prof_end(pslot, (hipStream_t)stream);
     return xq_check_launch(fn);
 }
