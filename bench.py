@@ -517,14 +517,15 @@ def main():
         # passes, gfx950 read correction applied: tools/pmc_traffic.py); null when that profile does not cover the kernel
         traffic = {}
         try:
-            tf = os.path.join(ROOT, "profiles", "r02_kernel_hbm_traffic.json")
-            if not os.path.exists(tf):
-                tf = os.path.join(ROOT, "profiles", "r01_kernel_hbm_traffic.json")
+            tf = os.path.join(ROOT, "profiles", "r04_kernel_hbm_traffic.json")       # PMC passes over THIS round's kernels
             with open(tf) as fh:
                 traffic = json.load(fh).get("kernels", {})
             traffic_src = os.path.relpath(tf, ROOT)
-        except (OSError, ValueError):
-            pass
+            with open(os.path.join(ROOT, "profiles", "r04_kernel_hbm_traffic_shapes.json")) as fh:
+                shape_ratio = {c["case"]: round(c["traffic_over_algorithmic"], 3) for c in json.load(fh).get("cases", [])
+                               if "traffic_over_algorithmic" in c}
+        except (OSError, ValueError, KeyError):
+            shape_ratio = {}
         if full and CFG["name"] == "VQ-8192" and B == 128:   # the profile was taken on this workload
             for e in entries:
                 keys = (["conv3x3"] if e["kernel"].startswith("conv3x3") else ["attn_fwd"] if e["kernel"].startswith("attn_fwd")
@@ -534,8 +535,9 @@ def main():
                     e["traffic"] = sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)
                     e["traffic_source"] = traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, average bytes per launch; per-shape rows in the file)"
                     e["traffic_note"] = ("fabric-side bytes: requests the eight L2s sent to the Infinity Fabric (they include Infinity-Cache hits) — an "
-                                         "UPPER bound on HBM bytes, MI355X_MICROARCH.md §HBM; collected on the round-2 kernels: the round-3 schedule "
-                                         "change (two phases per K tile) walks the same tiles in the same order")
+                                         "UPPER bound on HBM bytes, MI355X_MICROARCH.md §HBM; collected on this round's kernels")
+                    pre = "gemm" if keys == ["gemm"] else "attention" if keys[0].startswith("attn") else "conv3x3" if keys == ["conv3x3"] else "assign"
+                    e["traffic_over_algorithmic_by_shape"] = {k: v for k, v in shape_ratio.items() if k.startswith(pre)}
         entries.sort(key=lambda e: -e["ms_per_step"])
         out["roofline"] = dict(entries[0], note="kernel family with the most GPU time in the timed region (every MFMA kernel of "
                                                 "the step is hand-written and instrumented: HIP events on its launch stream); "
