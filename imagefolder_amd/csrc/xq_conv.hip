@@ -19,6 +19,7 @@
 #include "../../include/xq_ops.h"
 
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 #include "xq_vec.hpp"
 
 using namespace xq;
@@ -209,6 +210,133 @@ extern "C" int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int fo
     return xq_check_launch("pack_conv3x3_weights_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 64 -> 64 channels (conv1_2 of the LPIPS VGG16 trunk at 256^2 x 128 images, forward and data gradient: 4.3 GB of activations per
+// call against 0.6 TFLOP — the layer is HBM-bound on paper, 0.45 ms at 5 TB/s, and took 1.47 ms on the 128-pixel kernel above, which
+// re-gathers every input pixel nine times through registers with a barrier per 32-deep K step).  Round 4:
+//   * the whole weight matrix [9 taps][64 cout][64 cin] bf16 = 72 KiB stays in LDS for the life of a persistent workgroup (one per CU);
+//   * an output tile is 8 rows x 32 pixels; its 10 x 34 input halo arrives ONCE by LDS-DMA (global_load_lds_dwordx4, out-of-image
+//     pixels from a zero page) as 128-byte pixel slots, and all nine taps read their A fragments from it at shifted slot indices;
+//     two halo buffers: the next tile's halo lands while this tile is computed (first version, one 16 x 32 tile, load and compute
+//     in turn: 0.88 ms per call; profiles/r04_conv_c64.txt);
+//   * 8 waves, wave w owns output row w: per tap 4 A + 8 B fragment reads feed 8 MFMAs; ONE barrier per tile.
+// LDS rows of 128 B (weights: row = tap * 64 + cout; halo: row = slot = r * 34 + c): 16-byte chunk c sits at position
+// c ^ ((row >> 1) & 7), applied to the DMA's source address and on the reads — conflict-free ds_read_b128 for 32 consecutive rows at
+// any even or odd base (the shifted taps).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void cv_lds_void;
+typedef __attribute__((address_space(1))) void cv_gbl_void;
+__device__ __attribute__((aligned(64))) char cv_zero_page[64];
+
+static constexpr int C64_TH = 8, C64_TW = 32, C64_HW = C64_TW + 2, C64_SLOTS = (C64_TH + 2) * (C64_TW + 2);     // 340 halo slots
+static constexpr int C64_W_BYTES = 9 * 64 * 128, C64_H_INSTR = (C64_SLOTS + 7) / 8, C64_H_BYTES = C64_H_INSTR * 1024;
+static constexpr int C64_LDS = C64_W_BYTES + 2 * C64_H_BYTES;      // 72 KiB + 2 x 43 KiB = 158 KiB of the CU's 160
+
+template <bool RELU>
+__global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const char *__restrict__ X, const char *__restrict__ Wp, const float *__restrict__ bias,
+                                                          int H, int Wd, char *__restrict__ Y, int tiles_y, int tiles_x, long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char c64_smem[];
+    char *const Wl = c64_smem, *const Hl0 = c64_smem + C64_W_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, hh = lane >> 5;
+    const int drow = lane >> 3, dcp = lane & 7;
+
+    // weights -> LDS, once: wave-instruction i moves LDS rows 8 i .. 8 i + 7
+    for (int i = wave; i < 72; i += 8) {
+        const int r = 8 * i + drow;
+        const int c = dcp ^ ((r >> 1) & 7);
+        const char *src = Wp + ((long)(r & 63) * 576 + (r >> 6) * 64 + 8 * c) * 2;
+        __builtin_amdgcn_global_load_lds((cv_gbl_void *)src, (cv_lds_void *)(Wl + i * 1024), 16, 0, 0);
+    }
+    // B fragment offsets (row = 32 cg + li inside a tap: (row >> 1) & 7 = (li >> 1) & 7)
+    unsigned bo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) bo[k] = (unsigned)(li * 128 + (((2 * k + hh) ^ ((li >> 1) & 7)) << 4));
+    // this lane's 32 bias values: couts 32 cg + 8 q + 4 hh + 0..3
+    float4 bv[2][4];
+#pragma unroll
+    for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            bv[cg][q] = bias ? *reinterpret_cast<const float4 *>(bias + 32 * cg + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    const long per_img = (long)tiles_y * tiles_x;
+    // the halo of output tile `tile` -> LDS buffer `buf`: wave-instruction i moves the pixel slots 8 i .. 8 i + 7
+    auto stage = [&](long tile, int buf) {
+        const int b = (int)(tile / per_img);
+        const int tr = (int)(tile - (long)b * per_img);
+        const int y0 = (tr / tiles_x) * C64_TH, x0 = (tr % tiles_x) * C64_TW;
+        for (int i = wave; i < C64_H_INSTR; i += 8) {
+            const int s = 8 * i + drow;
+            const int hr = s / C64_HW, hc = s - hr * C64_HW;
+            const int yy = y0 - 1 + hr, xx = x0 - 1 + hc;
+            const bool ok = s < C64_SLOTS && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+            const int c = dcp ^ ((s >> 1) & 7);
+            const char *src = ok ? X + (((long)b * H + yy) * Wd + xx) * 128 + 16 * c : cv_zero_page;
+            __builtin_amdgcn_global_load_lds((cv_gbl_void *)src, (cv_lds_void *)(Hl0 + buf * C64_H_BYTES + i * 1024), 16, 0, 0);
+        }
+    };
+    int buf = 0;
+    if ((long)blockIdx.x < ntiles) stage(blockIdx.x, 0);
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int b = (int)(tile / per_img);
+        const int tr = (int)(tile - (long)b * per_img);
+        const int y0 = (tr / tiles_x) * C64_TH, x0 = (tr % tiles_x) * C64_TW;
+        // this tile's halo has landed (and the weights, and the previous tile's stores have drained); every wave is past its reads of the
+        // OTHER buffer (previous tile), which the next tile's halo now overwrites while this tile is computed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tile + gridDim.x < ntiles) stage(tile + gridDim.x, buf ^ 1);
+        const char *Hl = Hl0 + buf * C64_H_BYTES;
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            const int s = (wave + ky) * C64_HW + li + kx;
+            const int sw = (s >> 1) & 7;
+            bf16x8 af[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) af[k] = *reinterpret_cast<const bf16x8 *>(Hl + s * 128 + (((2 * k + hh) ^ sw) << 4));
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(Wl + tap * 8192 + cg * 4096 + bo[k]);
+                    acc[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af[k], acc[cg], 0, 0, 0);
+                }
+        }
+        // epilogue: lane (li, hh) holds pixel li of the wave's row, couts 32 cg + 8 q + 4 hh + 0..3 in register quad q
+        {
+            const int yy = y0 + wave, xx = x0 + li;
+            if (yy < H && xx < Wd) {
+                char *yp = Y + (((long)b * H + yy) * Wd + xx) * 128;
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float e0 = acc[cg][4 * q + 0] + bv[cg][q].x, e1 = acc[cg][4 * q + 1] + bv[cg][q].y;
+                        float e2 = acc[cg][4 * q + 2] + bv[cg][q].z, e3 = acc[cg][4 * q + 3] + bv[cg][q].w;
+                        if (RELU) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                        typedef __bf16 cv_bf2 __attribute__((ext_vector_type(2)));
+                        typedef float cv_f2 __attribute__((ext_vector_type(2)));
+                        const cv_bf2 lo = __builtin_convertvector(cv_f2{e0, e1}, cv_bf2), hi2 = __builtin_convertvector(cv_f2{e2, e3}, cv_bf2);
+                        uint2 pk;
+                        pk.x = __builtin_bit_cast(unsigned, lo);
+                        pk.y = __builtin_bit_cast(unsigned, hi2);
+                        *reinterpret_cast<uint2 *>(yp + (32 * cg + 8 * q + 4 * hh) * 2) = pk;
+                    }
+            }
+        }
+        buf ^= 1;
+    }
+}
+
 extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
                                     void *Y, xq_stream_t stream) {
     const char *fn = "xq_conv3x3_nhwc_bf16";
@@ -222,7 +350,21 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
     const __hip_bfloat16 *x = (const __hip_bfloat16 *)X, *w = (const __hip_bfloat16 *)Wp;
     __hip_bfloat16 *y = (__hip_bfloat16 *)Y;
     const int pslot = prof_begin(XQ_PROF_CONV3X3, 2.0 * (double)M * 9.0 * Cin * Cout, s);
-    if (Cout % 128 == 0) {
+    static const bool c64_off = [] { const char *e = getenv("XQ_CONV_C64"); return e && e[0] == '0'; }();
+    if (Cin == 64 && Cout == 64 && !c64_off) {      // weights resident in LDS, one halo load per 16 x 32 output tile
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS) != hipSuccess)
+                return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+            attr_done = true;
+        }
+        const int ty = (H + C64_TH - 1) / C64_TH, tx = (W + C64_TW - 1) / C64_TW;
+        const long ntiles = (long)B * ty * tx;
+        const long grid = ntiles < num_cus() ? ntiles : num_cus();
+        if (relu) hipLaunchKernelGGL((conv3x3_c64_kernel<true>), dim3((unsigned)grid), dim3(512), C64_LDS, s, (const char *)X, (const char *)Wp, bias, H, W, (char *)Y, ty, tx, ntiles);
+        else hipLaunchKernelGGL((conv3x3_c64_kernel<false>), dim3((unsigned)grid), dim3(512), C64_LDS, s, (const char *)X, (const char *)Wp, bias, H, W, (char *)Y, ty, tx, ntiles);
+    } else if (Cout % 128 == 0) {
         if (relu) hipLaunchKernelGGL((conv3x3_kernel<128, 64, true>), dim3((unsigned)(((gx * (Cout / 128) + 7) / 8) * 8)), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
         else hipLaunchKernelGGL((conv3x3_kernel<128, 64, false>), dim3((unsigned)(((gx * (Cout / 128) + 7) / 8) * 8)), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
     } else {

@@ -207,7 +207,10 @@ def test_lpips_hand_driven_vgg_backward_equals_per_op_autograd():
     assert ((res[True][1] - res[False][1]).norm() / res[False][1].norm()).item() <= 1e-2
 
 
-@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 16), (3, 64, 128, 9, 11), (1, 128, 256, 32, 32), (2, 512, 512, 5, 7), (1, 64, 192, 8, 8)])
+# (3, 64, 64, 37, 45) / (2, 64, 64, 64, 96): the 64 -> 64 kernel with LDS-resident weights (conv3x3_c64_kernel: 16 x 32 output tiles, ragged
+# edges, several tiles per workgroup)
+@pytest.mark.parametrize("shape", [(2, 64, 64, 16, 16), (3, 64, 128, 9, 11), (1, 128, 256, 32, 32), (2, 512, 512, 5, 7), (1, 64, 192, 8, 8),
+                                   (3, 64, 64, 37, 45), (2, 64, 64, 64, 96)])
 @pytest.mark.parametrize("relu", [False, True])
 def test_conv3x3_implicit_gemm_vs_aten_fp32(shape, relu):
     """hand-written NHWC bf16 conv3x3 (fwd + data gradient) vs F.conv2d in fp32 on the same bf16-rounded operands"""
