@@ -84,6 +84,14 @@ __device__ __forceinline__ float max3(float a, float b, float c) {
 }
 
 #define AT_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A), (B), (C), 0, 0, 0)
+// A (uint2: this lane's 4 bf16 of column group k) and B (group k + 1) -> one 16-byte store per lane: lanes 0-31 columns 8 k .. 8 k + 7, lanes
+// 32-63 columns 8 k + 8 .. 8 k + 15 (P already carries the upper half-wave's + 16 bytes).  Executed by ALL lanes; OK guards only the store.
+#define AT_STORE16_SWAPPED(P, A, B, OK)                                                         \
+    do {                                                                                        \
+        auto rx_ = __builtin_amdgcn_permlane32_swap((A).x, (B).x, false, false);                \
+        auto ry_ = __builtin_amdgcn_permlane32_swap((A).y, (B).y, false, false);                \
+        if (OK) *reinterpret_cast<uint4 *>(P) = make_uint4(rx_[0], ry_[0], rx_[1], ry_[1]);     \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: out[b, n, h, :] = softmax(q k^T * scale) v ; lse[b, h, n] = log sum exp (natural log, scaled scores)
@@ -240,16 +248,21 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const short *__restric
 #undef FW_STORE
 
     const float inv = 1.0f / l_run;
-    if (qn < N) {
-        short *op = out + ((long)b * N + qn) * (H * 64) + h * 64 + 4 * hh;
+    {
+        // lane i holds columns 8 k + 0..3, lane i + 32 columns 8 k + 4..7 of query i: the half-waves exchange register quads
+        // (v_permlane32_swap, cdna_hip_programming.md T21) and every lane stores 16 contiguous bytes — 4 instead of 8 store instructions
+        const bool okq = qn < N;
+        short *op = out + ((long)b * N + (okq ? qn : 0)) * (H * 64) + h * 64 + 8 * hh;
+#define FW_W(O, R4) make_uint2(pack_bf16(O[4 * (R4)] * inv, O[4 * (R4) + 1] * inv), pack_bf16(O[4 * (R4) + 2] * inv, O[4 * (R4) + 3] * inv))
 #pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            uint2 w0 = make_uint2(pack_bf16(o0[4 * r4] * inv, o0[4 * r4 + 1] * inv), pack_bf16(o0[4 * r4 + 2] * inv, o0[4 * r4 + 3] * inv));
-            uint2 w1 = make_uint2(pack_bf16(o1[4 * r4] * inv, o1[4 * r4 + 1] * inv), pack_bf16(o1[4 * r4 + 2] * inv, o1[4 * r4 + 3] * inv));
-            *reinterpret_cast<uint2 *>(op + 8 * r4) = w0;
-            *reinterpret_cast<uint2 *>(op + 32 + 8 * r4) = w1;
+        for (int r4 = 0; r4 < 4; r4 += 2) {
+            uint2 a = FW_W(o0, r4), c2 = FW_W(o0, r4 + 1);
+            AT_STORE16_SWAPPED(op + 8 * r4, a, c2, okq);
+            a = FW_W(o1, r4); c2 = FW_W(o1, r4 + 1);
+            AT_STORE16_SWAPPED(op + 32 + 8 * r4, a, c2, okq);
         }
-        if (hh == 0) lse[((long)b * H + h) * N + qn] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
+#undef FW_W
+        if (okq && hh == 0) lse[((long)b * H + h) * N + qn] = (m_run + __builtin_amdgcn_logf(l_run)) * 0.6931471805599453f;
     }
 }
 
@@ -401,14 +414,19 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__rest
 #undef DQ_LOAD
 #undef DQ_STORE
 
-    if (qn < N) {
-        short *op = dqkv + ((long)b * N + qn) * RS + h * 64 + 4 * hh;
+    {
+        uint2 w0[4], w1[4];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            uint2 w0 = make_uint2(pack_bf16(a0[4 * r4] * scale, a0[4 * r4 + 1] * scale), pack_bf16(a0[4 * r4 + 2] * scale, a0[4 * r4 + 3] * scale));
-            uint2 w1 = make_uint2(pack_bf16(a1[4 * r4] * scale, a1[4 * r4 + 1] * scale), pack_bf16(a1[4 * r4 + 2] * scale, a1[4 * r4 + 3] * scale));
-            *reinterpret_cast<uint2 *>(op + 8 * r4) = w0;
-            *reinterpret_cast<uint2 *>(op + 32 + 8 * r4) = w1;
+            w0[r4] = make_uint2(pack_bf16(a0[4 * r4] * scale, a0[4 * r4 + 1] * scale), pack_bf16(a0[4 * r4 + 2] * scale, a0[4 * r4 + 3] * scale));
+            w1[r4] = make_uint2(pack_bf16(a1[4 * r4] * scale, a1[4 * r4 + 1] * scale), pack_bf16(a1[4 * r4 + 2] * scale, a1[4 * r4 + 3] * scale));
+        }
+        const bool okq = qn < N;
+        short *op = dqkv + ((long)b * N + (okq ? qn : 0)) * RS + h * 64 + 8 * hh;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4 += 2) {      // 16-byte stores through the half-wave exchange (see attn_fwd_kernel)
+            AT_STORE16_SWAPPED(op + 8 * r4, w0[r4], w0[r4 + 1], okq);
+            AT_STORE16_SWAPPED(op + 32 + 8 * r4, w1[r4], w1[r4 + 1], okq);
         }
     }
 }
@@ -534,17 +552,24 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dkdv_kernel(const short *__re
 #undef KV_LOAD
 #undef KV_STORE
 
-    if (kn < N) {
-        short *kp = dqkv + ((long)b * N + kn) * RS + H * 64 + h * 64 + 4 * hh;
-        short *vp = kp + H * 64;
+    {
+        uint2 k0[4], k1[4], v0[4], v1[4];
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            *reinterpret_cast<uint2 *>(kp + 8 * r4) = make_uint2(pack_bf16(dk0[4 * r4] * scale, dk0[4 * r4 + 1] * scale),
-                                                                 pack_bf16(dk0[4 * r4 + 2] * scale, dk0[4 * r4 + 3] * scale));   // softmax scale, once
-            *reinterpret_cast<uint2 *>(kp + 32 + 8 * r4) = make_uint2(pack_bf16(dk1[4 * r4] * scale, dk1[4 * r4 + 1] * scale),
-                                                                      pack_bf16(dk1[4 * r4 + 2] * scale, dk1[4 * r4 + 3] * scale));
-            *reinterpret_cast<uint2 *>(vp + 8 * r4) = make_uint2(pack_bf16(dv0[4 * r4], dv0[4 * r4 + 1]), pack_bf16(dv0[4 * r4 + 2], dv0[4 * r4 + 3]));
-            *reinterpret_cast<uint2 *>(vp + 32 + 8 * r4) = make_uint2(pack_bf16(dv1[4 * r4], dv1[4 * r4 + 1]), pack_bf16(dv1[4 * r4 + 2], dv1[4 * r4 + 3]));
+            k0[r4] = make_uint2(pack_bf16(dk0[4 * r4] * scale, dk0[4 * r4 + 1] * scale), pack_bf16(dk0[4 * r4 + 2] * scale, dk0[4 * r4 + 3] * scale));   // softmax scale, once
+            k1[r4] = make_uint2(pack_bf16(dk1[4 * r4] * scale, dk1[4 * r4 + 1] * scale), pack_bf16(dk1[4 * r4 + 2] * scale, dk1[4 * r4 + 3] * scale));
+            v0[r4] = make_uint2(pack_bf16(dv0[4 * r4], dv0[4 * r4 + 1]), pack_bf16(dv0[4 * r4 + 2], dv0[4 * r4 + 3]));
+            v1[r4] = make_uint2(pack_bf16(dv1[4 * r4], dv1[4 * r4 + 1]), pack_bf16(dv1[4 * r4 + 2], dv1[4 * r4 + 3]));
+        }
+        const bool okk = kn < N;
+        short *kp = dqkv + ((long)b * N + (okk ? kn : 0)) * RS + H * 64 + h * 64 + 8 * hh;
+        short *vp = kp + H * 64;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; r4 += 2) {      // 16-byte stores through the half-wave exchange (see attn_fwd_kernel): 8 instead of 16 instructions
+            AT_STORE16_SWAPPED(kp + 8 * r4, k0[r4], k0[r4 + 1], okk);
+            AT_STORE16_SWAPPED(kp + 32 + 8 * r4, k1[r4], k1[r4 + 1], okk);
+            AT_STORE16_SWAPPED(vp + 8 * r4, v0[r4], v0[r4 + 1], okk);
+            AT_STORE16_SWAPPED(vp + 32 + 8 * r4, v1[r4], v1[r4 + 1], okk);
         }
     }
 }

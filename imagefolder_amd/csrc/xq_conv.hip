@@ -215,11 +215,11 @@ extern "C" int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int fo
 // call against 0.6 TFLOP — the layer is HBM-bound on paper, 0.45 ms at 5 TB/s, and took 1.47 ms on the 128-pixel kernel above, which
 // re-gathers every input pixel nine times through registers with a barrier per 32-deep K step).  Round 4:
 //   * the whole weight matrix [9 taps][64 cout][64 cin] bf16 = 72 KiB stays in LDS for the life of a persistent workgroup (one per CU);
-//   * an output tile is 8 rows x 32 pixels; its 10 x 34 input halo arrives ONCE by LDS-DMA (global_load_lds_dwordx4, out-of-image
-//     pixels from a zero page) as 128-byte pixel slots, and all nine taps read their A fragments from it at shifted slot indices;
-//     two halo buffers: the next tile's halo lands while this tile is computed (first version, one 16 x 32 tile, load and compute
-//     in turn: 0.88 ms per call; profiles/r04_conv_c64.txt);
-//   * 8 waves, wave w owns output row w: per tap 4 A + 8 B fragment reads feed 8 MFMAs; ONE barrier per tile.
+//   * an output tile is 16 rows x 32 pixels; its 18 x 34 input halo arrives ONCE by LDS-DMA (global_load_lds_dwordx4, out-of-image
+//     pixels from a zero page) as 128-byte pixel slots, and all nine taps read their A fragments from it at shifted slot indices
+//     (measured and dropped: 8 x 32 tiles with TWO halo buffers, the next halo landing under the compute — 0.96 ms against 0.88 ms:
+//     12 fragment reads per 8 MFMAs instead of 16 per 16, profiles/r04_conv_c64.txt);
+//   * 8 waves, wave w owns output rows 2w, 2w + 1: per tap 8 A + 8 B fragment reads feed 16 MFMAs (no barrier inside a tile).
 // LDS rows of 128 B (weights: row = tap * 64 + cout; halo: row = slot = r * 34 + c): 16-byte chunk c sits at position
 // c ^ ((row >> 1) & 7), applied to the DMA's source address and on the reads — conflict-free ds_read_b128 for 32 consecutive rows at
 // any even or odd base (the shifted taps).
@@ -228,15 +228,14 @@ typedef __attribute__((address_space(3))) void cv_lds_void;
 typedef __attribute__((address_space(1))) void cv_gbl_void;
 __device__ __attribute__((aligned(64))) char cv_zero_page[64];
 
-static constexpr int C64_TH = 8, C64_TW = 32, C64_HW = C64_TW + 2, C64_SLOTS = (C64_TH + 2) * (C64_TW + 2);     // 340 halo slots
-static constexpr int C64_W_BYTES = 9 * 64 * 128, C64_H_INSTR = (C64_SLOTS + 7) / 8, C64_H_BYTES = C64_H_INSTR * 1024;
-static constexpr int C64_LDS = C64_W_BYTES + 2 * C64_H_BYTES;      // 72 KiB + 2 x 43 KiB = 158 KiB of the CU's 160
+static constexpr int C64_TH = 16, C64_TW = 32, C64_HW = C64_TW + 2, C64_SLOTS = (C64_TH + 2) * (C64_TW + 2);     // 612 halo slots
+static constexpr int C64_W_BYTES = 9 * 64 * 128, C64_H_INSTR = (C64_SLOTS + 7) / 8, C64_LDS = C64_W_BYTES + C64_H_INSTR * 1024;   // 72 + 77 KiB
 
 template <bool RELU>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const char *__restrict__ X, const char *__restrict__ Wp, const float *__restrict__ bias,
                                                           int H, int Wd, char *__restrict__ Y, int tiles_y, int tiles_x, long ntiles) {
     extern __shared__ __attribute__((aligned(16))) char c64_smem[];
-    char *const Wl = c64_smem, *const Hl0 = c64_smem + C64_W_BYTES;
+    char *const Wl = c64_smem, *const Hl = c64_smem + C64_W_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, hh = lane >> 5;
@@ -262,11 +261,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const char *__restr
             bv[cg][q] = bias ? *reinterpret_cast<const float4 *>(bias + 32 * cg + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     const long per_img = (long)tiles_y * tiles_x;
-    // the halo of output tile `tile` -> LDS buffer `buf`: wave-instruction i moves the pixel slots 8 i .. 8 i + 7
-    auto stage = [&](long tile, int buf) {
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int b = (int)(tile / per_img);
         const int tr = (int)(tile - (long)b * per_img);
         const int y0 = (tr / tiles_x) * C64_TH, x0 = (tr % tiles_x) * C64_TW;
+        // every wave is done reading the previous tile's halo (its fragment reads fed MFMAs that have issued).  A raw barrier: __syncthreads()
+        // would also wait for the previous tile's output stores (vmcnt(0)) before the halo DMA may even be issued
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         for (int i = wave; i < C64_H_INSTR; i += 8) {
             const int s = 8 * i + drow;
             const int hr = s / C64_HW, hc = s - hr * C64_HW;
@@ -274,66 +276,68 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const char *__restr
             const bool ok = s < C64_SLOTS && yy >= 0 && yy < H && xx >= 0 && xx < Wd;
             const int c = dcp ^ ((s >> 1) & 7);
             const char *src = ok ? X + (((long)b * H + yy) * Wd + xx) * 128 + 16 * c : cv_zero_page;
-            __builtin_amdgcn_global_load_lds((cv_gbl_void *)src, (cv_lds_void *)(Hl0 + buf * C64_H_BYTES + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((cv_gbl_void *)src, (cv_lds_void *)(Hl + i * 1024), 16, 0, 0);
         }
-    };
-    int buf = 0;
-    if ((long)blockIdx.x < ntiles) stage(blockIdx.x, 0);
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int b = (int)(tile / per_img);
-        const int tr = (int)(tile - (long)b * per_img);
-        const int y0 = (tr / tiles_x) * C64_TH, x0 = (tr % tiles_x) * C64_TW;
-        // this tile's halo has landed (and the weights, and the previous tile's stores have drained); every wave is past its reads of the
-        // OTHER buffer (previous tile), which the next tile's halo now overwrites while this tile is computed
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tile + gridDim.x < ntiles) stage(tile + gridDim.x, buf ^ 1);
-        const char *Hl = Hl0 + buf * C64_H_BYTES;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
 
-        f32x16 acc[2];
+        f32x16 acc[2][2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - 3 * ky;
-            const int s = (wave + ky) * C64_HW + li + kx;
-            const int sw = (s >> 1) & 7;
-            bf16x8 af[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) af[k] = *reinterpret_cast<const bf16x8 *>(Hl + s * 128 + (((2 * k + hh) ^ sw) << 4));
+            bf16x8 bf[2][4];
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const bf16x8 bf = *reinterpret_cast<const bf16x8 *>(Wl + tap * 8192 + cg * 4096 + bo[k]);
-                    acc[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af[k], acc[cg], 0, 0, 0);
-                }
-        }
-        // epilogue: lane (li, hh) holds pixel li of the wave's row, couts 32 cg + 8 q + 4 hh + 0..3 in register quad q
-        {
-            const int yy = y0 + wave, xx = x0 + li;
-            if (yy < H && xx < Wd) {
-                char *yp = Y + (((long)b * H + yy) * Wd + xx) * 128;
+                for (int k = 0; k < 4; ++k) bf[cg][k] = *reinterpret_cast<const bf16x8 *>(Wl + tap * 8192 + cg * 4096 + bo[k]);
+#pragma unroll
+            for (int pg = 0; pg < 2; ++pg) {
+                const int s = (2 * wave + pg + ky) * C64_HW + li + kx;
+                const int sw = (s >> 1) & 7;
+                bf16x8 af[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) af[k] = *reinterpret_cast<const bf16x8 *>(Hl + s * 128 + (((2 * k + hh) ^ sw) << 4));
 #pragma unroll
                 for (int cg = 0; cg < 2; ++cg)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float e0 = acc[cg][4 * q + 0] + bv[cg][q].x, e1 = acc[cg][4 * q + 1] + bv[cg][q].y;
-                        float e2 = acc[cg][4 * q + 2] + bv[cg][q].z, e3 = acc[cg][4 * q + 3] + bv[cg][q].w;
-                        if (RELU) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
-                        typedef __bf16 cv_bf2 __attribute__((ext_vector_type(2)));
-                        typedef float cv_f2 __attribute__((ext_vector_type(2)));
-                        const cv_bf2 lo = __builtin_convertvector(cv_f2{e0, e1}, cv_bf2), hi2 = __builtin_convertvector(cv_f2{e2, e3}, cv_bf2);
-                        uint2 pk;
-                        pk.x = __builtin_bit_cast(unsigned, lo);
-                        pk.y = __builtin_bit_cast(unsigned, hi2);
-                        *reinterpret_cast<uint2 *>(yp + (32 * cg + 8 * q + 4 * hh) * 2) = pk;
-                    }
+                    for (int k = 0; k < 4; ++k) acc[pg][cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[cg][k], af[k], acc[pg][cg], 0, 0, 0);
             }
         }
-        buf ^= 1;
+        // epilogue: lane (li, hh) holds pixel li of its two rows, couts 32 cg + 8 q + 4 hh + 0..3 in register quad q.  The two half-waves
+        // exchange quads (v_permlane32_swap: cdna_hip_programming.md T21) so that every lane stores 16 contiguous bytes: lanes 0-31 the
+        // couts 8 q .. 8 q + 7 of the even quad, lanes 32-63 those of the odd quad — 8 instead of 16 store instructions per wave and tile
+#pragma unroll
+        for (int pg = 0; pg < 2; ++pg) {
+            const int yy = y0 + 2 * wave + pg, xx = x0 + li;
+            const bool ok = yy < H && xx < Wd;
+            char *yp = Y + (((long)b * H + (ok ? yy : 0)) * Wd + (ok ? xx : 0)) * 128 + 16 * hh;
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                uint2 pk[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float e0 = acc[pg][cg][4 * q + 0] + bv[cg][q].x, e1 = acc[pg][cg][4 * q + 1] + bv[cg][q].y;
+                    float e2 = acc[pg][cg][4 * q + 2] + bv[cg][q].z, e3 = acc[pg][cg][4 * q + 3] + bv[cg][q].w;
+                    if (RELU) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                    typedef __bf16 cv_bf2 __attribute__((ext_vector_type(2)));
+                    typedef float cv_f2 __attribute__((ext_vector_type(2)));
+                    pk[q].x = __builtin_bit_cast(unsigned, __builtin_convertvector(cv_f2{e0, e1}, cv_bf2));
+                    pk[q].y = __builtin_bit_cast(unsigned, __builtin_convertvector(cv_f2{e2, e3}, cv_bf2));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q += 2) {
+                    auto rx = __builtin_amdgcn_permlane32_swap(pk[q].x, pk[q + 1].x, false, false);
+                    auto ry = __builtin_amdgcn_permlane32_swap(pk[q].y, pk[q + 1].y, false, false);
+                    if (ok) *reinterpret_cast<uint4 *>(yp + (32 * cg + 8 * q) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                }
+            }
+        }
     }
 }
 

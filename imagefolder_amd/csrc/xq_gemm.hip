@@ -137,7 +137,6 @@ struct Stager<gm::KMAJOR_CONV, true> {
     const char *X;
     int Hi, Wi, Cin, stride, pad, up, transposed, Hl, Wl;
     long kt0;                     // first K tile of this work item
-    long ktc;                     // persistent schedule: K tile (relative to kt0) the staging cursor stands on
     int pix0[2][2];               // [half][i]: pixel index of (b, 0, 0)  (B * Hi * Wi < 2^31, checked by the launcher)
     int oyx[2][2];                // (oy << 16) | ox; -1: row beyond M
     unsigned kbyte[2];            // [i]: byte offset of the lane's chunk inside the 64-wide K slice (independent of the half)
@@ -150,12 +149,27 @@ struct Stager<gm::KMAJOR_CONV, true> {
     __device__ __forceinline__ void retarget(const char *m, long ld, long rc0, long rc_count, long k0, int wave, int lane, int wtn) {
         init(m, ld, rc0, rc_count, k0, wave, lane, wtn, 2);
     }
-    __device__ __forceinline__ void make_scalar() {}
-    __device__ __forceinline__ void step() { ++ktc; }
-    __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const { issue(half, ktc, dst, wave); }
+    // persistent schedule: the cursor's tap / channel offset live in wave-uniform registers and advance by adds (round 4: the per-piece
+    // form below divided a 64-bit K index by Cin four times per K tile — ~1400 scalar instructions per K tile in the load phase of the
+    // conv-mode kernel against ~45 in the Linear kernels)
+    int c_ky, c_kx, c_c0;
+    __device__ __forceinline__ void make_scalar() {
+        const unsigned kg = (unsigned)kt0 * gm::BKT;
+        const unsigned tap = kg / (unsigned)Cin;
+        c_c0 = __builtin_amdgcn_readfirstlane((int)(kg - tap * (unsigned)Cin));
+        c_ky = __builtin_amdgcn_readfirstlane((int)(tap / 3u));
+        c_kx = __builtin_amdgcn_readfirstlane((int)(tap - 3u * (tap / 3u)));
+    }
+    __device__ __forceinline__ void step() {
+        c_c0 += gm::BKT;
+        if (c_c0 >= Cin) {
+            c_c0 = 0;
+            if (++c_kx == 3) { c_kx = 0; ++c_ky; }
+        }
+    }
+    __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const { issue_at(half, c_ky, c_kx, c_c0, dst, wave); }
     __device__ __forceinline__ void init(const char *, long, long rc0, long rc_count, long k0, int wave, int lane, int wtn, int) {
         kt0 = k0 / gm::BKT;
-        ktc = 0;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -174,10 +188,14 @@ struct Stager<gm::KMAJOR_CONV, true> {
                 }
             }
     }
+    // simple / ring schedules: K tile kt of this work item (K = 9 Cin < 2^31: 32-bit arithmetic)
     __device__ __forceinline__ void issue(int half, long kt, char *dst, int wave) const {
-        const long kg = (kt0 + kt) * gm::BKT;
-        const int tap = (int)(kg / Cin), c0 = (int)(kg - (long)tap * Cin);
-        const int ky = tap / 3, kx = tap - 3 * ky;
+        const unsigned kg = (unsigned)(kt0 + kt) * gm::BKT;
+        const unsigned tap = kg / (unsigned)Cin;
+        issue_at(half, (int)(tap / 3u), (int)(tap - 3u * (tap / 3u)), (int)(kg - tap * (unsigned)Cin), dst, wave);
+    }
+    __device__ __forceinline__ void issue_at(int half, int ky, int kx, int c0, char *dst, int wave) const {
+        const int sh = stride >> 1, smask = stride - 1;      // stride is 1 or 2 (checked by the launcher)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int iy, ix;
@@ -191,8 +209,8 @@ struct Stager<gm::KMAJOR_CONV, true> {
             } else {
                 iy = oy_ + ky - (2 - pad);
                 ix = ox_ + kx - (2 - pad);
-                ok = ok && iy >= 0 && ix >= 0 && (iy % stride) == 0 && (ix % stride) == 0;
-                iy /= stride; ix /= stride;
+                ok = ok && iy >= 0 && ix >= 0 && (iy & smask) == 0 && (ix & smask) == 0;
+                iy >>= sh; ix >>= sh;
                 ok = ok && iy < Hi && ix < Wi;
             }
             const char *src = ok ? X + ((long)(pix0[half][i] + iy * Wi + ix) * Cin + c0) * 2 + kbyte[i] : xq_zero_page;
