@@ -10,7 +10,9 @@
 //   unfold1d_circular : cols[b, l, tap, :] = h[b, (l + tap - K/2) mod L, :]   (the im2col of the circular conv, so that the
 //                       conv itself is one library GEMM with the taps in the reduction)
 //   fold1d_circular   : dh[b, l, :] = sum_tap dcols[b, (l - tap + K/2) mod L, tap, :]
-// One block owns (group g) x (64 channels): its 8*L x 64 slab (200 KB bf16) stays in L2 across the passes.
+// One block owns (group g) x (CH channels), CH = 64, 32 or 16 — the widest that still gives >= 256 blocks (round 4: at C = 384 and 16
+// virtual batches the fixed 64-channel blocks made a 96-block grid on 256 CUs, each walking its 1568 rows three times: 55 - 75 us per
+// call for 40 - 60 MB); its 8*L x CH slab stays in L2 across the passes.
 #include "xq_common.hpp"
 #include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
@@ -19,31 +21,31 @@
 
 using namespace xq;
 
-static constexpr int BN_CH = 64;   // channels per block
+static constexpr int BN_CH = 64;   // widest channel block (and the granularity C must have)
 
 // column sums over the block's rows: thread (rt, ct) owns VEC columns, rows rt, rt+RPP, ...; reduce over rt through LDS
-template <int VEC, int TPR, int RPP>
-__device__ __forceinline__ void block_colsum(float (&acc)[VEC], float *lds /* [RPP][BN_CH] */, float *out /* [BN_CH] in LDS */) {
+template <int VEC, int TPR, int RPP, int CH>
+__device__ __forceinline__ void block_colsum(float (&acc)[VEC], float *lds /* [RPP][CH] */, float *out /* [CH] in LDS */) {
     const int ct = threadIdx.x % TPR, rt = threadIdx.x / TPR;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) lds[rt * BN_CH + ct * VEC + j] = acc[j];
+    for (int j = 0; j < VEC; ++j) lds[rt * CH + ct * VEC + j] = acc[j];
     __syncthreads();
-    if (threadIdx.x < BN_CH) {
+    if (threadIdx.x < CH) {
         float s = 0.0f;
-        for (int r = 0; r < RPP; ++r) s += lds[r * BN_CH + threadIdx.x];
+        for (int r = 0; r < RPP; ++r) s += lds[r * CH + threadIdx.x];
         out[threadIdx.x] = s;
     }
     __syncthreads();
 }
 
-template <typename T>
+template <typename T, int CH>
 __global__ __launch_bounds__(256) void bnlocal_lrelu_fwd_kernel(const T *__restrict__ y, const float *__restrict__ w, const float *__restrict__ b,
                                                                 const T *__restrict__ skip, int R, int C, float eps, float slope, float ratio,
                                                                 T *__restrict__ out, float *__restrict__ mean_out, float *__restrict__ rstd_out) {
-    constexpr int VEC = 16 / sizeof(T), TPR = BN_CH / VEC, RPP = 256 / TPR;
-    __shared__ float red[RPP * BN_CH];
-    __shared__ float stat[2][BN_CH];
-    const int g = blockIdx.y, c0 = blockIdx.x * BN_CH;
+    constexpr int VEC = 16 / sizeof(T), TPR = CH / VEC, RPP = 256 / TPR;
+    __shared__ float red[RPP * CH];
+    __shared__ float stat[2][CH];
+    const int g = blockIdx.y, c0 = blockIdx.x * CH;
     const int ct = threadIdx.x % TPR, rt = threadIdx.x / TPR;
     const T *yb = y + (long)g * R * C + c0 + ct * VEC;
     float acc[VEC], v[VEC];
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void bnlocal_lrelu_fwd_kernel(const T *__restr
 #pragma unroll
         for (int j = 0; j < VEC; ++j) acc[j] += v[j];
     }
-    block_colsum<VEC, TPR, RPP>(acc, red, stat[0]);
+    block_colsum<VEC, TPR, RPP, CH>(acc, red, stat[0]);
     float mu[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { mu[j] = stat[0][ct * VEC + j] / (float)R; acc[j] = 0.0f; }
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(256) void bnlocal_lrelu_fwd_kernel(const T *__restr
 #pragma unroll
         for (int j = 0; j < VEC; ++j) { const float d = v[j] - mu[j]; acc[j] = fmaf(d, d, acc[j]); }
     }
-    block_colsum<VEC, TPR, RPP>(acc, red, stat[1]);
+    block_colsum<VEC, TPR, RPP, CH>(acc, red, stat[1]);
     float rs[VEC], ww[VEC], bb[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -94,16 +96,16 @@ __global__ __launch_bounds__(256) void bnlocal_lrelu_fwd_kernel(const T *__restr
     }
 }
 
-template <typename T>
+template <typename T, int CH>
 __global__ __launch_bounds__(256) void bnlocal_lrelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ y, const float *__restrict__ w,
                                                                 const float *__restrict__ b, const float *__restrict__ mean,
                                                                 const float *__restrict__ rstd, int R, int C, float slope, float ratio,
                                                                 int has_skip, T *__restrict__ g_y, T *__restrict__ g_skip,
                                                                 float *__restrict__ gw_part, float *__restrict__ gb_part) {
-    constexpr int VEC = 16 / sizeof(T), TPR = BN_CH / VEC, RPP = 256 / TPR;
-    __shared__ float red[RPP * BN_CH];
-    __shared__ float stat[2][BN_CH];
-    const int g = blockIdx.y, c0 = blockIdx.x * BN_CH;
+    constexpr int VEC = 16 / sizeof(T), TPR = CH / VEC, RPP = 256 / TPR;
+    __shared__ float red[RPP * CH];
+    __shared__ float stat[2][CH];
+    const int g = blockIdx.y, c0 = blockIdx.x * CH;
     const int ct = threadIdx.x % TPR, rt = threadIdx.x / TPR;
     const long off = (long)g * R * C + c0 + ct * VEC;
     const float scale = has_skip ? ratio : 1.0f;
@@ -131,8 +133,8 @@ __global__ __launch_bounds__(256) void bnlocal_lrelu_bwd_kernel(const T *__restr
             s2[j] = fmaf(gp, z, s2[j]);
         }
     }
-    block_colsum<VEC, TPR, RPP>(s1, red, stat[0]);
-    block_colsum<VEC, TPR, RPP>(s2, red, stat[1]);
+    block_colsum<VEC, TPR, RPP, CH>(s1, red, stat[0]);
+    block_colsum<VEC, TPR, RPP, CH>(s2, red, stat[1]);
     float m1[VEC], m2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -209,6 +211,13 @@ __global__ __launch_bounds__(256) void fold1d_kernel(const T *__restrict__ dcols
     }
 }
 
+// channels per block: the widest of 64 / 32 / 16 that fills the chip (C % 64 == 0 by contract)
+static int bn_block_channels(int C, int G) {
+    for (int ch = 64; ch > 16; ch >>= 1)
+        if ((long)(C / ch) * G >= num_cus()) return ch;
+    return 16;
+}
+
 static int bn_check(const char *fn, int G, int R, int C) {
     if (G < 0 || R < 1 || C < 1 || C % BN_CH != 0)
         return xq_set_error(XQ_EINVAL, "%s: needs rows_per_group >= 1 and C %% 64 == 0 (got %ld, %ld)", fn, (long)R, (long)C);
@@ -222,14 +231,14 @@ extern "C" int xq_bnlocal_lrelu_forward(const void *y, const float *w, const flo
     if (int rc = bn_check(fn, G, rows_per_group, C)) return rc;
     if (G == 0) return XQ_OK;
     if (!y || !out || !mean || !rstd) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    const dim3 grid(C / BN_CH, G);
     hipStream_t s = (hipStream_t)stream;
-    if (act_bf16)
-        hipLaunchKernelGGL((bnlocal_lrelu_fwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16 *)y, w, b, (const bf16 *)skip, rows_per_group, C, eps,
-                           slope, ratio, (bf16 *)out, mean, rstd);
-    else
-        hipLaunchKernelGGL((bnlocal_lrelu_fwd_kernel<float>), grid, dim3(256), 0, s, (const float *)y, w, b, (const float *)skip, rows_per_group, C,
-                           eps, slope, ratio, (float *)out, mean, rstd);
+    const int ch = bn_block_channels(C, G);
+#define BN_FWD(T_, CH_)                                                                                                                          \
+    hipLaunchKernelGGL((bnlocal_lrelu_fwd_kernel<T_, CH_>), dim3(C / CH_, G), dim3(256), 0, s, (const T_ *)y, w, b, (const T_ *)skip, rows_per_group, \
+                       C, eps, slope, ratio, (T_ *)out, mean, rstd)
+    if (act_bf16) { if (ch == 64) BN_FWD(bf16, 64); else if (ch == 32) BN_FWD(bf16, 32); else BN_FWD(bf16, 16); }
+    else { if (ch == 64) BN_FWD(float, 64); else if (ch == 32) BN_FWD(float, 32); else BN_FWD(float, 16); }
+#undef BN_FWD
     return xq_check_launch(fn);
 }
 
@@ -241,14 +250,14 @@ extern "C" int xq_bnlocal_lrelu_backward(const void *g_out, const void *y, const
     if (G == 0) return XQ_OK;
     if (!g_out || !y || !mean || !rstd || !g_y || !gw_part || !gb_part || (has_skip && !g_skip))
         return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    const dim3 grid(C / BN_CH, G);
     hipStream_t s = (hipStream_t)stream;
-    if (act_bf16)
-        hipLaunchKernelGGL((bnlocal_lrelu_bwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16 *)g_out, (const bf16 *)y, w, b, mean, rstd,
-                           rows_per_group, C, slope, ratio, has_skip, (bf16 *)g_y, (bf16 *)g_skip, gw_part, gb_part);
-    else
-        hipLaunchKernelGGL((bnlocal_lrelu_bwd_kernel<float>), grid, dim3(256), 0, s, (const float *)g_out, (const float *)y, w, b, mean, rstd,
-                           rows_per_group, C, slope, ratio, has_skip, (float *)g_y, (float *)g_skip, gw_part, gb_part);
+    const int ch = bn_block_channels(C, G);
+#define BN_BWD(T_, CH_)                                                                                                                          \
+    hipLaunchKernelGGL((bnlocal_lrelu_bwd_kernel<T_, CH_>), dim3(C / CH_, G), dim3(256), 0, s, (const T_ *)g_out, (const T_ *)y, w, b, mean, rstd,   \
+                       rows_per_group, C, slope, ratio, has_skip, (T_ *)g_y, (T_ *)g_skip, gw_part, gb_part)
+    if (act_bf16) { if (ch == 64) BN_BWD(bf16, 64); else if (ch == 32) BN_BWD(bf16, 32); else BN_BWD(bf16, 16); }
+    else { if (ch == 64) BN_BWD(float, 64); else if (ch == 32) BN_BWD(float, 32); else BN_BWD(float, 16); }
+#undef BN_BWD
     return xq_check_launch(fn);
 }
 
