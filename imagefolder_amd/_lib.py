@@ -66,8 +66,9 @@ SIGNATURES = {
     "xq_lpips_level_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_lpips_level_backward_fused": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_pack_weights": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv3x3_nhwc_bf16_takes_out_mask": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "xq_conv3x3_nhwc_bf16": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
-                                            ctypes.c_int, vp, vp]),
+                                            ctypes.c_int, vp, vp, vp]),
     "xq_conv3x3_wgrad_nhwc_bf16": (ctypes.c_int, [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_wgrad_nhwc_bf16_ex": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp]),
     "xq_sumpool2x2_nhwc_bf16": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
@@ -109,7 +110,7 @@ SIGNATURES = {
     "xq_gemm_bf16_nt_gelu": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp]),
     "xq_gemm_colpart_rows": (ctypes.c_size_t, [ctypes.c_int64]),
     "xq_gemm_bf16_nn_gelu_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp]),
-    "xq_conv3x3_gemm_bf16": (ctypes.c_int, [vp, vp, vp] + [ctypes.c_int] * 12 + [vp, ctypes.c_int, vp]),
+    "xq_conv3x3_gemm_bf16": (ctypes.c_int, [vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, ctypes.c_int, vp]),
     "xq_gemm_bf16_batched": (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int] + [ctypes.c_int64] * 6 + [vp, vp]),
     "xq_gemm_bf16_tn": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_size_t, ctypes.c_int, vp]),
     "xq_prof_enable": (ctypes.c_int, [ctypes.c_int]),

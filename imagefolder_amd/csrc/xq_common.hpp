@@ -27,6 +27,16 @@ __device__ __forceinline__ float ord2f(uint32_t u) {
     return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
 }
 
+// out_mask of the convolutions (the ReLU of the layer BELOW a data gradient: aten::threshold_backward(g, y, 0) folded into the store of g):
+// of a packed bf16 pair of the output each half survives where the mask's bf16 value is > 0 — read as a signed 16-bit integer:
+// positive and not zero (the mask is a ReLU output: no NaN convention needed beyond "NaN with the sign clear passes", as ATen's y > 0 ... does not;
+// a NaN activation has poisoned the step long before)
+__device__ __forceinline__ uint32_t keep_where_positive(uint32_t v, uint32_t m) {
+    const uint32_t lo = (int16_t)(m & 0xffffu) > 0 ? 0x0000ffffu : 0u;
+    const uint32_t hi = (int32_t)m >= 0x00010000 ? 0xffff0000u : 0u;
+    return v & (lo | hi);
+}
+
 // (A1)+(A2) on a register-resident row; returns the clamped norm.
 template <int C>
 __device__ __forceinline__ float l2norm_row(const float (&x)[C], float (&y)[C]) {

@@ -233,7 +233,8 @@ static constexpr int C64_W_BYTES = 9 * 64 * 128, C64_H_INSTR = (C64_SLOTS + 7) /
 
 template <bool RELU>
 __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const char *__restrict__ X, const char *__restrict__ Wp, const float *__restrict__ bias,
-                                                          int H, int Wd, char *__restrict__ Y, int tiles_y, int tiles_x, long ntiles) {
+                                                          int H, int Wd, char *__restrict__ Y, int tiles_y, int tiles_x, long ntiles,
+                                                          const char *__restrict__ Mk) {
     extern __shared__ __attribute__((aligned(16))) char c64_smem[];
     char *const Wl = c64_smem, *const Hl = c64_smem + C64_W_BYTES;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -334,28 +335,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const char *__restr
                 for (int q = 0; q < 4; q += 2) {
                     auto rx = __builtin_amdgcn_permlane32_swap(pk[q].x, pk[q + 1].x, false, false);
                     auto ry = __builtin_amdgcn_permlane32_swap(pk[q].y, pk[q + 1].y, false, false);
-                    if (ok) *reinterpret_cast<uint4 *>(yp + (32 * cg + 8 * q) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    uint4 o = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+                    if (Mk != nullptr && ok) {      // out_mask: same layout as Y
+                        const uint4 mk = *reinterpret_cast<const uint4 *>(Mk + (yp - Y) + (32 * cg + 8 * q) * 2);
+                        o.x = xq::keep_where_positive(o.x, mk.x); o.y = xq::keep_where_positive(o.y, mk.y);
+                        o.z = xq::keep_where_positive(o.z, mk.z); o.w = xq::keep_where_positive(o.w, mk.w);
+                    }
+                    if (ok) *reinterpret_cast<uint4 *>(yp + (32 * cg + 8 * q) * 2) = o;
                 }
             }
         }
     }
 }
 
+static bool c64_disabled() {
+    static const bool off = [] { const char *e = getenv("XQ_CONV_C64"); return e && e[0] == '0'; }();
+    return off;
+}
+extern "C" int xq_conv3x3_nhwc_bf16_takes_out_mask(int Cin, int Cout) { return Cin == 64 && Cout == 64 && !c64_disabled(); }
+
 extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
-                                    void *Y, xq_stream_t stream) {
+                                    const void *out_mask, void *Y, xq_stream_t stream) {
     const char *fn = "xq_conv3x3_nhwc_bf16";
     if (B == 0) return XQ_OK;
     if (!X || !Wp || !Y) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     if (Cin % 64 != 0 || Cout % 64 != 0)
         return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %ld, %ld)", fn, Cin, Cout);
+    if (out_mask && !xq_conv3x3_nhwc_bf16_takes_out_mask(Cin, Cout))
+        return xq_set_error(XQ_EINVAL, "%s: out_mask is folded into the store of the 64 -> 64 channel kernel only (got %ld -> %ld)", fn, Cin, Cout);
     const long M = (long)B * H * W;
     hipStream_t s = (hipStream_t)stream;
     const long gx = (M + CV_BM - 1) / CV_BM;
     const __hip_bfloat16 *x = (const __hip_bfloat16 *)X, *w = (const __hip_bfloat16 *)Wp;
     __hip_bfloat16 *y = (__hip_bfloat16 *)Y;
     const int pslot = prof_begin(XQ_PROF_CONV3X3, 2.0 * (double)M * 9.0 * Cin * Cout, s);
-    static const bool c64_off = [] { const char *e = getenv("XQ_CONV_C64"); return e && e[0] == '0'; }();
-    if (Cin == 64 && Cout == 64 && !c64_off) {      // weights resident in LDS, one halo load per 16 x 32 output tile
+    if (Cin == 64 && Cout == 64 && !c64_disabled()) {      // weights resident in LDS, one halo load per 16 x 32 output tile
         static bool attr_done = false;
         if (!attr_done) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS) != hipSuccess ||
@@ -366,8 +380,8 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
         const int ty = (H + C64_TH - 1) / C64_TH, tx = (W + C64_TW - 1) / C64_TW;
         const long ntiles = (long)B * ty * tx;
         const long grid = ntiles < num_cus() ? ntiles : num_cus();
-        if (relu) hipLaunchKernelGGL((conv3x3_c64_kernel<true>), dim3((unsigned)grid), dim3(512), C64_LDS, s, (const char *)X, (const char *)Wp, bias, H, W, (char *)Y, ty, tx, ntiles);
-        else hipLaunchKernelGGL((conv3x3_c64_kernel<false>), dim3((unsigned)grid), dim3(512), C64_LDS, s, (const char *)X, (const char *)Wp, bias, H, W, (char *)Y, ty, tx, ntiles);
+        if (relu) hipLaunchKernelGGL((conv3x3_c64_kernel<true>), dim3((unsigned)grid), dim3(512), C64_LDS, s, (const char *)X, (const char *)Wp, bias, H, W, (char *)Y, ty, tx, ntiles, (const char *)out_mask);
+        else hipLaunchKernelGGL((conv3x3_c64_kernel<false>), dim3((unsigned)grid), dim3(512), C64_LDS, s, (const char *)X, (const char *)Wp, bias, H, W, (char *)Y, ty, tx, ntiles, (const char *)out_mask);
     } else if (Cout % 128 == 0) {
         if (relu) hipLaunchKernelGGL((conv3x3_kernel<128, 64, true>), dim3((unsigned)(((gx * (Cout / 128) + 7) / 8) * 8)), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);
         else hipLaunchKernelGGL((conv3x3_kernel<128, 64, false>), dim3((unsigned)(((gx * (Cout / 128) + 7) / 8) * 8)), dim3(256), 0, s, x, w, bias, M, H, W, Cin, Cout, y);

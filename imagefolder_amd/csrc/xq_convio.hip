@@ -19,6 +19,7 @@
 #include "../../include/xq_ops.h"
 
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 
 using namespace xq;
 
@@ -74,6 +75,101 @@ __global__ __launch_bounds__(256) void conv3x3_from3_kernel(const TIN *__restric
         for (int q = 0; q < 4; ++q)
             out[c0 / 8 + q] = make_uint4(pack2(acc[8 * q + 0], acc[8 * q + 1]), pack2(acc[8 * q + 2], acc[8 * q + 3]),
                                          pack2(acc[8 * q + 4], acc[8 * q + 5]), pack2(acc[8 * q + 6], acc[8 * q + 7]));
+    }
+}
+
+// The same convolution on the matrix cores (round 4).  K = 27 padded to 32 = two k-steps of v_mfma_f32_32x32x16_bf16: 16 % padding, not the
+// "> 90 %" the header feared for a 3-channel tile — the padding is along K, the 32 x 32 output tile is 32 pixels x 32 output channels, all
+// live.  One wave = 32 consecutive pixels x all C3_OUT channels per tile, persistent over tiles: lane (li, hh) gathers the 16 taps
+// k = 16 s + 8 hh + j of pixel li straight from the planar image (consecutive lanes = consecutive pixels: coalesced; every input value
+// is fetched 9 times, from L1), rounds them to bf16 as autocast does, and the weights sit in registers as bf16 fragments for the life of the
+// wave.  27 fp32 FMAs per output element on the VALU (the kernel above: 1.8 TB/s, VALU-bound) become 2 MFMAs per 32 x 32 outputs; what is
+// left is the 2 * C3_OUT bytes per pixel of the store (16 bytes per lane through v_permlane32_swap, as conv3x3_c64_kernel).
+// Accumulation starts from the bias, k ascending inside the MFMA: fp32 sums of the same 27 exact bf16 x bf16 products as the VALU kernel, in
+// another order (results agree to fp32 rounding, i.e. an occasional bf16 ulp).
+typedef __bf16 c3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float c3_f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename TIN, int C3_OUT>
+__global__ __launch_bounds__(256) void conv3x3_from3_mfma_kernel(const TIN *__restrict__ X, const float *__restrict__ Wk, const float *__restrict__ bias,
+                                                                 int B, int H, int W, int relu, char *__restrict__ Y) {
+    constexpr int NB = C3_OUT / 32;
+    const int lane = threadIdx.x & 63, li = lane & 31, hh = lane >> 5;
+    const unsigned total = (unsigned)B * (unsigned)H * (unsigned)W;          // host checks < 2^31
+    const unsigned ntiles = (total + 31u) / 32u;
+    // this lane's 16 taps: plane / row / column displacement of k = 16 s + 8 hh + j; k >= 27 gets row code 3 (never valid)
+    int koff[2][8], kyx[2][8];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 16 * s2 + 8 * hh + j;
+            const int tap = (k * 11) >> 5, ci = k - 3 * tap;                 // k / 3 for k < 32
+            const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+            koff[s2][j] = k < 27 ? (ci * H + (ky - 1)) * W + (kx - 1) : 0;
+            kyx[s2][j] = k < 27 ? (ky | (kx << 2)) : 3;
+        }
+    c3_bf16x8 wf[NB][2];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 16 * s2 + 8 * hh + j;
+                wf[nb][s2][j] = (__bf16)(k < 27 ? Wk[k * C3_OUT + 32 * nb + li] : 0.0f);
+            }
+    const unsigned HW = (unsigned)H * (unsigned)W;
+    // a workgroup walks a CONTIGUOUS run of tiles, its four waves interleaved: the image rows a tile shares with the tiles one row up / down
+    // (W / 32 tiles away) are then fetched by the same CU a few iterations apart and come out of its L1, not once per XCD out of HBM
+    const unsigned per_block = ((ntiles + gridDim.x - 1u) / gridDim.x + 3u) & ~3u;
+    const unsigned t_end = min(ntiles, (blockIdx.x + 1u) * per_block);
+    for (unsigned t = blockIdx.x * per_block + (threadIdx.x >> 6); t < t_end; t += 4u) {
+        const unsigned p = t * 32u + li;
+        const bool live = p < total;
+        const unsigned pp = live ? p : total - 1u;
+        const unsigned b = pp / HW, rem = pp - b * HW;
+        const int y = (int)(rem / (unsigned)W), x = (int)(rem - (unsigned)y * (unsigned)W);
+        const unsigned rowbits = (y > 0 ? 1u : 0u) | 2u | (y + 1 < H ? 4u : 0u);
+        const unsigned colbits = (x > 0 ? 1u : 0u) | 2u | (x + 1 < W ? 4u : 0u);
+        const TIN *xp = X + ((long)b * 3 * H + y) * W + x;
+        c3_bf16x8 af[2];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = ((rowbits >> (kyx[s2][j] & 3)) & (colbits >> (kyx[s2][j] >> 2)) & 1u) != 0u;
+                af[s2][j] = (__bf16)(ok ? (float)xp[ok ? koff[s2][j] : 0] : 0.0f);
+            }
+        const bool ok_store = live;
+        char *yp = Y + (long)pp * (2 * C3_OUT) + 16 * hh;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            c3_f32x16 acc;      // starts from the bias (wave-uniform per half: 16-byte loads that hit L1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 b4 = bias ? *reinterpret_cast<const float4 *>(bias + 32 * nb + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb][0], af[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb][1], af[1], acc, 0, 0, 0);
+            uint2 pk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float e0 = acc[4 * q + 0], e1 = acc[4 * q + 1], e2 = acc[4 * q + 2], e3 = acc[4 * q + 3];
+                if (relu) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                pk[q].x = pack2(e0, e1);
+                pk[q].y = pack2(e2, e3);
+            }
+            // lanes 0-31 hold the channels 8 q + 0..3 of their pixel, lanes 32-63 the channels 8 q + 4..7: after the swap a lane of the lower
+            // half owns the 8 channels of an even q, its partner those of the odd q (cdna_hip_programming.md T21)
+#pragma unroll
+            for (int q = 0; q < 4; q += 2) {
+                auto rx = __builtin_amdgcn_permlane32_swap(pk[q].x, pk[q + 1].x, false, false);
+                auto ry = __builtin_amdgcn_permlane32_swap(pk[q].y, pk[q + 1].y, false, false);
+                if (ok_store) *reinterpret_cast<uint4 *>(yp + (32 * nb + 8 * q) * 2) = make_uint4(rx[0], ry[0], rx[1], ry[1]);
+            }
+        }
     }
 }
 
@@ -296,13 +392,26 @@ extern "C" int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, con
     if (B == 0) return XQ_OK;
     if (!x_planar || !w_kc || !y_nhwc) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     const long total = (long)B * H * W;
-    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (total * 3 >= 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: image batch too large for 32-bit pixel indices", fn);
     hipStream_t s = (hipStream_t)stream;
-    __hip_bfloat16 *y = (__hip_bfloat16 *)y_nhwc;
+    static const bool valu = [] { const char *e = getenv("XQ_FROM3_VALU"); return e && e[0] == '1'; }();
+    if (valu) {
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        __hip_bfloat16 *y = (__hip_bfloat16 *)y_nhwc;
 #define FROM3(T, CO) hipLaunchKernelGGL((conv3x3_from3_kernel<T, CO>), dim3(blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, relu, y)
-    if (x_is_bf16) { if (Cout == 128) FROM3(__hip_bfloat16, 128); else FROM3(__hip_bfloat16, 64); }
-    else { if (Cout == 128) FROM3(float, 128); else FROM3(float, 64); }
+        if (x_is_bf16) { if (Cout == 128) FROM3(__hip_bfloat16, 128); else FROM3(__hip_bfloat16, 64); }
+        else { if (Cout == 128) FROM3(float, 128); else FROM3(float, 64); }
 #undef FROM3
+        return xq_check_launch(fn);
+    }
+    const long tiles = (total + 31) / 32;
+    long blocks = (tiles + 3) / 4;
+    const long cap = (long)num_cus() * (Cout == 128 ? 3 : 4);      // resident workgroups per CU at 137 / 121 VGPRs; each walks a contiguous run of tiles
+    if (blocks > cap) blocks = cap;
+#define FROM3M(T, CO) hipLaunchKernelGGL((conv3x3_from3_mfma_kernel<T, CO>), dim3((unsigned)blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, relu, (char *)y_nhwc)
+    if (x_is_bf16) { if (Cout == 128) FROM3M(__hip_bfloat16, 128); else FROM3M(__hip_bfloat16, 64); }
+    else { if (Cout == 128) FROM3M(float, 128); else FROM3M(float, 64); }
+#undef FROM3M
     return xq_check_launch(fn);
 }
 

@@ -234,6 +234,7 @@ __device__ __forceinline__ bf16x8 read_frag(const char *piece, int w, int f, int
 // ---------------------------------------------------------------------------------------------------------------------
 // epilogues
 // ---------------------------------------------------------------------------------------------------------------------
+using xq::keep_where_positive;      // out_mask of the convolutions (xq_common.hpp)
 template <int NFJ>
 __device__ __forceinline__ void epilogue_bf16(const f32x16 (&acc)[4][NFJ], const GemmArgs &g, char *region, long m0, long n0,
                                               int wr, int wc, int lane) {
@@ -269,10 +270,17 @@ __device__ __forceinline__ void epilogue_bf16(const f32x16 (&acc)[4][NFJ], const
     for (int it = 0; it < PASSES; ++it) {
         int row, c, off;
         gm::epi_read_map(it, lane, WTN, &row, &c, &off);
-        const uint4 v = *reinterpret_cast<const uint4 *>(region + off);
+        uint4 v = *reinterpret_cast<const uint4 *>(region + off);
         const long gr = m0 + 128 * wr + row;
         const long gc = ncol0 + 8 * c;
-        if (gr < g.M && gc + 8 <= g.N) *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
+        if (gr < g.M && gc + 8 <= g.N) {
+            if (g.H) {      // out_mask (convolutions only; the fused-GELU kernels, the other users of H, have their own epilogue)
+                const uint4 mk = *reinterpret_cast<const uint4 *>(reinterpret_cast<const __hip_bfloat16 *>(g.H) + gr * g.ldc + gc);
+                v.x = keep_where_positive(v.x, mk.x); v.y = keep_where_positive(v.y, mk.y);
+                v.z = keep_where_positive(v.z, mk.z); v.w = keep_where_positive(v.w, mk.w);
+            }
+            *reinterpret_cast<uint4 *>(C + gr * g.ldc + gc) = v;
+        }
     }
 }
 
@@ -783,6 +791,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             // bias and ReLU exist for the K-major B operand only (Linear forward, convolutions): the data gradients have neither, and
             // their epilogues keep the 32 registers
             constexpr bool HAS_BIAS = BK == gm::KMAJOR;
+            constexpr bool OUT_MASK = AK == gm::KMAJOR_CONV && ACT == ACT_NONE;   // H = out_mask of a convolution's data gradient
             float4 bv[2][4];
 #pragma unroll
             for (int fj = 0; fj < 2; ++fj)
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi) {
                 u32x4 hv[4];
-                if (ACT == ACT_GELU_BWD) {      // the pre-activations of the 4 store passes, fetched ahead of the LDS round trip
+                if (ACT == ACT_GELU_BWD || (OUT_MASK && g.H)) {      // the pre-activations (GELU') / the out_mask values of the 4 store passes, fetched ahead of the LDS round trip
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         int row, c, off;
@@ -853,6 +862,10 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                             o[e] = pack_bf16(bf16_lo(v[e]) * d0, bf16_hi(v[e]) * d1);
                             if (gr < g.M) { csum[2 * e] += bf16_lo(o[e]); csum[2 * e + 1] += bf16_hi(o[e]); }
                         }
+                    }
+                    if (OUT_MASK && g.H) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = keep_where_positive(v[e], hv[it][e]);
                     }
                     if (ok) {
                         u32x4 *p1 = reinterpret_cast<u32x4 *>(C + gr * g.ldc + gc);
@@ -1322,8 +1335,8 @@ extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const vo
 
 // ---- 3x3 convolution as an implicit GEMM on the tile engine (NHWC bf16; Cin % 64 == 0, Cout % 8 == 0, Cout >= 64) -------------
 extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int Ho,
-                                    int Wo, int stride, int pad, int upsample2x, int transposed, int relu, void *y, int impl,
-                                    xq_stream_t stream) {
+                                    int Wo, int stride, int pad, int upsample2x, int transposed, int relu, const void *out_mask, void *y,
+                                    int impl, xq_stream_t stream) {
     const char *fn = "xq_conv3x3_gemm_bf16";
     if (B < 0 || Hi < 1 || Wi < 1 || Ho < 1 || Wo < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
     if (Cin % 64 || Cout % 8 || Cout < 64) return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 64 == 0, Cout %% 8 == 0, Cout >= 64 (Cin=%ld Cout=%ld)", fn, (long)Cin, (long)Cout);
@@ -1338,6 +1351,7 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     GemmArgs g{};
     g.nt_store = 1;
     g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;
+    g.H = (const char *)out_mask;
     g.M = M; g.N = Cout; g.lda = K; g.ldb = K; g.ldc = Cout;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
     g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((Cout + BN - 1) / BN);

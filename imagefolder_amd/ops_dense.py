@@ -485,6 +485,23 @@ def run_blocks(blocks, x, final_norm, act_dtype, taps=None):
     a = LayerNormFn.apply(x, b0.norm1.weight, b0.norm1.bias, b0.norm1.eps, act_dtype)
     n = len(blocks)
     tapped = {}
+    # every DropPath mask of the stack from ONE uniform draw (drop_path1 then drop_path2 of each block, the reference's order): the per-module
+    # form costs two tiny launches per mask (bernoulli_ + div_), 88 per train step.  Same distribution (keep with probability 1 - p, scaled by
+    # 1 / keep), a different use of the generator stream — the parity tests replay recorded masks through DropPath.REPLAY, which bypasses this
+    pre_masks = None
+    if DropPath.REPLAY is None:
+        dps = [dp for blk in blocks for dp in (getattr(blk, "drop_path1", None), getattr(blk, "drop_path2", None))]
+        live = [j for j, dp in enumerate(dps) if isinstance(dp, DropPath) and dp.training and dp.drop_prob > 0.0]
+        if len(live) > 2:
+            probs = tuple(1.0 - dps[j].drop_prob for j in live)
+            cache = getattr(blocks[0], "_xq_keep_probs", None)       # (probs, device tensor): no host-to-device copy inside the step
+            if cache is None or cache[0] != probs or cache[1].device != x.device:
+                cache = (probs, torch.tensor(probs, dtype=torch.float32, device=x.device))
+                blocks[0]._xq_keep_probs = cache
+            keep = cache[1]
+            u = torch.rand(len(live), x.shape[0], device=x.device)
+            mk = ((u < keep[:, None]).to(torch.float32) / keep[:, None].clamp_min(1e-12)).view(len(live), x.shape[0], 1, 1)
+            pre_masks = {j: mk[k] for k, j in enumerate(live)}
     for i, blk in enumerate(blocks):
         at = blk.attn
         ls1, ls2 = getattr(blk, "ls1", None), getattr(blk, "ls2", None)
@@ -493,7 +510,7 @@ def run_blocks(blocks, x, final_norm, act_dtype, taps=None):
         o = attention_qkvpacked(qkv, at.num_heads)
         p = LinearFn.apply(o, at.proj.weight, at.proj.bias, True)
         g1 = ls1.gamma if isinstance(ls1, LayerScale) else None
-        m1 = dp1.keep_mask(p) if isinstance(dp1, DropPath) else None
+        m1 = (pre_masks.get(2 * i) if pre_masks is not None else dp1.keep_mask(p)) if isinstance(dp1, DropPath) else None
         x, a = ResLNFn.apply(x, p, g1, m1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, at.proj.bias)
         if mlp_fused_supported(a, blk.mlp):
             f = MlpFn.apply(a, blk.mlp.fc1.weight, blk.mlp.fc1.bias, blk.mlp.fc2.weight, blk.mlp.fc2.bias,
@@ -503,7 +520,7 @@ def run_blocks(blocks, x, final_norm, act_dtype, taps=None):
             hg = GeluFn.apply(h, blk.mlp.fc1.bias, bool(getattr(blk.mlp, "gelu_tanh", False)))
             f = LinearFn.apply(hg, blk.mlp.fc2.weight, blk.mlp.fc2.bias, True)
         g2 = ls2.gamma if isinstance(ls2, LayerScale) else None
-        m2 = dp2.keep_mask(f) if isinstance(dp2, DropPath) else None
+        m2 = (pre_masks.get(2 * i + 1) if pre_masks is not None else dp2.keep_mask(f)) if isinstance(dp2, DropPath) else None
         nxt = blocks[i + 1].norm1 if i + 1 < n else final_norm
         x, a = ResLNFn.apply(x, f, g2, m2, nxt.weight, nxt.bias, nxt.eps, blk.mlp.fc2.bias)
         if taps is not None and i in taps:
@@ -621,9 +638,13 @@ class LpipsVggFn(torch.autograd.Function):
                 g = fn.backward(c, g)                             # w.r.t. the tapped map below: the tap entry adds + masks
             else:
                 c.relu = False                                    # the ReLU mask is already in g
-                g = fn.backward(c, g)[0]
-                if li > 0 and layers[li - 1][0] == "conv":        # conv -> conv inside a slice: mask by the ReLU output below
-                    y_prev = layers[li - 1][2].saved_tensors[2]
+                y_prev = layers[li - 1][2].saved_tensors[2] if li > 0 and layers[li - 1][0] == "conv" else None
+                fused = (FUSED_RELU_MASK and y_prev is not None and fn is Conv3x3Fn and y_prev.dtype == torch.bfloat16
+                         and y_prev.is_contiguous(memory_format=torch.channels_last))
+                c.out_mask = y_prev if fused else None            # conv -> conv inside a slice: mask by the ReLU output below,
+                g = fn.backward(c, g)[0]                          # in the data-gradient kernel's store ...
+                c.out_mask = None
+                if y_prev is not None and not fused:              # ... or as a pass of its own
                     g = torch.ops.aten.threshold_backward(g.to(y_prev.dtype), y_prev, 0)
         return g.to(ctx.in_dtype), None, None, None      # (ctx.layers stays: a retain_graph backward may come again)
 
@@ -656,21 +677,31 @@ def conv3x3_supported(x, weight, stride, padding):
             and weight.shape[1] % 64 == 0 and weight.shape[0] % 64 == 0)  # the data gradient swaps the two
 
 
-def _conv3x3_call(x_cl, wp, bias, Cout, relu):
+def _out_mask(mask, shape):
+    """the activation whose ReLU masks a data gradient, as the kernels read it: bf16 channels_last, the output's shape"""
+    if mask is None:
+        return None
+    assert tuple(mask.shape) == tuple(shape) and mask.dtype == torch.bfloat16 and mask.is_contiguous(memory_format=torch.channels_last)
+    return mask
+
+
+def _conv3x3_call(x_cl, wp, bias, Cout, relu, out_mask=None):
     B, Cin, H, W = x_cl.shape
     y = torch.empty((B, Cout, H, W), dtype=torch.bfloat16, device=x_cl.device, memory_format=torch.channels_last)
     b32 = None if bias is None else bias.detach().float().contiguous()
+    mk = _out_mask(out_mask, y.shape)
     with torch.cuda.device(x_cl.device):
-        rc = _lib.lib().xq_conv3x3_nhwc_bf16(ptr(x_cl), ptr(wp), ptr(b32), B, H, W, Cin, Cout, int(relu), ptr(y), _stream(x_cl))
+        rc = _lib.lib().xq_conv3x3_nhwc_bf16(ptr(x_cl), ptr(wp), ptr(b32), B, H, W, Cin, Cout, int(relu), ptr(mk), ptr(y), _stream(x_cl))
     check(rc, "xq_conv3x3_nhwc_bf16")
     return y
 
 
+FUSED_RELU_MASK = _os.environ.get("XQ_FUSED_RELU_MASK", "1") == "1"   # threshold_backward of the VGG walk in the dgrad kernels' stores
 CONV_ENGINE = _os.environ.get("XQ_CONV", "gemm")     # "gemm": implicit GEMM on the tile engine of csrc/xq_gemm.hip; "r1": csrc/xq_conv.hip
 CONV_SCHEDULE = int(_os.environ.get("XQ_CONV_SCHEDULE", "0"), 0)
 
 
-def conv3x3_gemm(x_cl, wp, bias, Cout, relu=False, stride=1, pad=1, upsample=False, transposed=False, out_hw=None):
+def conv3x3_gemm(x_cl, wp, bias, Cout, relu=False, stride=1, pad=1, upsample=False, transposed=False, out_hw=None, out_mask=None):
     """3x3 convolution (or, transposed, its data gradient) on the GEMM tile engine: xq_conv3x3_gemm_bf16.
     x_cl: (B, Cin, Hi, Wi) bf16 channels_last; wp: packed weights [Cout][9 * Cin]; returns (B, Cout, Ho, Wo) channels_last."""
     B, Cin, Hi, Wi = x_cl.shape
@@ -680,9 +711,10 @@ def conv3x3_gemm(x_cl, wp, bias, Cout, relu=False, stride=1, pad=1, upsample=Fal
     Ho, Wo = out_hw
     y = torch.empty((B, Cout, Ho, Wo), dtype=torch.bfloat16, device=x_cl.device, memory_format=torch.channels_last)
     b32 = None if bias is None else bias.detach().float().contiguous()
+    mk = _out_mask(out_mask, y.shape)
     with torch.cuda.device(x_cl.device):
         rc = _lib.lib().xq_conv3x3_gemm_bf16(ptr(x_cl), ptr(wp), ptr(b32), B, Hi, Wi, Cin, Cout, Ho, Wo, stride, pad, int(bool(upsample)),
-                                             int(bool(transposed)), int(bool(relu)), ptr(y), CONV_SCHEDULE, _stream(x_cl))
+                                             int(bool(transposed)), int(bool(relu)), ptr(mk), ptr(y), CONV_SCHEDULE, _stream(x_cl))
     check(rc, "xq_conv3x3_gemm_bf16")
     return y
 
@@ -785,11 +817,15 @@ class Conv3x3Fn(torch.autograd.Function):
         B, Cin, H, W = x_cl.shape
         if ctx.needs_input_grad[0]:
             wpd = _packed_conv_weight(weight, True)
+            # hand-driven walks (LpipsVggFn) hang the ReLU output of the layer below on the context: its mask goes into the store of g_x
+            mask = getattr(ctx, "out_mask", None) if mode == "s1" and FUSED_RELU_MASK else None
             if mode == "s1":
                 if _use_gemm_engine(B * H * W, Cin):
-                    g_x = conv3x3_gemm(g, wpd, None, Cin)
+                    g_x = conv3x3_gemm(g, wpd, None, Cin, out_mask=mask)
+                elif mask is not None and not _lib.lib().xq_conv3x3_nhwc_bf16_takes_out_mask(g.shape[1], Cin):
+                    g_x = torch.ops.aten.threshold_backward(_conv3x3_call(g, wpd, None, Cin, False), mask, 0)
                 else:
-                    g_x = _conv3x3_call(g, wpd, None, Cin, False)
+                    g_x = _conv3x3_call(g, wpd, None, Cin, False, out_mask=mask)
             elif mode == "down":
                 g_x = conv3x3_gemm(g, wpd, None, Cin, stride=2, pad=0, transposed=True, out_hw=(H, W))
             else:

@@ -68,6 +68,8 @@ def lecam_reg(real_pred, fake_pred, lecam_ema):
 FUSED_VGG_BACKWARD = __import__("os").environ.get("XQ_FUSED_VGG", "1") == "1"
 FUSED_DIFFAUG = __import__("os").environ.get("XQ_FUSED_DIFFAUG", "1") == "1"
 FUSED_SPECTRAL_NORM = __import__("os").environ.get("XQ_FUSED_SN", "1") == "1"
+# discriminator update: reconstruction and input share one pass over the frozen DINO-S trunk (DinoDisc.forward_pair)
+PAIRED_DISC_TRUNK = __import__("os").environ.get("XQ_PAIRED_DISC", "1") == "1"
 _VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]  # features[0:30]
 
 
@@ -316,7 +318,9 @@ class FrozenDINOSmallNoDrop(nn.Module):
         self.eval()
         [p.requires_grad_(False) for p in self.parameters()]
 
-    def forward(self, x, grad_ckpt=False) -> List[torch.Tensor]:
+    def preprocess(self, x):
+        """ImageNet normalisation of the [-1, 1] image + the random 224-crop / area resize (discriminator_dino.py:327-337): the part of
+        the forward that draws random numbers, split off so that two batches can share one pass over the frozen blocks (`trunk`)."""
         with torch.autocast(device_type=x.device.type, enabled=False):
             x = (self.x_scale * x.float()).add_(self.x_shift)
             H, W = x.shape[-2], x.shape[-1]
@@ -326,6 +330,13 @@ class FrozenDINOSmallNoDrop(nn.Module):
                 x = x[..., i:i + self.img_size, j:j + self.img_size]
             else:
                 x = F.interpolate(x, size=(self.img_size, self.img_size), mode='area' if H > self.img_size else 'bicubic')
+        return x
+
+    def forward(self, x, grad_ckpt=False) -> List[torch.Tensor]:
+        return self.trunk(self.preprocess(x))
+
+    def trunk(self, x) -> List[torch.Tensor]:
+        """patch embedding + the frozen blocks on a preprocessed (B, 3, 224, 224) batch; every op acts per sample"""
         from . import nn_ops
         x = nn_ops.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.patch_size)  # conv as GEMM
         with torch.autocast(device_type=x.device.type, enabled=False):
@@ -451,14 +462,31 @@ class DinoDisc(nn.Module):
         return super()._apply(fn, *a, **k)
 
     def forward(self, x_in_pm1, grad_ckpt=False):
-        acts = self.dino_proxy[0](x_in_pm1.float())
-        B = x_in_pm1.shape[0]
+        return self._heads(self.dino_proxy[0](x_in_pm1.float()))
+
+    def _heads(self, acts):
+        B = acts[0].shape[0]
         from . import nn_ops
-        if x_in_pm1.is_cuda and nn_ops.FUSED_BLOCKS:
+        if acts[0].is_cuda and nn_ops.FUSED_BLOCKS:
             from . import ops_dense
             if all(ops_dense.disc_head_supported(a, h) for h, a in zip(self.heads, acts)):
                 return torch.cat([ops_dense.disc_head(h, a) for h, a in zip(self.heads, acts)], dim=1)
         return torch.cat([h(a).view(B, -1) for h, a in zip(self.heads, acts)], dim=1)
+
+    def forward_pair(self, make_first, make_second):
+        """logits of two batches that need no gradient into the image (the discriminator update, vq_loss.py:226-261 calls the
+        discriminator on the detached reconstruction, then on the input): the frozen trunk acts per sample, so both batches go
+        through it in ONE pass of twice the rows — the D = 384 products of a 128-image batch fill 2.3 rounds of the chip's 256 CUs and
+        are bound by their epilogues, two of them back to back 4.6 — and the heads, whose spectral-norm power iteration and virtual-batch
+        statistics are per call upstream, run per batch in upstream's order.  `make_*` are called in order (augmentation draws, then
+        the crop draw of that batch), so the random streams are consumed exactly as by two separate forwards."""
+        d = self.dino_proxy[0]
+        xa = d.preprocess(make_first().float())
+        xb = d.preprocess(make_second().float())
+        Ba = xa.shape[0]
+        with torch.no_grad():
+            acts = d.trunk(torch.cat([xa, xb], dim=0))
+        return self._heads([a[:Ba] for a in acts]), self._heads([a[Ba:] for a in acts])
 
 
 # ---- VQLoss (vq_loss.py:80-261) -------------------------------------------------------------------------------------
@@ -568,9 +596,14 @@ class VQLoss(nn.Module):
         if optimizer_idx == 1:  # discriminator update (:226-261)
             from ._lib import marker
             marker(40)
-            logits_fake = self.discriminator(self.daug.aug(reconstructions.contiguous().detach(), fade_blur_schedule))
-            marker(41)
-            logits_real = self.discriminator(self.daug.aug(inputs.contiguous().detach(), fade_blur_schedule))
+            if PAIRED_DISC_TRUNK and hasattr(self.discriminator, "forward_pair") and reconstructions.is_cuda:
+                logits_fake, logits_real = self.discriminator.forward_pair(
+                    lambda: self.daug.aug(reconstructions.contiguous().detach(), fade_blur_schedule),
+                    lambda: self.daug.aug(inputs.contiguous().detach(), fade_blur_schedule))
+            else:
+                logits_fake = self.discriminator(self.daug.aug(reconstructions.contiguous().detach(), fade_blur_schedule))
+                marker(41)
+                logits_real = self.discriminator(self.daug.aug(inputs.contiguous().detach(), fade_blur_schedule))
             marker(42)
             disc_weight = adopt_weight(self.disc_weight, global_step, threshold=self.discriminator_iter_start)
             if self.lecam_loss_weight is not None:

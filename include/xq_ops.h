@@ -222,9 +222,13 @@ int xq_lpips_level_backward_fused(const void *f0, const void *f1, const float *w
 int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad, void *Wp, xq_stream_t stream);
 
 /* Y[b,y,x,n] = act(bias[n] + sum_{ky,kx,c} X[b,y+ky-1,x+kx-1,c] * W[n][c][ky][kx]); X [B][H][W][Cin], Y [B][H][W][Cout]
- * bf16 NHWC (= torch channels_last); bias fp32 [Cout] nullable; relu != 0 fuses ReLU.  Cin % 64 == 0, Cout % 64 == 0. */
+ * bf16 NHWC (= torch channels_last); bias fp32 [Cout] nullable; relu != 0 fuses ReLU.  Cin % 64 == 0, Cout % 64 == 0.
+ * out_mask (nullable): bf16 [B][H][W][Cout]; Y is zeroed where out_mask <= 0 — when the call computes a data gradient, the ReLU of the
+ * layer below (the trunk walk of lpips.py:118-155 backwards; autograd's threshold_backward pass) folded into the store.  Accepted
+ * where xq_conv3x3_nhwc_bf16_takes_out_mask(Cin, Cout) != 0, XQ_EINVAL otherwise (the caller then masks in a pass of its own). */
+int xq_conv3x3_nhwc_bf16_takes_out_mask(int Cin, int Cout);
 int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *bias, int B, int H, int W, int Cin, int Cout, int relu,
-                         void *Y, xq_stream_t stream);
+                         const void *out_mask, void *Y, xq_stream_t stream);
 
 /* Weight gradient of the same convolution (the trainable CNN encoder/decoder, xqgan_model.py:454-622):
  * dWp fp32 [Cout][9*Cin], k = (ky*3+kx)*Cin + c (the forward's packed order), ACCUMULATED with fp32 atomics — the caller
@@ -438,9 +442,11 @@ int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int6
  *                (Upsample, xqgan_model.py:682-686); stride 2 / pad 0 with Ho = Hi / 2 is Downsample (:697-704);
  *   transposed:  the data gradient of a forward conv of that stride / pad: x = dY [B][Hi][Wi][Cin = forward Cout], w_packed = the
  *                for_data_grad pack, y = dX [B][Ho][Wo] (Ho x Wo = the forward input size).
+ * out_mask (nullable): bf16 [B][Ho][Wo][Cout]; y is zeroed where out_mask <= 0 (see xq_conv3x3_nhwc_bf16).
  * Cin % 64 == 0, Cout % 8 == 0, Cout >= 64. */
 int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int Ho, int Wo,
-                         int stride, int pad, int upsample2x, int transposed, int relu, void *y, int impl, xq_stream_t stream);
+                         int stride, int pad, int upsample2x, int transposed, int relu, const void *out_mask, void *y, int impl,
+                         xq_stream_t stream);
 /* `batch` independent products in one launch (matrix i at a + i * stride_a etc., strides in elements): op NT / NN write bf16
  * c[M][N], op TN (a [K][M], b [K][N], K % 64 == 0) writes fp32 c[M][N].  Used by the single-head spatial attention of the CNN
  * AttnBlock (xqgan_model.py:646-656: 256 positions x 512 channels per image). */

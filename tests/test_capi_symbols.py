@@ -66,7 +66,9 @@ def test_argument_validation_returns_errors_without_a_gpu():
     assert l.xq_attn_forward(None, 2, 16, 4, 64, f1, one, one, None) != 0 and "null" in err()
     assert l.xq_attn_forward(None, 0, 16, 4, 64, f1, None, None, None) == 0          # empty batch is a no-op
     assert l.xq_attn_backward(one, one, one, one, 2, 0, 4, 64, f1, one, one, None) != 0
-    assert l.xq_conv3x3_nhwc_bf16(one, one, None, 1, 8, 8, 48, 64, 0, one, None) != 0 and "Cin" in err()
+    assert l.xq_conv3x3_nhwc_bf16(one, one, None, 1, 8, 8, 48, 64, 0, None, one, None) != 0 and "Cin" in err()
+    assert l.xq_conv3x3_nhwc_bf16(one, one, None, 1, 8, 8, 128, 128, 0, one, one, None) != 0 and "out_mask" in err()
+    assert l.xq_conv3x3_nhwc_bf16_takes_out_mask(64, 64) in (0, 1) and l.xq_conv3x3_nhwc_bf16_takes_out_mask(128, 128) == 0
     assert l.xq_conv3x3_wgrad_nhwc_bf16(one, one, 1, 8, 8, 64, 128, one, None) != 0 and "128" in err()
     assert l.xq_maxpool2x2_nhwc_bf16_forward(one, 1, 4, 4, 12, one, None) != 0
     assert l.xq_groupnorm_silu_forward(one, None, None, 1, 16, 96, 32, ctypes.c_float(1e-6), 1, one, one, one, one, None) != 0

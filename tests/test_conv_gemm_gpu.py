@@ -102,3 +102,33 @@ def test_conv3x3_fn_modes_forward_and_gradients(mode):
         scale = r.abs().max().item()
         err = (a - r).abs().max().item()
         assert err <= tol * scale, f"{mode} {name}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+# (B, C_of_g, H, W, C_of_gx): 256-column tiles on the persistent schedule (a ragged last row tile; two items per workgroup), 128-column
+# tiles on the simple schedule, and the 64 -> 64 kernel with LDS-resident weights (ragged tile edges)
+@pytest.mark.parametrize("shape", [(4, 256, 33, 32, 256), (16, 256, 64, 65, 512), (4, 128, 64, 64, 128), (2, 512, 16, 16, 512), (3, 64, 37, 45, 64)])
+def test_out_mask_in_the_data_gradient_store_equals_threshold_backward(shape):
+    """out_mask of xq_conv3x3_gemm_bf16 / xq_conv3x3_nhwc_bf16 (the ReLU of the layer below folded into the store of a data gradient:
+    the VGG walk of ops_dense.LpipsVggFn) = aten::threshold_backward of the unmasked result, bit for bit — including -0.0, tiny and
+    negative mask values."""
+    from imagefolder_amd import ops_dense as od
+    B, Cg, H, W, Cx = shape
+    torch.manual_seed(sum(shape))
+    g = torch.randn(B, Cg, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.nn.Parameter(torch.randn(Cg, Cx, 3, 3, device="cuda") * 0.05)
+    wpd = od._packed_conv_weight(w, True)
+    m = torch.relu(torch.randn(B, Cx, H, W, device="cuda")).to(torch.bfloat16)
+    m.view(-1)[::7] = -0.0
+    m.view(-1)[3::11] = 1e-38          # bf16 subnormal-range positive: > 0
+    m.view(-1)[5::13] = -1.0           # not a ReLU output, but threshold_backward's rule is y > 0
+    m = m.contiguous(memory_format=torch.channels_last)
+    if Cx >= 128:
+        plain = od.conv3x3_gemm(g, wpd, None, Cx)
+        masked = od.conv3x3_gemm(g, wpd, None, Cx, out_mask=m)
+    else:
+        assert od._lib.lib().xq_conv3x3_nhwc_bf16_takes_out_mask(Cg, Cx)
+        plain = od._conv3x3_call(g, wpd, None, Cx, False)
+        masked = od._conv3x3_call(g, wpd, None, Cx, False, out_mask=m)
+    want = torch.ops.aten.threshold_backward(plain, m, 0)
+    assert plain.abs().max() > 0 and (want == 0).float().mean() > 0.3
+    assert torch.equal(masked.view(torch.int16), want.view(torch.int16))

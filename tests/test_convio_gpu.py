@@ -38,6 +38,24 @@ def test_conv_from_rgb(Cout, relu, dtype):
     _cmp(b.grad, br.grad, 3e-3, "g_b")
 
 
+@pytest.mark.parametrize("Cout,dtype,B,H,W", [(64, torch.float32, 1, 37, 45), (128, torch.bfloat16, 2, 5, 3), (64, torch.float32, 5, 64, 64)])
+def test_conv_from_rgb_on_the_matrix_cores_ragged_tiles(Cout, dtype, B, H, W):
+    """conv3x3_from3_mfma_kernel: 32-pixel tiles that straddle image rows and images, a ragged last tile, maps narrower than a tile;
+    against F.conv2d in fp32 on the bf16-rounded operands to 1 bf16 ulp of each value (fp32 accumulation of exact products, one rounding)"""
+    from imagefolder_amd import ops_dense as od
+    torch.manual_seed(B * H + W)
+    x = (torch.rand(B, 3, H, W, device="cuda") * 2 - 1).to(dtype)
+    w = torch.randn(Cout, 3, 3, 3, device="cuda") * 0.2
+    b = torch.randn(Cout, device="cuda")
+    for relu in (False, True):
+        y = od.Conv3x3SmallCinFn.apply(x, w, b, relu)
+        ref = F.conv2d(x.to(torch.bfloat16).float(), w.to(torch.bfloat16).float(), b, padding=1)
+        ref = ref.relu() if relu else ref
+        assert tuple(y.shape) == tuple(ref.shape) and y.dtype == torch.bfloat16
+        err = (y.float() - ref).abs()
+        assert bool((err <= ref.abs() * 2.0 ** -8 + 3e-6).all()), float(err.max())
+
+
 @pytest.mark.parametrize("gdtype", [torch.float32, torch.bfloat16])
 def test_conv_to_rgb(gdtype):
     from imagefolder_amd import nn_ops

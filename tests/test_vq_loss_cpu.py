@@ -164,3 +164,28 @@ def test_diffaug_translation_is_the_upstream_padded_gather():
     out = _ShiftZeroFill.apply(x, th.view(B), tw.view(B))
     (go,) = torch.autograd.grad(out, x, g)
     assert torch.equal(out, ref) and torch.equal(go, gr)
+
+
+def test_discriminator_pair_pass_equals_two_forwards():
+    """DinoDisc.forward_pair (one pass over the frozen trunk for the two batches of the discriminator update) = two forwards in
+    upstream's order (vq_loss.py:226-261: fake, then real): same logits, same spectral-norm state afterwards, same random draws."""
+    import copy
+    from imagefolder_amd.vq_loss import DinoDisc
+    torch.manual_seed(0)
+    d1 = DinoDisc(depth=3, key_depths=(0, 2)).train()
+    d2 = copy.deepcopy(d1)
+    fake, real = torch.rand(16, 3, 256, 256) * 2 - 1, torch.rand(16, 3, 256, 256) * 2 - 1
+    for seed in (1, 2, 3):      # crop and resize branches of the preprocessing both come up
+        random.seed(seed)
+        torch.manual_seed(seed)
+        lf1, lr1 = d1(fake), d1(real)
+        random.seed(seed)
+        torch.manual_seed(seed)
+        lf2, lr2 = d2.forward_pair(lambda: fake, lambda: real)
+        assert torch.allclose(lf1, lf2, atol=1e-5, rtol=1e-5) and torch.allclose(lr1, lr2, atol=1e-5, rtol=1e-5)
+    for (n1, b1), (n2, b2) in zip(d1.named_buffers(), d2.named_buffers()):
+        assert n1 == n2 and torch.allclose(b1, b2, atol=1e-6), n1
+    (lf2.sum() - lr2.sum()).backward()
+    (lf1.sum() - lr1.sum()).backward()
+    for (n1, p1), (n2, p2) in zip(d1.named_parameters(), d2.named_parameters()):
+        assert torch.allclose(p1.grad, p2.grad, atol=1e-4, rtol=1e-4), n1
