@@ -100,6 +100,7 @@ SIGNATURES = {
     "xq_ms_area_pool": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv2d_f32_pack_weights": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv2d_f32_nhwc": (ctypes.c_int, [vp, vp, vp] + [ctypes.c_int] * 13 + [vp, vp]),
+    "xq_gemm_f32_tn": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_attention_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, vp, vp]),
     "xq_groupnorm_silu_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int,

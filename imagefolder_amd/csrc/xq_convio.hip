@@ -119,12 +119,16 @@ __global__ __launch_bounds__(256) void conv3x3_from3_mfma_kernel(const TIN *__re
                 const int k = 16 * s2 + 8 * hh + j;
                 wf[nb][s2][j] = (__bf16)(k < 27 ? Wk[k * C3_OUT + 32 * nb + li] : 0.0f);
             }
+    __shared__ __attribute__((aligned(16))) float sbias[C3_OUT];      // 16 LDS reads per tile instead of 4 * NB more registers per lane
+    if (threadIdx.x < C3_OUT) sbias[threadIdx.x] = bias ? bias[threadIdx.x] : 0.0f;
+    __syncthreads();
     const unsigned HW = (unsigned)H * (unsigned)W;
-    // a workgroup walks a CONTIGUOUS run of tiles, its four waves interleaved: the image rows a tile shares with the tiles one row up / down
-    // (W / 32 tiles away) are then fetched by the same CU a few iterations apart and come out of its L1, not once per XCD out of HBM
-    const unsigned per_block = ((ntiles + gridDim.x - 1u) / gridDim.x + 3u) & ~3u;
-    const unsigned t_end = min(ntiles, (blockIdx.x + 1u) * per_block);
-    for (unsigned t = blockIdx.x * per_block + (threadIdx.x >> 6); t < t_end; t += 4u) {
+    // tile t -> wave t mod (waves of the grid): at any moment the chip's waves store to ADJACENT 4 KiB runs of the output, spread over all HBM
+    // channels.  (Measured and dropped: one contiguous run of tiles per workgroup for L1 reuse of the image rows between vertically adjacent
+    // tiles — every workgroup then sits at the same offset of its 1 MiB run and the stores camp on a few channels: 170 -> 225 us on the
+    // bf16-input shape, profiles/r04_conv_from3.txt.)
+    const unsigned nwaves = gridDim.x * 4u;
+    for (unsigned t = blockIdx.x * 4u + (threadIdx.x >> 6); t < ntiles; t += nwaves) {
         const unsigned p = t * 32u + li;
         const bool live = p < total;
         const unsigned pp = live ? p : total - 1u;
@@ -145,10 +149,10 @@ __global__ __launch_bounds__(256) void conv3x3_from3_mfma_kernel(const TIN *__re
         char *yp = Y + (long)pp * (2 * C3_OUT) + 16 * hh;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            c3_f32x16 acc;      // starts from the bias (wave-uniform per half: 16-byte loads that hit L1)
+            c3_f32x16 acc;      // starts from the bias
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 b4 = bias ? *reinterpret_cast<const float4 *>(bias + 32 * nb + 8 * q + 4 * hh) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 b4 = *reinterpret_cast<const float4 *>(sbias + 32 * nb + 8 * q + 4 * hh);
                 acc[4 * q + 0] = b4.x; acc[4 * q + 1] = b4.y; acc[4 * q + 2] = b4.z; acc[4 * q + 3] = b4.w;
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nb][0], af[0], acc, 0, 0, 0);
@@ -406,7 +410,7 @@ extern "C" int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, con
     }
     const long tiles = (total + 31) / 32;
     long blocks = (tiles + 3) / 4;
-    const long cap = (long)num_cus() * (Cout == 128 ? 3 : 4);      // resident workgroups per CU at 137 / 121 VGPRs; each walks a contiguous run of tiles
+    const long cap = (long)num_cus() * (Cout == 128 ? 3 : 4);      // resident workgroups per CU at 137 / 121 VGPRs; each wave walks its tiles
     if (blocks > cap) blocks = cap;
 #define FROM3M(T, CO) hipLaunchKernelGGL((conv3x3_from3_mfma_kernel<T, CO>), dim3((unsigned)blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, relu, (char *)y_nhwc)
     if (x_is_bf16) { if (Cout == 128) FROM3M(__hip_bfloat16, 128); else FROM3M(__hip_bfloat16, 64); }

@@ -12,6 +12,8 @@
 //   attention_f32_kernel : softmax(q k^T * scale) v for one (batch, head, query) per wave — the ViT's SDPA
 //                          (vision_transformer.py:175-195) and the CNN AttnBlock (xqgan_model.py:635-659, one head of C dims).
 //   groupnorm_silu_f32   : GroupNorm(32, eps 1e-6) [+ x * sigmoid(x)] (xqgan_model.py:662-672), two-pass statistics in double.
+//   gemm_f32_tn_kernel   : dW = g^T x of nn.Linear (round 4): with conv2d_f32_kernel on W / W^T the three products of a Linear layer's
+//                          fp32 TRAINING step, so that the fp32 leg of the gradient-parity tests exercises hand-written kernels.
 #include "xq_common.hpp"
 #include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
@@ -164,6 +166,49 @@ __global__ __launch_bounds__(256) void groupnorm_silu_f32_kernel(const float *__
     }
 }
 
+// Weight gradient of nn.Linear in fp32 (round 4: the fp32 TRAINING leg of the parity tests runs its products on these kernels — forward
+// and data gradient are conv2d_f32_kernel with the weight / its transpose):  C[i][j] = sum_m A[m][i] * B[m][j], A [M][Na] = the output
+// gradient, B [M][Nb] = the layer input, C [Na][Nb] = dW.  64 x 64 outputs per block, 4 waves of 32 x 32, 16 rows of m per LDS stage; the
+// sum over m is ONE ascending fp32 fma chain per output (v_mfma_f32_32x32x2_f32 consumes m, m + 1 per instruction, in order): deterministic,
+// and the order a sequential CPU loop over the rows would use.  Blocks are not split over m — this is a parity path, not a fast one.
+__global__ __launch_bounds__(256) void gemm_f32_tn_kernel(const float *__restrict__ A, const float *__restrict__ Bm, long M, int Na, int Nb,
+                                                          float *__restrict__ C) {
+    __shared__ float As[16][68], Bs[16][68];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int i0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+    const int r = tid >> 4, cq = (tid & 15) * 4;      // staging: row r of the 16, columns cq .. cq + 3
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.0f;
+    for (long m0 = 0; m0 < M; m0 += 16) {
+        const long m = m0 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ia = i0 + cq + e, jb = j0 + cq + e;
+            As[r][cq + e] = (m < M && ia < Na) ? A[m * Na + ia] : 0.0f;
+            Bs[r][cq + e] = (m < M && jb < Nb) ? Bm[m * Nb + jb] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wi * 32 + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wj * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // D[i][j]: j = lane & 31, i = (q & 3) + 8 (q >> 2) + 4 (lane >> 5)
+    const int j = j0 + wj * 32 + (lane & 31);
+    if (j < Nb) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int i = i0 + wi * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+            if (i < Na) C[(long)i * Nb + j] = acc[q];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void pack_conv_weights_f32_kernel(const float *__restrict__ W, int Cout, int Cin, int KH, int KW,
                                                                     float *__restrict__ Wp) {
     const long o = (long)blockIdx.x * 256 + threadIdx.x;
@@ -200,6 +245,15 @@ extern "C" int xq_conv2d_f32_nhwc(const float *x, const float *w_packed, const f
     const long gx = (p.M + 63) / 64;
     if (gx > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: too many pixels", fn);
     hipLaunchKernelGGL(conv2d_f32_kernel, dim3((unsigned)gx, (unsigned)((Cout + 63) / 64)), dim3(256), 0, (hipStream_t)stream, p);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_gemm_f32_tn(const float *a, const float *b, int64_t M, int Na, int Nb, float *c, xq_stream_t stream) {
+    const char *fn = "xq_gemm_f32_tn";
+    if (M < 0 || Na < 1 || Nb < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (!c || (M > 0 && (!a || !b))) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(gemm_f32_tn_kernel, dim3((unsigned)((Na + 63) / 64), (unsigned)((Nb + 63) / 64)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       (long)M, Na, Nb, c);
     return xq_check_launch(fn);
 }
 

@@ -36,6 +36,9 @@ def _lib_ran(name, what):
 
 # ViT blocks as fused HIP row kernels + attention kernels + the hand-written GEMMs (ops_dense.run_blocks) instead of per-op ATen calls
 FUSED_BLOCKS = True
+# nn.Linear of an fp32 TRAINING step (autocast off) on the hand-written fp32-MFMA kernels (ops_f32.LinearF32Fn) instead of the library:
+# exact fp32 chains at 1/16 of the bf16 rate — the parity leg, not the product path (the reference trains under bf16 autocast)
+F32_TRAIN_LINEAR = __import__("os").environ.get("XQ_F32_TRAIN_LINEAR", "1") == "1"
 
 
 def vit_blocks(blocks, x, final_norm):
@@ -67,6 +70,9 @@ def linear(x, weight, bias=None):
     if ops_f32.eligible(x, weight, bias) and x.numel():
         IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"
         return ops_f32.linear(x, weight, bias)
+    if F32_TRAIN_LINEAR and x.numel() and ops_f32.trainable(x, weight, bias):
+        IMPL["linear_fp32_training"] = "hip (LinearF32Fn: xq_conv2d_f32_nhwc fwd / dgrad, xq_gemm_f32_tn wgrad — fp32 MFMA)"
+        return ops_f32.LinearF32Fn.apply(x, weight, bias)
     if x.is_cuda and x.numel() and weight.dim() == 2:
         act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else x.dtype
         if act == torch.bfloat16 and x.dtype in (torch.bfloat16, torch.float32):

@@ -268,7 +268,7 @@ class LinearFn(torch.autograd.Function):
         from . import nn_ops
         shp = x.shape
         x2 = x.detach().reshape(-1, shp[-1])
-        hip = False
+        hip = f32 = False
         pad_k = pad_n = 0
         n_out = weight.shape[0]
         if x2.dtype == torch.bfloat16:
@@ -303,10 +303,17 @@ class LinearFn(torch.autograd.Function):
                 # fp32 inference (the reference-parity path): exact fp32 MFMA product, no library call
                 nn_ops.IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"
                 return ops_f32.linear(x2, W, b).view(*shp[:-1], W.shape[0])
-        if not hip:
+            if nn_ops.F32_TRAIN_LINEAR and x2.numel() and W.dim() == 2 and ops_f32.trainable(x2, W, b):
+                # fp32 training (the parity leg): the same exact fp32 MFMA product, and its two gradients in backward()
+                f32 = True
+                x2, W = x2.contiguous(), W.contiguous()
+                y = ops_f32._rows_times(x2, W, None if b is None else b.contiguous())
+                nn_ops.IMPL["linear_fp32_training"] = "hip (xq_conv2d_f32_nhwc fwd / dgrad, xq_gemm_f32_tn wgrad — fp32 MFMA)"
+        if not hip and not f32:
             y = torch.addmm(b, x2, W.t()) if b is not None else torch.mm(x2, W.t())
         ctx.save_for_backward(x2, W)
         ctx.meta = (shp, weight.dtype, bias is not None and not bias_grad_external, bias is not None, hip, pad_k, pad_n, tuple(weight.shape))
+        ctx.f32 = f32
         return y.reshape(*shp[:-1], n_out)
 
     @staticmethod
@@ -319,16 +326,27 @@ class LinearFn(torch.autograd.Function):
         hip = hip and g2.dtype == torch.bfloat16 and g2.shape[0] > 0
         g_x = g_w = None
         gp = F.pad(g2, (0, pad_n)) if (hip and pad_n) else g2       # zero columns for the padded outputs
+        f32 = ctx.f32 and g2.dtype == torch.float32 and g2.shape[0] > 0
+        if f32:
+            from . import ops_f32
         if ctx.needs_input_grad[0]:
             if hip:
                 g_x = gemm_nn(gp, W)
                 g_x = (g_x[:, :wshape[1]] if pad_k else g_x).reshape(shp)
+            elif f32:
+                g_x = ops_f32._rows_times(g2, W.t().contiguous(), None).view(shp)
             else:
                 g_x = torch.mm(g2, W).view(shp)
         if ctx.needs_input_grad[1]:
             if hip:
                 g_w = gemm_tn(gp, x2)
                 g_w = (g_w[:wshape[0], :wshape[1]] if (pad_k or pad_n) else g_w).to(wdtype)
+            elif f32:
+                g_w = torch.empty(W.shape, dtype=torch.float32, device=g2.device)
+                with torch.cuda.device(g2.device):
+                    rc = _lib.lib().xq_gemm_f32_tn(ptr(g2), ptr(x2), g2.shape[0], W.shape[0], W.shape[1], ptr(g_w), _stream(g2))
+                check(rc, "xq_gemm_f32_tn")
+                g_w = g_w.to(wdtype)
             else:
                 g_w = _weight_grad(g2, x2, wdtype)
         g_b = None
@@ -851,7 +869,14 @@ def _planar(t):
     return t.contiguous()
 
 
+FROM3_CAST = _os.environ.get("XQ_FROM3_CAST", "1") == "1"
+
+
 def _from3(x_planar, w_kc, bias, Cout, relu=False):
+    if FROM3_CAST and x_planar.dtype == torch.float32:
+        # the kernel rounds the image to bf16 anyway (autocast); rounding it ONCE in a 150 MB pass instead of in each of the 9 gathers
+        # halves the bytes the gathers pull through L1, whose 32 KiB the 16 waves' 3 x 3-row windows otherwise overflow
+        x_planar = x_planar.to(torch.bfloat16)
     B, _, H, W = x_planar.shape
     y = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=x_planar.device)
     b32 = None if bias is None else bias.detach().float().contiguous()

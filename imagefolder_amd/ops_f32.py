@@ -2,7 +2,9 @@
 
 BASELINE.json: reconstructions within 1e-4 (fp32) of the reference CPU path.  nn_ops routes here when the activations are
 fp32 CUDA tensors outside autocast and nothing needs a gradient (inference: img_to_reconstructed_img, img_to_idx, the
-model-level parity tests); training runs the bf16 kernels.  No autograd, no CPU fallback."""
+model-level parity tests); training runs the bf16 kernels — except nn.Linear, whose fp32 training step (forward, data gradient,
+weight gradient) also runs here (LinearF32Fn) so that the fp32 leg of the gradient-parity tests exercises hand-written kernels.
+No CPU fallback."""
 import ctypes
 
 import torch
@@ -87,6 +89,69 @@ def linear(x, weight, bias=None):
             rc = _lib.lib().xq_conv2d_f32_nhwc(ptr(x2), ptr(w), ptr(b), 1, M, 1, K, N, 1, 1, 1, 0, 0, M, 1, 0, ptr(y), _stream(x))
         check(rc, "xq_conv2d_f32_nhwc")
     return y.view(*shp[:-1], N)
+
+
+def trainable(*tensors):
+    """fp32 CUDA tensors, autocast off — a gradient may be wanted (the fp32 TRAINING leg of the parity tests)"""
+    if torch.is_autocast_enabled("cuda"):
+        return False
+    return all(t is None or (t.is_cuda and t.dtype == torch.float32) for t in tensors)
+
+
+def _rows_times(x2, w_nk, bias):
+    """y[M][N] = x2[M][K] . w_nk[N][K]^T (+ bias) on conv2d_f32_kernel (a 1 x 1 convolution over M pixels)"""
+    M, K = x2.shape
+    N = w_nk.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x2.device)
+    if M:
+        with torch.cuda.device(x2.device):
+            rc = _lib.lib().xq_conv2d_f32_nhwc(ptr(x2), ptr(w_nk), ptr(bias), 1, M, 1, K, N, 1, 1, 1, 0, 0, M, 1, 0, ptr(y), _stream(x2))
+        check(rc, "xq_conv2d_f32_nhwc")
+    return y
+
+
+class LinearF32Fn(torch.autograd.Function):
+    """nn.Linear in fp32 WITH its backward on the hand-written fp32-MFMA kernels (csrc/xq_f32.hip): y = x W^T + b on conv2d_f32_kernel,
+    g_x = g W on the same kernel with the transposed weight, g_W = g^T x on gemm_f32_tn_kernel, g_b = column sums on xq_colsum.  Every
+    output is one ascending fp32 fma chain.  This is what the fp32 leg of tests/test_train_backward_parity.py trains through (the bf16
+    leg runs the tile engine of csrc/xq_gemm.hip): the three products of every Linear layer on our own kernels in BOTH precisions."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shp = x.shape
+        x2 = x.detach().reshape(-1, shp[-1]).contiguous()
+        N = weight.shape[0]
+        w = weight.detach().reshape(N, -1).contiguous()
+        b = None if bias is None else bias.detach().contiguous()
+        ctx.save_for_backward(x2, w)
+        ctx.shp, ctx.wshape, ctx.has_bias = shp, weight.shape, bias is not None
+        return _rows_times(x2, w, b).view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, g):
+        x2, w = ctx.saved_tensors
+        N, K = w.shape
+        g2 = g.detach().reshape(-1, N).float().contiguous()
+        M = g2.shape[0]
+        g_x = g_w = g_b = None
+        if ctx.needs_input_grad[0]:
+            g_x = _rows_times(g2, w.t().contiguous(), None).view(ctx.shp)
+        if ctx.needs_input_grad[1]:
+            g_w = torch.empty(N, K, dtype=torch.float32, device=g2.device)
+            with torch.cuda.device(g2.device):
+                rc = _lib.lib().xq_gemm_f32_tn(ptr(g2), ptr(x2), M, N, K, ptr(g_w), _stream(g2))
+            check(rc, "xq_gemm_f32_tn")
+            g_w = g_w.view(ctx.wshape)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if N % 4 or M == 0:
+                g_b = g2.sum(0)        # below xq_colsum's 16-byte vector (1-channel heads)
+            else:
+                g_b = torch.empty(N, dtype=torch.float32, device=g2.device)
+                part = torch.empty(_lib.lib().xq_row_partials_blocks(M * 4) * N, dtype=torch.float32, device=g2.device)
+                with torch.cuda.device(g2.device):
+                    rc = _lib.lib().xq_colsum(ptr(g2), M, N, 0, ptr(g_b), 0, ptr(part), _stream(g2))
+                check(rc, "xq_colsum")
+        return g_x, g_w, g_b
 
 
 def attention_qkvpacked(qkv, num_heads):

@@ -366,7 +366,8 @@ int xq_ms_phi_accumulate(const float *u, int B, int C, int H, int W, const float
 int xq_ms_area_pool(const float *in, int B, int C, int H, int W, int pn, float *out, xq_stream_t stream);
 
 /* ---- fp32 forward kernels of the encoder / decoder layers: the reference-parity path (csrc/xq_f32.hip).  Exact fp32 fma chains
- *      on v_mfma_f32_32x32x2_f32, IEEE expf / sqrt / division; inference only (no backward).  Activations NHWC fp32. ---------- */
+ *      on v_mfma_f32_32x32x2_f32, IEEE expf / sqrt / division; inference, plus the three products of nn.Linear's training step.
+ *      Activations NHWC fp32. ------------------------------------------------------------------------------------------------------ */
 /* w_packed[n][(ky * KW + kx) * Cin + c] = w_oihw[n][c][ky][kx] */
 int xq_conv2d_f32_pack_weights(const float *w_oihw, int Cout, int Cin, int KH, int KW, float *w_packed, xq_stream_t stream);
 /* y[B][Ho][Wo][Cout] = conv(x[B][Hi][Wi][Cin]) (+ bias): kernel 1x1 or 3x3, stride 1 or 2, pad_top / pad_left zeros before the
@@ -375,6 +376,10 @@ int xq_conv2d_f32_pack_weights(const float *w_oihw, int Cout, int Cin, int KH, i
  * of x (Upsample, :682-686) without it being materialised.  Hi = Wi = Ho = Wo = 1, B = rows: y = x . w^T + b (nn.Linear). */
 int xq_conv2d_f32_nhwc(const float *x, const float *w_packed, const float *bias, int B, int Hi, int Wi, int Cin, int Cout, int KH, int KW,
                        int stride, int pad_top, int pad_left, int Ho, int Wo, int upsample2x, float *y, xq_stream_t stream);
+/* c[Na][Nb] = a[M][Na]^T . b[M][Nb] in fp32, each output one ascending fma chain over the M rows (deterministic): the weight gradient
+ * dW = g^T x of nn.Linear on the fp32 parity path (its forward and data gradient are xq_conv2d_f32_nhwc with Hi = Wi = 1 on W and on
+ * W^T).  M = 0 writes zeros. */
+int xq_gemm_f32_tn(const float *a, const float *b, int64_t M, int Na, int Nb, float *c, xq_stream_t stream);
 /* out[b][i][h][:] = sum_j softmax_j(q_i . k_j * scale) v_j per (batch, head); element (b, token t, head h, d) of q / k / v lives at
  * b * batch_stride + t * token_stride + h * hd + d (ViT packed qkv: three pointers into one [B][N][3][H][hd] buffer;
  * CNN AttnBlock, xqgan_model.py:635-659: H = 1, hd = C); out is [B][N][H][hd] contiguous. */

@@ -331,14 +331,24 @@ def gen_train_forward(name, kw, B, alpha, beta, delta, seed):
         t = real_randint(*a, **k)
         draws["randint"].append((tuple(int(v) for v in a[:2] if isinstance(v, int)), t.detach().cpu().clone()))
         return t
+    # the `delta` nearest codes of add_perturbation (latent_perturbation.py:20: topk(d, delta, largest=False)), values and indices, of the
+    # tokens of the perturbed samples: with them a test can tell a wrong pick from a pick of the SAME distance rank on a near-tie
+    topk_rec = []
+    real_topk = torch.topk
+
+    def rec_topk(*a, **k):
+        out = real_topk(*a, **k)
+        if k.get("largest", True) is False and len(a) >= 2 and int(a[1]) == int(delta):
+            topk_rec.append((out[0].detach().cpu().clone(), out[1].detach().cpu().clone()))
+        return out
     timm_shim.DropPath.RECORD = []
     torch.manual_seed(seed + 17)
-    torch.rand, torch.randint = rec_rand, rec_randint
+    torch.rand, torch.randint, torch.topk = rec_rand, rec_randint, rec_topk
     try:
         with contextlib.redirect_stdout(io.StringIO()):          # the forward prints (alpha, beta, delta) every call (:296)
             dec, (vq, commit, ent, usages), sem, detail, dep = m(x, 0, alpha, beta, delta)
     finally:
-        torch.rand, torch.randint = real_rand, real_randint
+        torch.rand, torch.randint, torch.topk = real_rand, real_randint, real_topk
         masks = timm_shim.DropPath.RECORD
         timm_shim.DropPath.RECORD = None
     P, SN = kw["product_quant"], len(kw["v_patch_nums"])
@@ -348,12 +358,17 @@ def gen_train_forward(name, kw, B, alpha, beta, delta, seed):
     lp_idx = [t for (_, t) in draws["randint"] if tuple(t.shape) == (N,)]
     assert len(dropout_rand) == (1 if SN > 1 else 0), (len(dropout_rand), SN)
     assert len(lp_prob) == len(lp_idx) == (1 if P == 1 else 0)
+    assert len(topk_rec) == len(lp_prob)
+    n_pert_tok = int(B * beta) * kw["num_latent_tokens"]
+    lp_topk_val = topk_rec[0][0][:n_pert_tok].numpy().astype(np.float32) if topk_rec else np.zeros((0, 0), np.float32)
+    lp_topk_idx = topk_rec[0][1][:n_pert_tok].numpy().astype(np.int32) if topk_rec else np.zeros((0, 0), np.int32)
     dec = dec.detach()
     np.savez(os.path.join(OUT, name + ".npz"), seed=np.int32(seed), B=np.int32(B), alpha=np.float32(alpha), beta=np.float32(beta),
              delta=np.int32(delta), droppath=torch.stack(masks).numpy() if masks else np.zeros((0, B), np.float32),
              dropout_rand=dropout_rand[0].numpy().astype(np.int64) if dropout_rand else np.zeros(0, np.int64),
              lp_prob=lp_prob[0].numpy() if lp_prob else np.zeros(0, np.float32),
              lp_idx=lp_idx[0].numpy().astype(np.int64) if lp_idx else np.zeros(0, np.int64),
+             lp_topk_val=lp_topk_val, lp_topk_idx=lp_topk_idx,
              dec_sub=dec[:, :, ::4, ::4].contiguous().numpy(), dec_mean=np.float64(dec.double().mean()), dec_l2=np.float64(dec.double().square().mean().sqrt()),
              dec_absmax=np.float32(dec.abs().max()), vq=np.float32(float(vq)), commit=np.float32(float(commit)), entropy=np.float32(float(ent)),
              usages=np.array(usages, np.float32), sem=np.float32(float(sem)), dep=np.float32(float(dep)), meta=np.array(str(meta())))
@@ -611,8 +626,10 @@ def main():
         gen_msvq("msvq_var_models_quant_v512_c32_b4", 512, 32, 4, [1, 2, 3, 4, 5, 6, 8, 10], seed=23, var_variant=True)
         if only:
             return
-    if only == "train":
+    if only in ("train", "train5"):
         for i, (nm, (kw, B, al, be, de)) in enumerate(TRAIN_CASES.items()):
+            if only == "train5" and "cfg5" not in nm:
+                continue
             gen_train_forward(nm, kw, B, al, be, de, seed=60 + i)
         return
     if only == "tokens":

@@ -9,9 +9,10 @@ LPIPS / GAN terms need downloaded checkpoints); gradients of ~25 parameter tenso
 recorded twice — fp32, and under torch.autocast('cpu', bfloat16): the reference's own reduced-precision backward.
 
 Checked here on the MI355X:
-  (a) fp32 step (HIP quantizers + perturbation with their hand-written backward; fp32 TRAINING runs the dense layers on ATen, the
-      hand-written dense kernels are the bf16 ones of (b)): every tapped gradient within REL_F32 of the reference's fp32 gradient
-      (relative L2 over the sub-sample);
+  (a) fp32 step (HIP quantizers + perturbation with their hand-written backward; every nn.Linear — forward, data gradient, weight
+      gradient — on the hand-written fp32-MFMA kernels of csrc/xq_f32.hip since round 4 (ops_dense.LinearFn's fp32 branch / ops_f32.LinearF32Fn;
+      asserted below through nn_ops.IMPL); attention and the element-wise backward passes of this leg are ATen's): every tapped gradient
+      within REL_F32 of the reference's fp32 gradient (relative L2 over the sub-sample);
   (b) the bf16 TRAINING path (hand-written bf16 MFMA GEMMs fwd / dgrad / wgrad, attention fwd / bwd, fused row kernels, quantizer
       backward): its distance to the reference's fp32 gradient is bounded by the distance of the reference's OWN bf16-autocast
       backward to it (x SLACK + FLOOR) — tensor by tensor;
@@ -109,7 +110,12 @@ def test_model_level_gradients_match_the_reference_autograd(name, monkeypatch):
     assert len(taps) >= 20
     # ---- (a) fp32 ----
     lr = 1e-4
+    from imagefolder_amd import nn_ops
+    nn_ops.IMPL.pop("linear_fp32_training", None)
+    nn_ops.IMPL.pop("linear_library", None)
     loss32, g32, after32, seed = _run(name, None, monkeypatch, lr=lr)
+    # the Linear layers of this leg ran on the hand-written fp32-MFMA kernels (forward, data gradient, weight gradient), none on the library
+    assert nn_ops.IMPL.get("linear_fp32_training", "").startswith("hip") and "linear_library" not in nn_ops.IMPL
     np.testing.assert_allclose(loss32, float(gb["loss_f32"]), rtol=1e-4 if name == "train_bwd_cfg5_robusttok" else 5e-6)
     rows = []
     for n in taps:

@@ -5,8 +5,9 @@ Goldens (oracle/make_golden.py gen_train_forward): the unmodified reference mode
 with EVERY random draw of the pass recorded — the DropPath masks of the 24 transformer blocks, the per-sample quantizer
 dropout depths, the two draws of add_perturbation.  The mirror replays them ("pass RNG draws as tensors") and runs
 its fp32 path on the GPU: HIP quantizers / perturbation + fused row kernels + the fp32-MFMA kernels of csrc/xq_f32.hip.
-Bounds: pixels 1e-4 on at least 97 % of the (4x-subsampled) decoder output — a token that sits on an fp32 near-tie may flip
-and legitimately change its 16 x 16 patch; codebook / commitment / semantic losses 2e-3 relative."""
+Bounds: pixels 1e-4 on >= 99.99 % of the (4x-subsampled) decoder output of every sample whose perturbed tokens all picked the reference's
+code; a perturbed token may pick another code only on a tie of the reference's own sorted distances (checked against the top-delta lists
+recorded in the golden); codebook / commitment / semantic losses 2e-3 relative."""
 import numpy as np
 import pytest
 import torch
@@ -61,6 +62,16 @@ def test_train_mode_forward_matches_reference(name, monkeypatch):
             assert n_tokens == rank.numel()
             return rank.to(device)
         monkeypatch.setattr(latent_perturbation, "draw_ranks", draw)
+    # the codes the perturbation kernel picked (ops.perturb_forward_raw returns them): compared below with the reference's own top-k lists
+    from imagefolder_amd import ops
+    picked = []
+    real_perturb = ops.perturb_forward_raw
+
+    def perturb(*a, **k):
+        out, sel = real_perturb(*a, **k)
+        picked.append(sel)
+        return out, sel
+    monkeypatch.setattr(ops, "perturb_forward_raw", perturb)
     try:
         with torch.no_grad():
             dec, (vq, commit, ent, usages), sem, detail, dep = m(x, 0, float(g["alpha"]), float(g["beta"]), int(g["delta"]))
@@ -72,8 +83,36 @@ def test_train_mode_forward_matches_reference(name, monkeypatch):
     frac = float(np.mean(np.abs(diff) <= 1e-4))
     print(f"{name}: pixels within 1e-4: {100 * frac:.2f} %, max |diff| {np.abs(diff).max():.2e}; vq {float(vq):.6f} / {float(g['vq']):.6f}; "
           f"sem {float(sem):.6f} / {float(g['sem']):.6f}; usages {usages[:3]} / {g['usages'][:3]}")
-    # measured (profiles/r04_parity_measured.txt): 100.00 % of the pixels within 1e-4 on all four configs, max |diff| 5.6e-6 .. 7.6e-6
-    assert frac >= 0.9999, f"only {100 * frac:.2f} % of the pixels within 1e-4 (max {np.abs(diff).max():.3e})"
+    # measured (profiles/r04_parity_measured.txt): 100.00 % of the pixels within 1e-4 on all four configs, max |diff| 5.6e-6 .. 7.6e-6 —
+    # as long as every perturbed token picks the reference's code.  add_perturbation replaces a token by the code of distance RANK r among
+    # the `delta` nearest (latent_perturbation.py:20-24); the reference's own sorted distances hold exact and 1e-7 ties between neighbouring
+    # ranks (0.05 % of the gaps of this golden are below 1e-6, the smallest is 0.0), so a latent that agrees with the reference's to 1e-6
+    # can land on the neighbour of equal distance ("parity on exact ties is only defined up to the chosen code's distance") and
+    # the decoder's attention then spreads that token over the whole sample.  So: samples without a flipped pick must match to 1e-4;
+    # every flipped pick must be IN the reference's top-delta list at a distance within TIE of the reference's rank-r distance.
+    n_pert = int(B * float(g["beta"])) if len(g["lp_prob"]) else 0
+    flipped_samples = set()
+    if n_pert:
+        assert len(picked) == 1 and picked[0] is not None
+        sel = picked[0].cpu().numpy()
+        ref_idx, ref_val = g["lp_topk_idx"], g["lp_topk_val"]
+        r = rank[:sel.size].numpy()
+        rows = np.arange(sel.size)
+        flips = np.nonzero(sel != ref_idx[rows, r])[0]
+        TIE = 5e-6
+        for t in flips:
+            pos = np.nonzero(ref_idx[t] == sel[t])[0]
+            assert pos.size == 1, f"token {t}: picked code {sel[t]} is not among the reference's {ref_idx.shape[1]} nearest"
+            gap = abs(float(ref_val[t, pos[0]]) - float(ref_val[t, r[t]]))
+            assert gap <= TIE, f"token {t}: picked rank {pos[0]} instead of {r[t]}, distances {gap:.3e} apart — not a tie"
+            flipped_samples.add(int(t) // (sel.size // n_pert))
+        print(f"{name}: {flips.size} of {sel.size} perturbed tokens picked a code other than the reference's (all ties within {TIE:g}); samples {sorted(flipped_samples)}")
+        assert flips.size <= 4
+    clean = [b for b in range(B) if b not in flipped_samples]
+    frac_clean = float(np.mean(np.abs(diff[clean]) <= 1e-4))
+    assert frac_clean >= 0.9999, f"only {100 * frac_clean:.2f} % of the pixels of the samples without a tie flip within 1e-4 (max {np.abs(diff[clean]).max():.3e})"
+    if flipped_samples:
+        assert np.isfinite(diff).all() and np.abs(diff[sorted(flipped_samples)]).max() <= 0.5
     np.testing.assert_allclose(float(vq), float(g["vq"]), rtol=2e-3)
     np.testing.assert_allclose(float(commit), float(g["commit"]), rtol=2e-3)
     np.testing.assert_allclose(float(sem), float(g["sem"]), rtol=2e-3, atol=1e-5)

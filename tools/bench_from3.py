@@ -23,7 +23,7 @@ def timed(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
-tag = "VALU" if os.environ.get("XQ_FROM3_VALU") == "1" else "MFMA"
+tag = ("VALU" if os.environ.get("XQ_FROM3_VALU") == "1" else "MFMA") + (" cast-once" if od.FROM3_CAST else " fp32-gather")
 for B, Cout, HW, dt in [(128, 64, 256, torch.float32), (32, 128, 256, torch.float32), (32, 128, 256, torch.bfloat16)]:
     x = (torch.rand(B, 3, HW, HW, device="cuda") * 2 - 1).to(dt)
     w = torch.randn(Cout, 3, 3, 3, device="cuda") * 0.2
