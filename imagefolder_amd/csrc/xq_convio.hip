@@ -3,11 +3,11 @@
 //   conv_in  (xqgan_model.py:495: Conv2d(3, 128, 3, 1, 1) on the image)            K = 27:  6.9 kFLOP and 262 B per pixel
 //   conv_out (xqgan_model.py:584: Conv2d(128, 3, 3, 1, 1) producing the pixels)    N = 3:   the same, mirrored
 // Both are HBM-bound (SURVEY.md §8d names conv_in as the layer to report GB/s on): a 128-channel NHWC activation row is read
-// or written once per pixel; the matrix cores have nothing to contribute at 3 channels (an MFMA tile would be > 90 % padding).
-// One thread per pixel, the weights come in through SCALAR loads (uniform index -> s_load, an SGPR operand of every FMA):
-//   conv3x3_from3_kernel : planar 3-channel input [B][3][H][W] (fp32 image or bf16 gradient) -> NHWC bf16 [B][H][W][128]:
-//                          27 x 128 v_fmac with an SGPR weight per pixel (= the fp32 VALU time of the HBM traffic);
-//                          conv_in forward, and the data gradient of conv_out (same kernel on the rotated weights);
+// or written once per pixel.  Rounds 1-3 assumed the matrix cores had nothing to contribute at 3 channels; that holds for conv_out (N = 3
+// output columns: > 90 % of a tile is padding) but not for conv_in, where the 3 channels are on the K side: 27 taps pad to K = 32.
+//   conv3x3_from3_mfma_kernel : planar 3-channel input [B][3][H][W] (fp32 image or bf16 gradient) -> NHWC bf16 [B][H][W][64 | 128] on the
+//                          matrix cores, K = 27 padded to 32 (round 4; before: one thread per pixel, 27 x Cout v_fmac, VALU-bound);
+//                          conv_in forward, VGG conv1_1, and the data gradient of conv_out (same kernel on the rotated weights);
 //   conv3x3_to3_kernel   : NHWC bf16 [B][H][W][C] -> planar bf16 [B][3][H][W]: 9 x C/2 v_dot2c_f32_bf16 per output channel;
 //                          conv_out forward;
 //   im2col27_kernel      : the 27 (+5 zero) taps of every pixel as a [pixels][32] bf16 matrix: the weight gradient of conv_in is then
@@ -37,56 +37,17 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {
 }
 
 
-// Wk: fp32 [27][128], k = (ky * 3 + kx) * 3 + ci (values already rounded to bf16); bias fp32 [128] or null
-template <typename TIN, int C3_OUT>
-__global__ __launch_bounds__(256) void conv3x3_from3_kernel(const TIN *__restrict__ X, const float *__restrict__ Wk, const float *__restrict__ bias,
-                                                            int B, int H, int W, int relu, __hip_bfloat16 *__restrict__ Y) {
-    const long p = (long)blockIdx.x * 256 + threadIdx.x;
-    const long total = (long)B * H * W;
-    if (p >= total) return;
-    const int x = (int)(p % W), y = (int)((p / W) % H);
-    const long b = p / ((long)W * H);
-    float in[27];
-#pragma unroll
-    for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int yy = y + ky - 1, xx = x + kx - 1;
-            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci)
-                in[(ky * 3 + kx) * 3 + ci] = ok ? ld_in(X + ((b * 3 + ci) * H + yy) * (long)W + xx) : 0.0f;
-        }
-    uint4 *out = reinterpret_cast<uint4 *>(Y + p * C3_OUT);
-#pragma unroll
-    for (int c0 = 0; c0 < C3_OUT; c0 += 32) {        // 32 accumulators at a time: 4 passes over the 27 taps
-        float acc[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) acc[j] = bias ? bias[c0 + j] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 27; ++k)
-#pragma unroll
-            for (int j = 0; j < 32; ++j) acc[j] = __builtin_fmaf(in[k], Wk[k * C3_OUT + c0 + j], acc[j]);
-        if (relu) {
-#pragma unroll
-            for (int j = 0; j < 32; ++j) acc[j] = fmaxf(acc[j], 0.0f);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            out[c0 / 8 + q] = make_uint4(pack2(acc[8 * q + 0], acc[8 * q + 1]), pack2(acc[8 * q + 2], acc[8 * q + 3]),
-                                         pack2(acc[8 * q + 4], acc[8 * q + 5]), pack2(acc[8 * q + 6], acc[8 * q + 7]));
-    }
-}
-
-// The same convolution on the matrix cores (round 4).  K = 27 padded to 32 = two k-steps of v_mfma_f32_32x32x16_bf16: 16 % padding, not the
+// conv3x3_from3 on the matrix cores (round 4; rounds 1-3: one thread per pixel, 27 x Cout v_fmac with SGPR weights — VALU-bound at 1.6-1.8 TB/s,
+// profiles/r04_conv_from3.txt).  Wk: fp32 [27][C3_OUT], k = (ky * 3 + kx) * 3 + ci (values already rounded to bf16); bias fp32 [C3_OUT] or null.
+// K = 27 padded to 32 = two k-steps of v_mfma_f32_32x32x16_bf16: 16 % padding, not the
 // "> 90 %" the header feared for a 3-channel tile — the padding is along K, the 32 x 32 output tile is 32 pixels x 32 output channels, all
 // live.  One wave = 32 consecutive pixels x all C3_OUT channels per tile, persistent over tiles: lane (li, hh) gathers the 16 taps
 // k = 16 s + 8 hh + j of pixel li straight from the planar image (consecutive lanes = consecutive pixels: coalesced; every input value
 // is fetched 9 times, from L1), rounds them to bf16 as autocast does, and the weights sit in registers as bf16 fragments for the life of the
-// wave.  27 fp32 FMAs per output element on the VALU (the kernel above: 1.8 TB/s, VALU-bound) become 2 MFMAs per 32 x 32 outputs; what is
+// wave.  27 fp32 FMAs per output element on the VALU become 2 MFMAs per 32 x 32 outputs; what is
 // left is the 2 * C3_OUT bytes per pixel of the store (16 bytes per lane through v_permlane32_swap, as conv3x3_c64_kernel).
 // Accumulation starts from the bias, k ascending inside the MFMA: fp32 sums of the same 27 exact bf16 x bf16 products as the VALU kernel, in
-// another order (results agree to fp32 rounding, i.e. an occasional bf16 ulp).
+// another order (results agree with the VALU kernel's to fp32 rounding, i.e. an occasional bf16 ulp).
 typedef __bf16 c3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float c3_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -398,16 +359,6 @@ extern "C" int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, con
     const long total = (long)B * H * W;
     if (total * 3 >= 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: image batch too large for 32-bit pixel indices", fn);
     hipStream_t s = (hipStream_t)stream;
-    static const bool valu = [] { const char *e = getenv("XQ_FROM3_VALU"); return e && e[0] == '1'; }();
-    if (valu) {
-        const unsigned blocks = (unsigned)((total + 255) / 256);
-        __hip_bfloat16 *y = (__hip_bfloat16 *)y_nhwc;
-#define FROM3(T, CO) hipLaunchKernelGGL((conv3x3_from3_kernel<T, CO>), dim3(blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, relu, y)
-        if (x_is_bf16) { if (Cout == 128) FROM3(__hip_bfloat16, 128); else FROM3(__hip_bfloat16, 64); }
-        else { if (Cout == 128) FROM3(float, 128); else FROM3(float, 64); }
-#undef FROM3
-        return xq_check_launch(fn);
-    }
     const long tiles = (total + 31) / 32;
     long blocks = (tiles + 3) / 4;
     const long cap = (long)num_cus() * (Cout == 128 ? 3 : 4);      // resident workgroups per CU at 137 / 121 VGPRs; each wave walks its tiles

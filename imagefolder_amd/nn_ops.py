@@ -195,10 +195,10 @@ def conv2d(x, weight, bias, stride=1, padding=0, relu=False):
             IMPL["conv2d"] = "hip (3x3: implicit GEMM on the tile engine / 128-pixel kernel; fwd, data grad, weight grad)"
             return ops_dense.Conv3x3Fn.apply(x, weight, bias, relu)
         if ops_dense.conv3x3_small_cin_supported(x, weight, stride, padding):
-            IMPL["conv2d_from_rgb"] = "hip (conv3x3_from3_kernel; dgrad conv3x3_to3_kernel; wgrad im2col27 + TN GEMM)"
+            IMPL["conv2d_from_rgb"] = "hip (conv3x3_from3_mfma_kernel; dgrad conv3x3_to3_kernel; wgrad im2col27 + TN GEMM)"
             return ops_dense.Conv3x3SmallCinFn.apply(x, weight, bias, relu)
         if ops_dense.conv3x3_to3_supported(x, weight, stride, padding) and x.shape[1] in (64, 128):
-            IMPL["conv2d_to_rgb"] = "hip (conv3x3_to3_kernel; dgrad conv3x3_from3_kernel; wgrad conv3x3_to3_wgrad_kernel)"
+            IMPL["conv2d_to_rgb"] = "hip (conv3x3_to3_kernel; dgrad conv3x3_from3_mfma_kernel; wgrad conv3x3_to3_wgrad_kernel)"
             y = ops_dense.Conv3x3ToRgbFn.apply(x, weight, bias)
             return torch.relu(y) if relu else y
         if tuple(weight.shape[2:]) == (1, 1) and stride == 1 and padding == 0 and weight.shape[1] % 64 == 0 and weight.shape[0] % 8 == 0 \

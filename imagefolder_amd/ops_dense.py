@@ -908,7 +908,7 @@ def conv3x3_small_cin_supported(x, weight, stride, padding):
 
 
 class Conv3x3SmallCinFn(torch.autograd.Function):
-    """y = [relu](conv3x3(x, W) + b) for a 3-channel input: forward on conv3x3_from3_kernel (planar image in, NHWC bf16 out), data
+    """y = [relu](conv3x3(x, W) + b) for a 3-channel input: forward on conv3x3_from3_mfma_kernel (planar image in, NHWC bf16 out), data
     gradient on conv3x3_to3_kernel with the rotated weights, weight gradient = im2col27 + the split-K TN GEMM."""
 
     @staticmethod
@@ -956,7 +956,7 @@ def conv3x3_to3_supported(x, weight, stride, padding):
 
 
 class Conv3x3ToRgbFn(torch.autograd.Function):
-    """y (B, 3, H, W) = conv3x3(x, W) + b for a 3-channel output: forward on conv3x3_to3_kernel, data gradient on conv3x3_from3_kernel with
+    """y (B, 3, H, W) = conv3x3(x, W) + b for a 3-channel output: forward on conv3x3_to3_kernel, data gradient on conv3x3_from3_mfma_kernel with
     the rotated weights, weight gradient on conv3x3_to3_wgrad_kernel (per-block partials, summed in a fixed order)."""
 
     @staticmethod

@@ -1,6 +1,6 @@
-"""conv3x3 from a 3-channel planar image (csrc/xq_convio.hip): the MFMA kernel (default) vs the one-thread-per-pixel VALU kernel
-(XQ_FROM3_VALU=1, read once per process) on the VGG conv1_1 (fp32 image -> 64 ch + ReLU, 256^2) and CNN conv_in (-> 128 ch) shapes.
-    python tools/bench_from3.py ; XQ_FROM3_VALU=1 python tools/bench_from3.py"""
+"""conv3x3 from a 3-channel planar image (csrc/xq_convio.hip, conv3x3_from3_mfma_kernel) on the VGG conv1_1 (fp32 image -> 64 ch + ReLU,
+256^2) and CNN conv_in (-> 128 ch) shapes: image cast to bf16 once (default) vs fp32 gathers (XQ_FROM3_CAST=0).
+    python tools/bench_from3.py ; XQ_FROM3_CAST=0 python tools/bench_from3.py"""
 import os
 import sys
 
@@ -23,7 +23,7 @@ def timed(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
-tag = ("VALU" if os.environ.get("XQ_FROM3_VALU") == "1" else "MFMA") + (" cast-once" if od.FROM3_CAST else " fp32-gather")
+tag = "MFMA" + (" cast-once" if od.FROM3_CAST else " fp32-gather")
 for B, Cout, HW, dt in [(128, 64, 256, torch.float32), (32, 128, 256, torch.float32), (32, 128, 256, torch.bfloat16)]:
     x = (torch.rand(B, 3, HW, HW, device="cuda") * 2 - 1).to(dt)
     w = torch.randn(Cout, 3, 3, 3, device="cuda") * 0.2
