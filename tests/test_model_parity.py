@@ -48,7 +48,7 @@ def test_gpu_fp32_indices_and_pixels_match_reference_cpu(oracle, name):
     m = m.cuda()
     x = torch.from_numpy(g["x"]).cuda()
     for key in list(nn_ops.IMPL):
-        if key.endswith("_fp32_inference"):
+        if key.endswith("_fp32_inference") or key == "linear_fp32_training":
             del nn_ops.IMPL[key]
     import torch.nn.functional as F
     lib_calls = []
@@ -63,6 +63,18 @@ def test_gpu_fp32_indices_and_pixels_match_reference_cpu(oracle, name):
         return f
     for n in saved:
         setattr(F, n, spy(n))
+    # ... and the raw products (round 4: ops_dense.LinearFn's fp32 branch called torch.addmm for parameters that require a gradient —
+    # autograd reports needs_input_grad for them under no_grad too — and the functional spies above never saw it)
+    saved_t = {n: getattr(torch, n) for n in ("addmm", "mm", "bmm", "matmul", "baddbmm")}
+
+    def spy_t(n):
+        def f(*a, **k):
+            if any(isinstance(t, torch.Tensor) and t.is_cuda and t.numel() > 4096 for t in a):
+                lib_calls.append("torch." + n)
+            return saved_t[n](*a, **k)
+        return f
+    for n in saved_t:
+        setattr(torch, n, spy_t(n))
     try:
         with torch.no_grad():
             f = m.encode(x)
@@ -71,10 +83,12 @@ def test_gpu_fp32_indices_and_pixels_match_reference_cpu(oracle, name):
     finally:
         for n, fn in saved.items():
             setattr(F, n, fn)
+        for n, fn in saved_t.items():
+            setattr(torch, n, fn)
     # every dense op of the fp32 path ran on a hand-written kernel
     assert not lib_calls, f"library ops on the fp32 parity path: {sorted(set(lib_calls))}"
     want = ["conv2d_fp32_inference", "group_norm_silu_fp32_inference", "spatial_attention_fp32_inference"] if CASES[name]["enc_type"] == "cnn" \
-        else ["linear_fp32_inference", "attention_fp32_inference"]
+        else ["linear_fp32_inference", "attention_fp32_inference", "linear_fp32_training"]   # (the blocks' Linear layers: LinearFn's fp32 branch)
     for key in want:
         assert nn_ops.IMPL.get(key, "").startswith("hip"), (key, nn_ops.IMPL.get(key))
     # latent within fp32 rounding of the CPU reference
