@@ -400,7 +400,7 @@ def main():
         if captured is None and i % PROF_EVERY == 0:
             lib.xq_prof_enable(0)
         if use_dist and args.workload == "train_step":
-            ts.reducer.collect_exposed_ms()   # (elapsed_time of the previous step's events: no extra synchronisation)
+            ts.reducer.collect_exposed_ms()   # reads the event pairs that have completed; never synchronises
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -172,7 +172,7 @@ class GradAllReducer:
         self._works = []
         self._armed = False
         self.exposed_ms = []          # one entry per wait(): time the compute stream was blocked by the collectives
-        self._ev = None
+        self._pending_ev = []         # (start, end) event pairs of wait()s not yet read
         if self.active and params is not None:
             for i, p in enumerate(params):
                 p.register_post_accumulate_grad_hook(self._make_hook(self._chunk_of_param[i]))
@@ -229,15 +229,21 @@ class GradAllReducer:
                 self.g[s:e].copy_(buf)
         if timed:
             e1.record()
-            self._ev = (e0, e1)
+            self._pending_ev.append((e0, e1))
         self._works = []
         self._launched = [False] * len(self.chunks)
 
     def collect_exposed_ms(self):
-        """call after a device synchronisation: duration of the last wait() on the compute stream"""
-        if self._ev is not None:
-            self.exposed_ms.append(self._ev[0].elapsed_time(self._ev[1]))
-            self._ev = None
+        """durations of the wait()s whose events have completed (never blocks: an event pair still in flight stays pending and is picked
+        up by a later call; after a device synchronisation every pair is complete).  Round 4: the one-pair form read elapsed_time of
+        the step just enqueued — "Both events must be completed" whenever the host ran ahead of the device, i.e. on every fast box."""
+        still = []
+        for e0, e1 in self._pending_ev:
+            if e1.query():
+                self.exposed_ms.append(e0.elapsed_time(e1))
+            else:
+                still.append((e0, e1))
+        self._pending_ev = still
         return self.exposed_ms
 
 
