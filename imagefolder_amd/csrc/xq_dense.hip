@@ -206,6 +206,36 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float *__res
     }
 }
 
+// First level of the column sums when a kernel left many partial rows (2048 blocks x 4 D floats = 25 MB per LayerNorm backward at D = 768):
+// grid (width / 64, FIN_CHUNKS) — each block sums one chunk of the rows for 64 columns with 16-byte loads, 256 contiguous bytes per row, in
+// a fixed order — into FIN_CHUNKS rows behind the partials (xq_row_partials_blocks reserves them); colsum_finalize_kernel then sums those.
+// (The one-level kernel alone: 192 blocks walking 2048 rows in 64-byte pieces, 13 - 20 us per call, 175 calls per train step.)
+static constexpr int FIN_CHUNKS = 8, FIN_TWO_LEVEL_FROM = 128;
+__global__ __launch_bounds__(256) void colsum_stage_kernel(const float *__restrict__ partials, int nblocks, int width, float *__restrict__ tmp) {
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c4 = (blockIdx.x * 16 + cq) * 4;
+    const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * per, r1 = min(nblocks, r0 + per);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a, c = a, d = a;
+    if (c4 < width) {
+        const float *p = partials + c4;
+        int r = r0 + rl;
+#define FIN_ADD(ACC, R) { const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)(R) * width); ACC.x += v.x; ACC.y += v.y; ACC.z += v.z; ACC.w += v.w; }
+        for (; r + 48 < r1; r += 64) { FIN_ADD(a, r) FIN_ADD(b, r + 16) FIN_ADD(c, r + 32) FIN_ADD(d, r + 48) }
+        for (; r < r1; r += 16) FIN_ADD(a, r)
+#undef FIN_ADD
+    }
+    __shared__ float4 red[16][16];
+    red[rl][cq] = make_float4((a.x + b.x) + (c.x + d.x), (a.y + b.y) + (c.y + d.y), (a.z + b.z) + (c.z + d.z), (a.w + b.w) + (c.w + d.w));
+    __syncthreads();
+    if (rl == 0 && c4 < width) {
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = red[k][cq]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4 *>(tmp + (size_t)blockIdx.y * width + c4) = t;
+    }
+}
+
 template <typename T, bool TANH>
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const T *__restrict__ h, long n, T *__restrict__ out) {
     constexpr int VEC = 16 / sizeof(T);
@@ -329,7 +359,21 @@ static int row_blocks(long rows) {
     return (int)(b < 1 ? 1 : b);
 }
 
-extern "C" int xq_row_partials_blocks(int64_t rows) { return row_blocks((long)rows); }
+// + FIN_CHUNKS rows behind the kernels' own: the second level of the column sums (colsum_stage_kernel)
+extern "C" int xq_row_partials_blocks(int64_t rows) { return row_blocks((long)rows) + FIN_CHUNKS; }
+
+// out[q][c] (+)= sum over the `blocks` partial rows [blocks][nq][D] a row / column kernel left in `partials` (sized by xq_row_partials_blocks)
+static void launch_finalize(float *partials, int blocks, int nq, int D, float *o0, float *o1, float *o2, float *o3, int accumulate, hipStream_t s) {
+    const float *src = partials;
+    int n = blocks;
+    if (blocks >= FIN_TWO_LEVEL_FROM && (nq * D) % 4 == 0) {
+        float *tmp = partials + (size_t)blocks * nq * D;
+        hipLaunchKernelGGL(colsum_stage_kernel, dim3((nq * D / 4 + 15) / 16, FIN_CHUNKS), dim3(256), 0, s, partials, blocks, nq * D, tmp);
+        src = tmp;
+        n = FIN_CHUNKS;
+    }
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((nq * D + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, s, src, n, nq, D, o0, o1, o2, o3, accumulate);
+}
 
 // kernels without column partials (the forward passes): the block count is only a question of bytes in flight
 static int row_blocks_fwd(long rows) {
@@ -387,8 +431,7 @@ extern "C" int xq_res_ln_backward(const void *g_a, const float *g_xnew, const fl
     if (act_bf16) { DISPATCH_D(D, BWD_BF16) } else { DISPATCH_D(D, BWD_F32) }
 #undef BWD_BF16
 #undef BWD_F32
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((4 * D + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, s, partials, blocks, 4, D, g_lnw, g_lnb, g_gamma, g_ybias,
-                       accumulate);
+    launch_finalize(partials, blocks, 4, D, g_lnw, g_lnb, g_gamma, g_ybias, accumulate, s);
     return xq_check_launch(fn);
 }
 
@@ -426,7 +469,7 @@ extern "C" int xq_gelu_backward(const void *g_out, const void *h, int64_t rows, 
     else { if (approximate_tanh) GELU_BWD(float, true); else GELU_BWD(float, false); }
 #undef GELU_BWD
     if (g_bias)
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, s, partials, blocks, 1, H, g_bias, nullptr, nullptr, nullptr, accumulate);
+        launch_finalize(partials, blocks, 1, H, g_bias, nullptr, nullptr, nullptr, accumulate, s);
     return xq_check_launch(fn);
 }
 
@@ -442,7 +485,7 @@ extern "C" int xq_colsum(const void *g, int64_t rows, int H, int act_bf16, float
     const int threads = col_threads(H / vec);
     if (act_bf16) hipLaunchKernelGGL((colsum_kernel<bf16>), dim3(blocks), dim3(threads), 0, s, (const bf16 *)g, (long)rows, H, partials);
     else hipLaunchKernelGGL((colsum_kernel<float>), dim3(blocks), dim3(threads), 0, s, (const float *)g, (long)rows, H, partials);
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, s, partials, blocks, 1, H, out, nullptr, nullptr, nullptr, accumulate);
+    launch_finalize(partials, blocks, 1, H, out, nullptr, nullptr, nullptr, accumulate, s);
     return xq_check_launch(fn);
 }
 
@@ -617,7 +660,7 @@ extern "C" int xq_rowdot_backward(const void *h, const float *w, const float *g,
     if (act_bf16) hipLaunchKernelGGL((rowdot_bwd_kernel<bf16>), dim3(blocks), dim3(threads), 0, s, (const bf16 *)h, w, g, (long)rows, C, (bf16 *)g_h, part);
     else hipLaunchKernelGGL((rowdot_bwd_kernel<float>), dim3(blocks), dim3(threads), 0, s, (const float *)h, w, g, (long)rows, C, (float *)g_h, part);
     if (g_w)
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3((C + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, s, partials, blocks, 1, C, g_w, nullptr, nullptr, nullptr, 0);
+        launch_finalize(partials, blocks, 1, C, g_w, nullptr, nullptr, nullptr, 0, s);
     return xq_check_launch(fn);
 }
 

@@ -268,6 +268,86 @@ static int fold_check(const char *fn, int B, int L, int C, int K, int act_bf16) 
     return XQ_OK;
 }
 
+// ---- class-token readout of the frozen DINO trunk (discriminator_dino.py:339-347: acts.append((x[:, 1:] + x[:, :1]) ...)) -------------------
+// out[b][l][:] = t[b][l + 1][:] + t[b][0][:] from the fp32 residual stream t [B][L + 1][C], written in the heads' activation dtype (one pass
+// instead of an fp32 add + a cast); backward: gt[b][l + 1][:] = g[b][l][:], gt[b][0][:] = sum_l g[b][l][:] in a fixed order.
+template <typename T>
+__global__ __launch_bounds__(256) void cls_readout_fwd_kernel(const float *__restrict__ t, int B, int L, int C, T *__restrict__ out) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int cv = C / VEC;
+    const long total = (long)B * L * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * VEC;
+        const long row = i / cv;
+        const long b = row / L, l = row - b * L;
+        const float *cls = t + b * (long)(L + 1) * C + c, *tok = cls + (l + 1) * (long)C;
+        float v[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; j += 4) {
+            const float4 a = *reinterpret_cast<const float4 *>(tok + j), k = *reinterpret_cast<const float4 *>(cls + j);
+            v[j] = a.x + k.x; v[j + 1] = a.y + k.y; v[j + 2] = a.z + k.z; v[j + 3] = a.w + k.w;
+        }
+        store_vec<T, VEC>(out + row * C + c, v);
+    }
+}
+
+// block (b, 64-column chunk): 8 column octets x 32 row lanes; each lane walks the tokens l = lane, lane + 32, ...
+template <typename T>
+__global__ __launch_bounds__(256) void cls_readout_bwd_kernel(const T *__restrict__ g, int L, int C, float *__restrict__ gt) {
+    const int b = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 7) * 8, rl = threadIdx.x >> 3;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool live = c < C;      // C % 8 == 0
+    if (live) {
+        for (int l = rl; l < L; l += 32) {
+            float v[8];
+            if (sizeof(T) == 2) load_vec<T, 8>(g + ((long)b * L + l) * C + c, v);
+            else { load_vec<T, 4>(g + ((long)b * L + l) * C + c, reinterpret_cast<float(&)[4]>(v[0])); load_vec<T, 4>(g + ((long)b * L + l) * C + c + 4, reinterpret_cast<float(&)[4]>(v[4])); }
+            float *o = gt + ((long)b * (L + 1) + l + 1) * C + c;
+            *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += v[j];
+        }
+    }
+    __shared__ float red[32][65];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rl][(threadIdx.x & 7) * 8 + j] = acc[j];
+    __syncthreads();
+    if (threadIdx.x < 64 && blockIdx.y * 64 + threadIdx.x < C) {
+        float s = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+        gt[(long)b * (L + 1) * C + blockIdx.y * 64 + threadIdx.x] = s;
+    }
+}
+
+extern "C" int xq_cls_readout_forward(const float *t, int B, int L, int C, int act_bf16, void *out, xq_stream_t stream) {
+    const char *fn = "xq_cls_readout_forward";
+    if (B < 0 || L < 1 || C < 8 || C % 8) return xq_set_error(XQ_EINVAL, "%s: bad shape (C %% 8 == 0)", fn);
+    if (B == 0) return XQ_OK;
+    if (!t || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * L * (C / (act_bf16 ? 8 : 4));
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 32;
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    if (act_bf16) hipLaunchKernelGGL((cls_readout_fwd_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, s, t, B, L, C, (bf16 *)out);
+    else hipLaunchKernelGGL((cls_readout_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, t, B, L, C, (float *)out);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_cls_readout_backward(const void *g, int B, int L, int C, int act_bf16, float *gt, xq_stream_t stream) {
+    const char *fn = "xq_cls_readout_backward";
+    if (B < 0 || L < 1 || C < 8 || C % 8 || B > 65535) return xq_set_error(XQ_EINVAL, "%s: bad shape (C %% 8 == 0, B <= 65535)", fn);
+    if (B == 0) return XQ_OK;
+    if (!g || !gt) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)B, (unsigned)((C + 63) / 64));
+    if (act_bf16) hipLaunchKernelGGL((cls_readout_bwd_kernel<bf16>), grid, dim3(256), 0, s, (const bf16 *)g, L, C, gt);
+    else hipLaunchKernelGGL((cls_readout_bwd_kernel<float>), grid, dim3(256), 0, s, (const float *)g, L, C, gt);
+    return xq_check_launch(fn);
+}
+
 extern "C" int xq_unfold1d_circular(const void *h, int B, int L, int C, int K, int act_bf16, void *cols, xq_stream_t stream) {
     const char *fn = "xq_unfold1d_circular";
     if (int rc = fold_check(fn, B, L, C, K, act_bf16)) return rc;

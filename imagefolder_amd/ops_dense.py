@@ -1190,6 +1190,37 @@ class Unfold1dCircularFn(torch.autograd.Function):
         return dh, None
 
 
+class ClsReadoutFn(torch.autograd.Function):
+    """(t[:, 1:] + t[:, :1]) of the frozen DINO trunk's residual stream t (B, L + 1, C) fp32 (discriminator_dino.py:339-347), written in the
+    heads' activation dtype — one kernel instead of an fp32 add and a cast; the transpose of it in one kernel too (class-token row = the
+    sum over the tokens, in a fixed order).  Returns (B, L, C); the caller hands the heads its (B, C, L) transposed VIEW."""
+
+    @staticmethod
+    def forward(ctx, t, act_dtype):
+        B, L1, C = t.shape
+        tc = t.detach().float().contiguous()
+        out = torch.empty(B, L1 - 1, C, dtype=act_dtype, device=tc.device)
+        with torch.cuda.device(tc.device):
+            rc = _lib.lib().xq_cls_readout_forward(ptr(tc), B, L1 - 1, C, _act_flag(act_dtype), ptr(out), _stream(tc))
+        check(rc, "xq_cls_readout_forward")
+        ctx.in_dtype = t.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, L, C = g.shape
+        gc = g.detach().contiguous()
+        gt = torch.empty(B, L + 1, C, dtype=torch.float32, device=gc.device)
+        with torch.cuda.device(gc.device):
+            rc = _lib.lib().xq_cls_readout_backward(ptr(gc), B, L, C, _act_flag(gc.dtype), ptr(gt), _stream(gc))
+        check(rc, "xq_cls_readout_backward")
+        return gt.to(ctx.in_dtype), None
+
+
+def cls_readout_supported(t):
+    return t.is_cuda and t.dim() == 3 and t.shape[1] >= 2 and t.shape[2] % 8 == 0 and t.dtype == torch.float32
+
+
 def disc_head_supported(a, head):
     conv9 = head[1].fn[0]
     return a.is_cuda and a.shape[1] % 64 == 0 and conv9.padding_mode == 'circular' and conv9.kernel_size[0] <= a.shape[2]

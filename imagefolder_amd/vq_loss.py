@@ -70,6 +70,8 @@ FUSED_DIFFAUG = __import__("os").environ.get("XQ_FUSED_DIFFAUG", "1") == "1"
 FUSED_SPECTRAL_NORM = __import__("os").environ.get("XQ_FUSED_SN", "1") == "1"
 # discriminator update: reconstruction and input share one pass over the frozen DINO-S trunk (DinoDisc.forward_pair)
 PAIRED_DISC_TRUNK = __import__("os").environ.get("XQ_PAIRED_DISC", "1") == "1"
+# class-token readout of the discriminator trunk as one kernel per tap (ops_dense.ClsReadoutFn)
+FUSED_READOUT = __import__("os").environ.get("XQ_FUSED_READOUT", "1") == "1"
 _VGG16_CFG = [64, 64, 'M', 128, 128, 'M', 256, 256, 256, 'M', 512, 512, 512, 'M', 512, 512, 512]  # features[0:30]
 
 
@@ -341,17 +343,23 @@ class FrozenDINOSmallNoDrop(nn.Module):
         x = nn_ops.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.patch_size)  # conv as GEMM
         with torch.autocast(device_type=x.device.type, enabled=False):
             x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x.float()), dim=1) + self.pos_embed
-            acts = [(x[:, 1:] + x[:, :1]).transpose(1, 2)]
         if x.is_cuda and nn_ops.FUSED_BLOCKS:
             from . import ops_dense
             blocks = list(self.blocks)
             if ops_dense.fused_supported(x, blocks):  # fused row kernels + attention kernels, as the tokenizer's ViT blocks
                 act = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
+                if FUSED_READOUT and ops_dense.cls_readout_supported(x):
+                    # tokens + class token straight into the heads' dtype (they cast their input first thing): one kernel per tap
+                    readout = lambda t: ops_dense.ClsReadoutFn.apply(t, act).transpose(1, 2)
+                else:
+                    readout = lambda t: (t[:, 1:] + t[:, :1]).transpose(1, 2)
+                acts = [readout(x)]
                 _, tapped = ops_dense.run_blocks(blocks, x, self.norm, act, taps=self.key_depths)
                 for i in sorted(tapped):
-                    t = tapped[i]
-                    acts.append((t[:, 1:] + t[:, :1]).transpose(1, 2))
+                    acts.append(readout(tapped[i]))
                 return acts
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            acts = [(x[:, 1:] + x[:, :1]).transpose(1, 2)]
         for i, b in enumerate(self.blocks):
             x = b(x)
             if i in self.key_depths:

@@ -168,7 +168,8 @@ int xq_adamw_ema_step_dev(float *p, float *g, float *m, float *v, float *ema, vo
  * Activations are [rows][D] row-major; act_bf16 selects their dtype (1 = bf16, 0 = fp32); the residual stream,
  * LayerNorm statistics and all parameter tensors are fp32 (what bf16 autocast does upstream). */
 
-/* number of per-block partial rows the backward kernels write (size the `partials` workspace with it) */
+/* rows of the `partials` workspace of the backward kernels: the per-block partial rows they write + the few rows of the second
+ * level of the column sums that follow them (size the workspace with it: rows x quantities x width floats) */
 int xq_row_partials_blocks(int64_t rows);
 
 /* x_new = x + mask[row / rows_per_sample] * (gamma * y)   (LayerScale :291, DropPath, residual :337-338; y/gamma/mask
@@ -345,6 +346,11 @@ int xq_bnlocal_lrelu_forward(const void *y, const float *w, const float *b, cons
 int xq_bnlocal_lrelu_backward(const void *g_out, const void *y, const float *w, const float *b, const float *mean, const float *rstd,
                               int G, int rows_per_group, int C, int act_bf16, float slope, float ratio, int has_skip, void *g_y,
                               void *g_skip, float *gw_part, float *gb_part, xq_stream_t stream);
+/* class-token readout of the frozen DINO trunk (discriminator_dino.py:339-347: (x[:, 1:] + x[:, :1]) per tapped block): out [B][L][C] (bf16 or
+ * fp32) = t[b][l + 1][:] + t[b][0][:] from the fp32 residual stream t [B][L + 1][C]; backward: gt [B][L + 1][C] fp32 with gt[b][l + 1] = g[b][l]
+ * and gt[b][0] = sum_l g[b][l] (fixed order).  C % 8 == 0. */
+int xq_cls_readout_forward(const float *t, int B, int L, int C, int act_bf16, void *out, xq_stream_t stream);
+int xq_cls_readout_backward(const void *g, int B, int L, int C, int act_bf16, float *gt, xq_stream_t stream);
 /* im2col of Conv1d(kernel K, padding K/2, padding_mode='circular') (:157-166 make_block with ks = 9):
  * cols[b][l][tap][c] = h[b][(l + tap - K/2) mod L][c]; the conv is then cols[B*L][K*C] x W[Cout][K*C]^T. */
 int xq_unfold1d_circular(const void *h, int B, int L, int C, int K, int act_bf16, void *cols, xq_stream_t stream);

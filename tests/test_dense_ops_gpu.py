@@ -574,3 +574,23 @@ def test_rowdot_kernels_vs_reference(rows, C, dt):
     tol = 1e-5 if dt == torch.float32 else 1e-2
     assert (gh.float() - ghr).abs().max().item() <= tol * ghr.abs().max().item()
     assert (gw - gwr).abs().max().item() <= 1e-4 * gwr.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,L,C,dt", [(3, 196, 384, torch.bfloat16), (2, 37, 72, torch.float32), (5, 1, 64, torch.bfloat16), (1, 257, 768, torch.float32)])
+def test_cls_readout_kernels_vs_reference_expression(B, L, C, dt):
+    """ClsReadoutFn = (t[:, 1:] + t[:, :1]) of the discriminator trunk (discriminator_dino.py:339-347) in the heads' dtype, and its transpose:
+    token rows copied, class-token row = the sum over the tokens"""
+    from imagefolder_amd.ops_dense import ClsReadoutFn, cls_readout_supported
+    torch.manual_seed(B + L + C)
+    t = torch.randn(B, L + 1, C, device="cuda", requires_grad=True)
+    assert cls_readout_supported(t)
+    out = ClsReadoutFn.apply(t, dt)
+    ref = (t[:, 1:] + t[:, :1])
+    assert out.dtype == dt and tuple(out.shape) == (B, L, C)
+    assert torch.equal(out, ref.detach().to(dt))                     # one fp32 add, one rounding: bit-identical to add-then-cast
+    g = torch.randn(B, L, C, device="cuda").to(dt)
+    (gt,) = torch.autograd.grad(out, t, g)
+    (gr,) = torch.autograd.grad(ref, t, g.float())
+    assert torch.equal(gt[:, 1:], gr[:, 1:])
+    assert (gt[:, 0] - gr[:, 0]).abs().max().item() <= 1e-5 * max(1.0, gr[:, 0].abs().max().item()) * L ** 0.5
