@@ -19,6 +19,7 @@
 #include "../../include/xq_ops.h"
 
 #include "xq_vec.hpp"
+#include <cstdlib>
 #include "xq_act.hpp"
 
 using namespace xq;
@@ -366,7 +367,7 @@ extern "C" int xq_row_partials_blocks(int64_t rows) { return row_blocks((long)ro
 static void launch_finalize(float *partials, int blocks, int nq, int D, float *o0, float *o1, float *o2, float *o3, int accumulate, hipStream_t s) {
     const float *src = partials;
     int n = blocks;
-    if (blocks >= FIN_TWO_LEVEL_FROM && (nq * D) % 4 == 0) {
+    if (blocks >= FIN_TWO_LEVEL_FROM && (nq * D) % 4 == 0) {      // (one level for everything: +0.3 .. +1.0 ms per train step, profiles/r04_step_ab_readout_finalize.txt)
         float *tmp = partials + (size_t)blocks * nq * D;
         hipLaunchKernelGGL(colsum_stage_kernel, dim3((nq * D / 4 + 15) / 16, FIN_CHUNKS), dim3(256), 0, s, partials, blocks, nq * D, tmp);
         src = tmp;
