@@ -23,7 +23,8 @@ for k in sorted(acc):
     cyc = avg["GRBM_GUI_ACTIVE"] / 8.0
     mf = avg.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
     wc = max(avg.get("SQ_WAVE_CYCLES", 0.0), 1.0)
-    name = k.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "")[:70]
+    name = k.replace("void ", "").replace("(anonymous namespace)::", "")
+    name = (name[:name.index(">(") + 1] if ">(" in name else name.split("(")[0])[:70]
     print(f"{name:70s} {len(d['GRBM_GUI_ACTIVE']):8d} {cyc:11.4g} {mf / (1024.0 * cyc):9.3f} {100 * avg.get('SQ_WAIT_ANY', 0) / wc:7.1f} "
           f"{100 * avg.get('SQ_WAIT_INST_ANY', 0) / wc:13.1f} {100 * avg.get('SQ_WAIT_INST_LDS', 0) / wc:11.1f} "
           f"{avg.get('SQ_LDS_BANK_CONFLICT', 0) / max(mf, 1.0):20.4f} {avg.get('SQ_INSTS_VALU', 0) / max(mf, 1.0):14.3f}")
