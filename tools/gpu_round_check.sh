@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call: GPU test suite, default bench line, rocprofv3 kernel trace of the same command, PMC traffic passes.
 #   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/gpu_round_check.sh <tag> [parts]'
-# parts: any of  tests bench trace pmc shapes sections configs cnntrace gemmtests gemmab gemmclock   (default: the first five)
+# parts: any of  tests bench trace pmc shapes sections configs cnntrace gemmtests gemmab gemmclock sq   (default: the first five)
 TAG=${1:-check}; export XQ_TAG=$TAG
 PARTS=${2:-"tests bench trace pmc shapes"}
 export TMPDIR=/tmp
@@ -54,6 +54,14 @@ if has gemmclock; then
   # in-kernel shader-clock sums of the persistent GEMM kernel: cycles per phase (load / barrier wait / MFMA / barrier wait) per shape and op
   timeout 120 python tools/gemm_timeline.py --layers qkv proj fc1 fc2 --ops nt nn tn --out $OUT/gemm_phase_sums.txt > $OUT/gemm_phase_sums.log 2>&1
   echo "gemmclock rc=$?"; grep -E "^## |K tile period" $OUT/gemm_phase_sums.txt | cut -c1-160
+fi
+if has sq; then
+  # SQ counters (MFMA-pipe busy, wait / stall shares) of the GEMM and attention kernels: ONE --pmc pass each, no trace flags beside it
+  SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE"
+  timeout 300 rocprofv3 --pmc $SQ --output-format csv -d /tmp/pmc_gemm_$TAG -- python tools/bench_gemm.py --rows 65664 --scheds 3 --no-library --iters 3 > $OUT/pmc_gemm.log 2>&1
+  python tools/pmc_sq_table.py /tmp/pmc_gemm_$TAG gemm_ > $OUT/gemm_pmc_sq.txt 2>&1; cut -c1-200 $OUT/gemm_pmc_sq.txt
+  timeout 300 rocprofv3 --pmc $SQ --output-format csv -d /tmp/pmc_attn_$TAG -- python tools/bench_attn.py > $OUT/pmc_attn.log 2>&1
+  python tools/pmc_sq_table.py /tmp/pmc_attn_$TAG attn_ > $OUT/attn_pmc_sq.txt 2>&1; cut -c1-200 $OUT/attn_pmc_sq.txt
 fi
 if has configs; then
   for CFG in VP2-16384 MSVR10P2-4096 RobustTok; do
