@@ -102,6 +102,9 @@ SIGNATURES = {
     "xq_ms_area_pool": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv2d_f32_pack_weights": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv2d_f32_nhwc": (ctypes.c_int, [vp, vp, vp] + [ctypes.c_int] * 13 + [vp, vp]),
+    "xq_attention_f32_lse": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                            ctypes.c_float, vp, vp, vp]),
+    "xq_attention_f32_backward": (ctypes.c_int, [vp] * 6 + [ctypes.c_int] * 4 + [ctypes.c_int64, ctypes.c_int64, ctypes.c_float, vp, vp, vp, vp, vp]),
     "xq_gemm_f32_tn": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_attention_f32": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                         ctypes.c_float, vp, vp]),

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void conv2d_f32_kernel(const ConvF32 p) {
 // q / k / v: element offset of (b, token, head) = b * batch_stride + token * tok_stride + h * hd; out row = (b * N + i) * (H * hd) + h * hd
 __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
                                                             int B, int N, int H, int hd, long batch_stride, long tok_stride, float scale,
-                                                            float *__restrict__ out) {
+                                                            float *__restrict__ out, float *__restrict__ lse) {
     extern __shared__ float sm[];          // [4 waves][hd + N]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long item = (long)blockIdx.x * 4 + wave;            // (b, h, i) flattened, i fastest
@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restr
     sum = wave_sum(sum);
     __builtin_amdgcn_wave_barrier();
     const float inv = 1.0f / sum;
+    if (lse != nullptr && lane == 0) lse[(b * H + h) * (long)N + i] = mx + logf(sum);      // for the backward kernels: p_ij = exp(s_ij - lse_i)
     float *op = out + ((b * N + i) * (long)H + h) * hd;
     for (int d = lane; d < hd; d += 64) {
         float o = 0.0f;
@@ -133,6 +134,72 @@ __global__ __launch_bounds__(256) void attention_f32_kernel(const float *__restr
         for (int j = 0; j < N; ++j) o = __builtin_fmaf(ps[j] * inv, vp[(long)j * tok_stride], o);
         op[d] = o;
     }
+}
+
+// Backward of the same attention in fp32 (round 4: the fp32 TRAINING leg of the parity tests), head dim <= 64, lane = channel d.
+// With p_ij = exp(scale q_i.k_j - lse_i), delta_i = dO_i.O_i, dP_ij = dO_i.v_j, dS_ij = p_ij (dP_ij - delta_i):
+//   attention_f32_bwd_q_kernel  : one wave per (b, h, query i), keys in ascending order:  dq_i = scale sum_j dS_ij k_j;  writes delta_i
+//   attention_f32_bwd_kv_kernel : one wave per (b, h, key j), queries in ascending order: dk_j = scale sum_i dS_ij q_i,  dv_j = sum_i p_ij dO_i
+// Every dot product is a butterfly sum over the 64 lanes, every output one ascending chain: deterministic, no atomics.  ~40 wave
+// instructions per (query, key) pair and direction — a parity path (milliseconds at the sizes the goldens use), not a fast one.
+__device__ __forceinline__ float f32_bfly_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void attention_f32_bwd_q_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                                  const float *__restrict__ out, const float *__restrict__ dout,
+                                                                  const float *__restrict__ lse, int B, int N, int H, int hd, long batch_stride,
+                                                                  long tok_stride, float scale, float *__restrict__ dq, float *__restrict__ delta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)B * H * N) return;
+    const int i = (int)(item % N), h = (int)((item / N) % H);
+    const long b = item / ((long)N * H);
+    const bool on = lane < hd;
+    const long qoff = b * batch_stride + (long)i * tok_stride + (long)h * hd + lane;
+    const long ooff = ((b * N + i) * (long)H + h) * hd + lane;
+    const float qd = on ? q[qoff] : 0.0f, dod = on ? dout[ooff] : 0.0f, od = on ? out[ooff] : 0.0f;
+    const float dl = f32_bfly_sum(dod * od), ls = lse[(b * H + h) * (long)N + i];
+    if (lane == 0) delta[(b * H + h) * (long)N + i] = dl;
+    float acc = 0.0f;
+    const float *kp = k + b * batch_stride + (long)h * hd + lane, *vp = v + b * batch_stride + (long)h * hd + lane;
+    for (int j = 0; j < N; ++j) {
+        const float kd = on ? kp[(long)j * tok_stride] : 0.0f, vd = on ? vp[(long)j * tok_stride] : 0.0f;
+        const float sc = f32_bfly_sum(qd * kd) * scale;
+        const float pj = expf(sc - ls);
+        const float ds = pj * (f32_bfly_sum(dod * vd) - dl);
+        acc = __builtin_fmaf(ds, kd, acc);
+    }
+    if (on) dq[qoff] = acc * scale;
+}
+
+__global__ __launch_bounds__(256) void attention_f32_bwd_kv_kernel(const float *__restrict__ q, const float *__restrict__ k, const float *__restrict__ v,
+                                                                   const float *__restrict__ dout, const float *__restrict__ lse,
+                                                                   const float *__restrict__ delta, int B, int N, int H, int hd, long batch_stride,
+                                                                   long tok_stride, float scale, float *__restrict__ dk, float *__restrict__ dv) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long item = (long)blockIdx.x * 4 + wave;
+    if (item >= (long)B * H * N) return;
+    const int j = (int)(item % N), h = (int)((item / N) % H);
+    const long b = item / ((long)N * H);
+    const bool on = lane < hd;
+    const long koff = b * batch_stride + (long)j * tok_stride + (long)h * hd + lane;
+    const float kd = on ? k[koff] : 0.0f, vd = on ? v[koff] : 0.0f;
+    float ak = 0.0f, av = 0.0f;
+    const float *qp = q + b * batch_stride + (long)h * hd + lane;
+    const float *dop = dout + (b * N * (long)H + h) * hd + lane;
+    const float *lp = lse + (b * H + h) * (long)N, *dp = delta + (b * H + h) * (long)N;
+    for (int i = 0; i < N; ++i) {
+        const float qd = on ? qp[(long)i * tok_stride] : 0.0f, dod = on ? dop[(long)i * H * hd] : 0.0f;
+        const float sc = f32_bfly_sum(qd * kd) * scale;
+        const float pi = expf(sc - lp[i]);
+        const float ds = pi * (f32_bfly_sum(dod * vd) - dp[i]);
+        av = __builtin_fmaf(pi, dod, av);
+        ak = __builtin_fmaf(ds, qd, ak);
+    }
+    if (on) { dk[koff] = ak * scale; dv[koff] = av; }
 }
 
 // one block per (sample, group): x [B][HW][C] -> y, statistics in double
@@ -257,8 +324,31 @@ extern "C" int xq_gemm_f32_tn(const float *a, const float *b, int64_t M, int Na,
     return xq_check_launch(fn);
 }
 
+extern "C" int xq_attention_f32_lse(const float *q, const float *k, const float *v, int B, int N, int H, int hd, int64_t batch_stride,
+                                    int64_t token_stride, float scale, float *out, float *lse, xq_stream_t stream);
 extern "C" int xq_attention_f32(const float *q, const float *k, const float *v, int B, int N, int H, int hd, int64_t batch_stride,
                                 int64_t token_stride, float scale, float *out, xq_stream_t stream) {
+    return xq_attention_f32_lse(q, k, v, B, N, H, hd, batch_stride, token_stride, scale, out, nullptr, stream);
+}
+
+extern "C" int xq_attention_f32_backward(const float *q, const float *k, const float *v, const float *out, const float *dout, const float *lse,
+                                         int B, int N, int H, int hd, int64_t batch_stride, int64_t token_stride, float scale, float *dq,
+                                         float *dk, float *dv, float *delta, xq_stream_t stream) {
+    const char *fn = "xq_attention_f32_backward";
+    if (B < 0 || N < 1 || H < 1 || hd < 1 || hd > 64) return xq_set_error(XQ_EINVAL, "%s: bad shape (head dim <= 64)", fn);
+    if (B == 0) return XQ_OK;
+    if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv || !delta) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long items = (long)B * H * N;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(attention_f32_bwd_q_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, q, k, v, out, dout, lse, B, N, H, hd,
+                       (long)batch_stride, (long)token_stride, scale, dq, delta);
+    hipLaunchKernelGGL(attention_f32_bwd_kv_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, s, q, k, v, dout, lse, delta, B, N, H, hd,
+                       (long)batch_stride, (long)token_stride, scale, dk, dv);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_attention_f32_lse(const float *q, const float *k, const float *v, int B, int N, int H, int hd, int64_t batch_stride,
+                                    int64_t token_stride, float scale, float *out, float *lse, xq_stream_t stream) {
     const char *fn = "xq_attention_f32";
     if (B < 0 || N < 1 || H < 1 || hd < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
     if (B == 0) return XQ_OK;
@@ -267,7 +357,7 @@ extern "C" int xq_attention_f32(const float *q, const float *k, const float *v, 
     if (lds > 64 * 1024) return xq_set_error(XQ_EINVAL, "%s: hd + N = %ld exceeds the 4096-float LDS row", fn, (long)(hd + N));
     const long items = (long)B * H * N;
     hipLaunchKernelGGL(attention_f32_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, (hipStream_t)stream, q, k, v, B, N, H, hd,
-                       (long)batch_stride, (long)token_stride, scale, out);
+                       (long)batch_stride, (long)token_stride, scale, out, lse);
     return xq_check_launch(fn);
 }
 

@@ -36,7 +36,7 @@ def _lib_ran(name, what):
 
 # ViT blocks as fused HIP row kernels + attention kernels + the hand-written GEMMs (ops_dense.run_blocks) instead of per-op ATen calls
 FUSED_BLOCKS = True
-# nn.Linear of an fp32 TRAINING step (autocast off) on the hand-written fp32-MFMA kernels (ops_f32.LinearF32Fn) instead of the library:
+# nn.Linear and attention of an fp32 TRAINING step (autocast off) on the hand-written fp32 kernels (ops_f32.LinearF32Fn / AttentionF32Fn) instead of the library:
 # exact fp32 chains at 1/16 of the bf16 rate — the parity leg, not the product path (the reference trains under bf16 autocast)
 F32_TRAIN_LINEAR = __import__("os").environ.get("XQ_F32_TRAIN_LINEAR", "1") == "1"
 
@@ -98,6 +98,9 @@ def attention_qkvpacked(qkv, num_heads):
         if ops_f32.eligible(qkv):
             IMPL["attention_fp32_inference"] = "hip (xq_attention_f32)"
             return ops_f32.attention_qkvpacked(qkv, num_heads)
+        if F32_TRAIN_LINEAR and ops_f32.attention_trainable(qkv, num_heads):
+            IMPL["attention_fp32_training"] = "hip (xq_attention_f32_lse / xq_attention_f32_backward)"
+            return ops_f32.AttentionF32Fn.apply(qkv, num_heads)
     B, N, C3 = qkv.shape
     C = C3 // 3
     q, k, v = qkv.reshape(B, N, 3, num_heads, C // num_heads).permute(2, 0, 3, 1, 4).unbind(0)

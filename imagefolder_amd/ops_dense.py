@@ -478,6 +478,9 @@ def attention_qkvpacked(qkv, num_heads):
     if qkv.is_cuda and ops_f32.eligible(qkv):
         nn_ops.IMPL["attention_fp32_inference"] = "hip (xq_attention_f32)"
         return ops_f32.attention_qkvpacked(qkv, num_heads)
+    if nn_ops.F32_TRAIN_LINEAR and qkv.is_cuda and ops_f32.attention_trainable(qkv, num_heads):
+        nn_ops.IMPL["attention_fp32_training"] = "hip (xq_attention_f32_lse / xq_attention_f32_backward)"
+        return ops_f32.AttentionF32Fn.apply(qkv, num_heads)
     nn_ops.IMPL["attention"] = "library (SDPA)"
     B, N, C3 = qkv.shape
     C = C3 // 3

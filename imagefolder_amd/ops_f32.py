@@ -169,6 +169,56 @@ def attention_qkvpacked(qkv, num_heads):
     return out
 
 
+class AttentionF32Fn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(d)) v on a packed (B, N, 3 * C) fp32 projection WITH its backward on the fp32 kernels of csrc/xq_f32.hip
+    (attention_f32_kernel + lse; attention_f32_bwd_q / _kv kernels: deterministic ascending chains, head dim <= 64): the attention of the
+    fp32 TRAINING leg of the parity tests (tests/test_train_backward_parity.py leg (a)); the bf16 leg runs csrc/xq_attn.hip."""
+
+    @staticmethod
+    def forward(ctx, qkv, num_heads):
+        B, N, C3 = qkv.shape
+        C = C3 // 3
+        hd = C // num_heads
+        q = qkv.detach().contiguous()
+        out = torch.empty(B, N, C, dtype=torch.float32, device=q.device)
+        lse = torch.empty(B, num_heads, N, dtype=torch.float32, device=q.device)
+        base = q.data_ptr()
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().xq_attention_f32_lse(ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * C), ctypes.c_void_p(base + 8 * C), B, N,
+                                                 num_heads, hd, N * C3, C3, ctypes.c_float(float(hd) ** -0.5), ptr(out), ptr(lse), _stream(q))
+        check(rc, "xq_attention_f32")
+        ctx.save_for_backward(q, out, lse)
+        ctx.num_heads = num_heads
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        q, out, lse = ctx.saved_tensors
+        B, N, C3 = q.shape
+        C = C3 // 3
+        H = ctx.num_heads
+        hd = C // H
+        gc = g.detach().float().contiguous()
+        dqkv = torch.empty_like(q)
+        delta = torch.empty_like(lse)
+        base, dbase = q.data_ptr(), dqkv.data_ptr()
+        with torch.cuda.device(q.device):
+            rc = _lib.lib().xq_attention_f32_backward(ctypes.c_void_p(base), ctypes.c_void_p(base + 4 * C), ctypes.c_void_p(base + 8 * C), ptr(out),
+                                                      ptr(gc), ptr(lse), B, N, H, hd, N * C3, C3, ctypes.c_float(float(hd) ** -0.5),
+                                                      ctypes.c_void_p(dbase), ctypes.c_void_p(dbase + 4 * C), ctypes.c_void_p(dbase + 8 * C),
+                                                      ptr(delta), _stream(q))
+        check(rc, "xq_attention_f32_backward")
+        return dqkv, None
+
+
+def attention_trainable(qkv, num_heads):
+    """packed fp32 CUDA projection, autocast off, head dim <= 64, a score row that fits the forward kernel's LDS"""
+    if not (trainable(qkv) and qkv.dim() == 3 and qkv.shape[-1] % (3 * num_heads) == 0):
+        return False
+    hd = qkv.shape[-1] // (3 * num_heads)
+    return hd <= 64 and 16 * (hd + qkv.shape[1]) <= 64 * 1024
+
+
 def spatial_attention(q, k, v):
     """single-head attention over the H*W positions (CNN AttnBlock, xqgan_model.py:646-656): q, k, v (B, C, H, W) -> (B, C, H, W)"""
     B, C, H, W = q.shape

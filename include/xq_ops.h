@@ -391,6 +391,14 @@ int xq_gemm_f32_tn(const float *a, const float *b, int64_t M, int Na, int Nb, fl
  * CNN AttnBlock, xqgan_model.py:635-659: H = 1, hd = C); out is [B][N][H][hd] contiguous. */
 int xq_attention_f32(const float *q, const float *k, const float *v, int B, int N, int H, int hd, int64_t batch_stride,
                      int64_t token_stride, float scale, float *out, xq_stream_t stream);
+/* the same with lse [B][H][N] (nullable) = log sum_j exp(scale q_i . k_j) written beside it, and the backward of it for the fp32 TRAINING leg
+ * of the parity tests (head dim <= 64): dq / dk / dv in the layout of q / k / v (same strides: three pointers into one packed gradient
+ * buffer), dout [B][N][H][hd] contiguous, delta [B][H][N] workspace (dO_i . O_i).  Deterministic: every output is one ascending chain. */
+int xq_attention_f32_lse(const float *q, const float *k, const float *v, int B, int N, int H, int hd, int64_t batch_stride,
+                         int64_t token_stride, float scale, float *out, float *lse, xq_stream_t stream);
+int xq_attention_f32_backward(const float *q, const float *k, const float *v, const float *out, const float *dout, const float *lse, int B, int N,
+                              int H, int hd, int64_t batch_stride, int64_t token_stride, float scale, float *dq, float *dk, float *dv,
+                              float *delta, xq_stream_t stream);
 /* y = [silu](GroupNorm(x)) on x [B][HW][C] fp32, G groups, statistics accumulated in double (xqgan_model.py:662-672) */
 int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int B, int HW, int C, int G, float eps, int silu, float *y,
                           xq_stream_t stream);

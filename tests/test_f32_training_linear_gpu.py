@@ -63,3 +63,30 @@ def test_weight_gradient_is_deterministic_and_handles_empty_batches():
     assert _lib.lib().xq_gemm_f32_tn(None, None, 0, 96, 200, ptr(c), None) == 0
     torch.cuda.synchronize()
     assert bool((c == 0).all())
+
+
+@pytest.mark.parametrize("B,N,H,hd", [(2, 257, 12, 64), (3, 70, 6, 64), (1, 197, 3, 32), (2, 5, 2, 64)])
+def test_attention_fp32_forward_and_gradients(B, N, H, hd):
+    """ops_f32.AttentionF32Fn (attention_f32_kernel + lse, attention_f32_bwd_q / _kv kernels) against float64 softmax attention and its
+    autograd on the same packed projection; run twice: bit-identical (no atomics)."""
+    from imagefolder_amd import nn_ops, ops_dense, ops_f32
+    torch.manual_seed(B + N + H)
+    C = H * hd
+    qkv = (torch.randn(B, N, 3 * C, device="cuda") * 0.7).requires_grad_(True)
+    assert ops_f32.attention_trainable(qkv, H)
+    nn_ops.IMPL.pop("attention_fp32_training", None)
+    y = ops_dense.attention_qkvpacked(qkv, H)
+    assert nn_ops.IMPL.get("attention_fp32_training", "").startswith("hip")
+    g = torch.randn_like(y)
+    (dqkv,) = torch.autograd.grad(y, qkv, g)
+    q64 = qkv.detach().double().requires_grad_(True)
+    q, k, v = q64.view(B, N, 3, H, hd).permute(2, 0, 3, 1, 4).unbind(0)
+    p = torch.softmax(q @ k.transpose(-1, -2) * hd ** -0.5, dim=-1)
+    y64 = (p @ v).transpose(1, 2).reshape(B, N, C)
+    (d64,) = torch.autograd.grad(y64, q64, g.double())
+    assert (y.double() - y64).abs().max().item() <= 2e-6 * max(1.0, y64.abs().max().item())
+    assert ((dqkv.double() - d64).norm() / d64.norm()).item() <= 2e-6
+    assert (dqkv.double() - d64).abs().max().item() <= 1e-5 * d64.abs().max().item()
+    y2 = ops_f32.AttentionF32Fn.apply(qkv, H)
+    (d2,) = torch.autograd.grad(y2, qkv, g)
+    assert torch.equal(y2, y) and torch.equal(d2, dqkv)

@@ -11,7 +11,8 @@ recorded twice — fp32, and under torch.autocast('cpu', bfloat16): the referenc
 Checked here on the MI355X:
   (a) fp32 step (HIP quantizers + perturbation with their hand-written backward; every nn.Linear — forward, data gradient, weight
       gradient — on the hand-written fp32-MFMA kernels of csrc/xq_f32.hip since round 4 (ops_dense.LinearFn's fp32 branch / ops_f32.LinearF32Fn;
-      asserted below through nn_ops.IMPL); attention and the element-wise backward passes of this leg are ATen's): every tapped gradient
+      asserted below through nn_ops.IMPL) and the attention on attention_f32_kernel / attention_f32_bwd_q / _kv kernels; LayerNorm / residual /
+      GELU run on the fp32 instantiations of the fused row kernels; what is left to ATen are element-wise glue ops): every tapped gradient
       within REL_F32 of the reference's fp32 gradient (relative L2 over the sub-sample);
   (b) the bf16 TRAINING path (hand-written bf16 MFMA GEMMs fwd / dgrad / wgrad, attention fwd / bwd, fused row kernels, quantizer
       backward): its distance to the reference's fp32 gradient is bounded by the distance of the reference's OWN bf16-autocast
@@ -111,11 +112,14 @@ def test_model_level_gradients_match_the_reference_autograd(name, monkeypatch):
     # ---- (a) fp32 ----
     lr = 1e-4
     from imagefolder_amd import nn_ops
-    nn_ops.IMPL.pop("linear_fp32_training", None)
-    nn_ops.IMPL.pop("linear_library", None)
+    for key in ("linear_fp32_training", "linear_library", "attention_fp32_training", "attention_library", "attention"):
+        nn_ops.IMPL.pop(key, None)
     loss32, g32, after32, seed = _run(name, None, monkeypatch, lr=lr)
-    # the Linear layers of this leg ran on the hand-written fp32-MFMA kernels (forward, data gradient, weight gradient), none on the library
+    # the Linear layers (forward, data gradient, weight gradient) and the attention (forward, backward) of this leg ran on the hand-written
+    # fp32 kernels, none on the library
     assert nn_ops.IMPL.get("linear_fp32_training", "").startswith("hip") and "linear_library" not in nn_ops.IMPL
+    assert nn_ops.IMPL.get("attention_fp32_training", "").startswith("hip") and "attention_library" not in nn_ops.IMPL
+    assert not nn_ops.IMPL.get("attention", "").startswith("library")
     np.testing.assert_allclose(loss32, float(gb["loss_f32"]), rtol=1e-4 if name == "train_bwd_cfg5_robusttok" else 5e-6)
     rows = []
     for n in taps:
