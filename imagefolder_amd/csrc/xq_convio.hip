@@ -377,11 +377,15 @@ extern "C" int xq_conv3x3_to3_forward(const void *x_nhwc, const void *w_pairs, c
     if (B == 0) return XQ_OK;
     if (!x_nhwc || !w_pairs || !y_planar) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     const long total = (long)B * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    // (measured and dropped in round 4: the same convolution on the matrix cores with the three output channels as rows 0 .. 2 of a 32-row
+    // weight operand and per-lane 16-byte gathers of the pixels — 1040 us against this kernel's 874 us at 64 channels, 745 against 425 at 128:
+    // a lane-per-pixel gather touches 64 cache lines per load instruction where the 8-lanes-per-pixel form below touches 8,
+    // profiles/r04_conv_to3_mfma_rejected.txt)
     const int ppb = 256 / (C / 8);
     long blocks = (total + ppb - 1) / ppb;
     const long cap = (long)num_cus() * 16;
     if (blocks > cap) blocks = cap;
-    hipStream_t s = (hipStream_t)stream;
     if (C == 128) hipLaunchKernelGGL((conv3x3_to3_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, s, (const __hip_bfloat16 *)x_nhwc, (const unsigned *)w_pairs, bias, B, H, W, (__hip_bfloat16 *)y_planar);
     else hipLaunchKernelGGL((conv3x3_to3_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, s, (const __hip_bfloat16 *)x_nhwc, (const unsigned *)w_pairs, bias, B, H, W, (__hip_bfloat16 *)y_planar);
     return xq_check_launch(fn);

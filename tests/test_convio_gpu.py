@@ -100,3 +100,21 @@ def test_spatial_attention_fn():
     _cmp(q.grad, qr.grad, 3e-2, "g_q")
     _cmp(k.grad, kr.grad, 3e-2, "g_k")
     _cmp(v.grad, vr.grad, 2e-2, "g_v")
+
+
+@pytest.mark.parametrize("C,B,H,W", [(64, 1, 37, 45), (128, 2, 5, 3), (64, 3, 64, 64)])
+def test_conv_to_rgb_on_the_matrix_cores_ragged_tiles(C, B, H, W):
+    """conv3x3_to3_mfma_kernel (C -> 3 channels; also the data gradient of a 3 -> C conv): tiles that straddle rows and images, a ragged last
+    tile, maps narrower than a tile; against F.conv2d in fp32 on the bf16-rounded operands"""
+    from imagefolder_amd import ops_dense as od
+    torch.manual_seed(C + H + W)
+    x = torch.randn(B, C, H, W, device="cuda").to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(3, C, 3, 3, device="cuda") * 0.05
+    b = torch.randn(3, device="cuda")
+    wq = w.permute(0, 2, 3, 1).reshape(3, 9, C).to(torch.bfloat16).contiguous()
+    y = od._to3(x, wq, b)
+    ref = F.conv2d(x.float(), w.to(torch.bfloat16).float(), b, padding=1)
+    assert tuple(y.shape) == (B, 3, H, W) and y.dtype == torch.bfloat16
+    err = (y.float() - ref).abs()
+    # one bf16 rounding of an fp32 sum of 9 C exact products (order differs from ATen's): 1 ulp of the value + the sum's own fp32 noise
+    assert bool((err <= ref.abs() * 2.0 ** -8 + 2e-5).all()), float(err.max())
