@@ -224,3 +224,14 @@ def test_discriminator_step_two_ranks_equals_single_process_on_the_global_batch(
         ds(imgs[it], rec[it])
     for k, v in L.state_dict().items():
         assert torch.allclose(v, dp[k], atol=1e-6, rtol=1e-5), k
+
+
+def test_library_formulation_switches_every_hand_written_dense_path_off():
+    """tools/library_backend.library_dense_ops is what bench.py's flop-counting pass runs under: every hand-written dense path has to be off
+    inside it (the fp32 training kernels of round 4 were not, and `mfu` was counted on half the flops), and restored after."""
+    from imagefolder_amd import nn_ops, ops_dense
+    from tools.library_backend import library_dense_ops
+    before = (nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL, nn_ops.F32_TRAIN_LINEAR)
+    with library_dense_ops():
+        assert nn_ops.FUSED_BLOCKS is False and ops_dense.GEMM_IMPL == "library" and nn_ops.F32_TRAIN_LINEAR is False
+    assert (nn_ops.FUSED_BLOCKS, ops_dense.GEMM_IMPL, nn_ops.F32_TRAIN_LINEAR) == before
