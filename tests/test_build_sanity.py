@@ -13,7 +13,10 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 # substring of the mangled kernel name -> least plausible code size in bytes
 EXPECT = {"gemm_pring_kernel": 12000, "gemm_ring_kernel": 5000, "gemm_simple_kernel": 4000, "attn_fwd_kernel": 2500, "attn_bwd_dkdv_kernel": 2500,
           "attn_bwd_dq_kernel": 2500, "assign_kernel": 2000, "conv3x3_kernel": 2500, "conv3x3_wgrad_kernel": 2500, "res_ln_fwd_kernel": 1000,
-          "res_ln_bwd_kernel": 1000, "adamw_ema_kernel": 400}
+          "res_ln_bwd_kernel": 1000, "adamw_ema_kernel": 400,
+          # round 4
+          "conv3x3_c64_kernel": 4000, "conv3x3_from3_mfma_kernel": 2500, "conv2d_f32_kernel": 3000, "gemm_f32_tn_kernel": 900,
+          "attention_f32_bwd_q_kernel": 1800, "attention_f32_bwd_kv_kernel": 1800, "bnlocal_lrelu_fwd_kernel": 1500, "cls_readout_bwd_kernel": 500}
 
 
 def _kernel_sizes(obj, tmp):
