@@ -79,6 +79,8 @@ def parse():
     p.add_argument("--no-mfu", action="store_true", help="skip the FlopCounterMode pass (mfu = null)")
     p.add_argument("--allow-library", action="store_true", help="do not raise when a dense op of the bf16 step falls back to a PyTorch-ROCm "
                    "library op (default: nn_ops.STRICT_HIP on — such a fallback aborts the run instead of being timed)")
+    p.add_argument("--max-grad-norm", type=float, default=0.0, help="gradient clipping of both optimizers (xqgan_train.py:104,456-458,471-473; 0 = off, "
+                   "what the yamls run: their `max_grad_norm: 1.0` lines are commented out and the first argparse default is 0.0)")
     p.add_argument("--grad-comm", default="fp32", choices=["fp32", "bf16"], help="dtype of the gradient all-reduce on the links")
     p.add_argument("--graph", default="off", choices=["auto", "on", "off"],
                    help="off (default): the eager step — the program every N > 1 run executes, and since round 3 level with the replay "
@@ -208,7 +210,7 @@ def build_train_step(args, dev, world, amp_dtype=torch.bfloat16, disc_group=None
                          codebook_weight=1.0, lecam_loss_weight=0.001, disc_adaptive_weight=True, norm_type="bn",
                          aug_prob=1.0).to(dev).train()
         disc = DiscriminatorStep(vq_loss, lr=disc_lr, betas=(0.9, 0.95), weight_decay=0.0005, amp_dtype=amp_dtype,
-                                 group=disc_group, always_reduce=always_reduce)
+                                 group=disc_group, always_reduce=always_reduce, max_grad_norm=getattr(args, "max_grad_norm", 0.0))
         state = {"step": 0}
 
         def gen_loss(out, imgs):
@@ -223,7 +225,8 @@ def build_train_step(args, dev, world, amp_dtype=torch.bfloat16, disc_group=None
             return torch.nn.functional.mse_loss(imgs, recons.float()) + vq + commit + entropy + (sem if sem is not None else 0.0)
         disc_fn = None
     ts = TokenizerTrainStep(model, gen_loss, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9999, use_ema=True,
-                            amp_dtype=amp_dtype, disc_step_fn=disc_fn, always_reduce=always_reduce, comm_dtype=comm_dtype)
+                            amp_dtype=amp_dtype, disc_step_fn=disc_fn, always_reduce=always_reduce, comm_dtype=comm_dtype,
+                            max_grad_norm=getattr(args, "max_grad_norm", 0.0))
     return model, ts
 
 

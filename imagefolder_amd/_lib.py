@@ -46,6 +46,11 @@ SIGNATURES = {
                                          ctypes.c_int, vp]),
     "xq_adamw_ema_step_dev": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                              ctypes.c_float, ctypes.c_float, vp, ctypes.c_float, ctypes.c_float, ctypes.c_int, vp]),
+    "xq_grad_norm_workspace_bytes": (ctypes.c_size_t, []),
+    "xq_grad_norm_clip": (ctypes.c_int, [vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, vp, ctypes.c_size_t, vp, vp]),
+    "xq_adamw_ema_step_ex": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_float, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_float, ctypes.c_float, ctypes.c_int64, vp, vp, ctypes.c_float, ctypes.c_float,
+                                            ctypes.c_int, vp]),
     "xq_diffaug_workspace_floats": (ctypes.c_size_t, [ctypes.c_int]),
     "xq_diffaug_forward": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp, vp]),
     "xq_diffaug_backward": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp, vp]),

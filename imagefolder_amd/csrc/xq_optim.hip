@@ -20,6 +20,9 @@ struct AdamArgs {
     int zero_grad, has_ema;
     const float *coeffs;   // device [2] = {step_size, inv_bc2_sqrt} (xq_adamw_ema_step_dev: the step count lives on the device so that
                            // the launch can sit in a hipGraph and still see an advancing step) or null
+    const float *clip;     // device [2] = {total gradient norm, clip coefficient <= 1} written by xq_grad_norm_clip, or null:
+                           // torch.nn.utils.clip_grad_norm_ (xqgan_train.py:456-458,471-473) without a host read — the step multiplies
+                           // grad_scale by clip[1]
 };
 
 __device__ __forceinline__ void adam1(float &p, float &g, float &m, float &v, float &e, const AdamArgs &a) {
@@ -37,6 +40,7 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, f
                                                         float *__restrict__ v, float *__restrict__ ema,
                                                         __hip_bfloat16 *__restrict__ p16, long n, AdamArgs a) {
     if (a.coeffs) { a.step_size = a.coeffs[0]; a.inv_bc2_sqrt = a.coeffs[1]; }
+    if (a.clip) a.grad_scale *= a.clip[1];
     const long n4 = n >> 2;
     const long stride = (long)gridDim.x * 256;
     float4 *p4 = reinterpret_cast<float4 *>(p), *g4 = reinterpret_cast<float4 *>(g), *m4 = reinterpret_cast<float4 *>(m),
@@ -67,9 +71,81 @@ __global__ __launch_bounds__(256) void adamw_ema_kernel(float *__restrict__ p, f
     }
 }
 
+// ---- global gradient norm + clip coefficient (torch.nn.utils.clip_grad_norm_, norm_type 2; xqgan_train.py:456-458,471-473) ----------------
+// Two launches, fixed summation order (deterministic): per-block sums of squares of g * grad_scale in double, then one block folds them:
+// out[0] = total_norm, out[1] = min(1, max_norm / (total_norm + 1e-6)) — torch's clip_coef_clamped.  max_norm <= 0: out[1] = 1 (norm only).
+constexpr int GN_BLOCK = 256;
+
+__global__ __launch_bounds__(GN_BLOCK) void grad_sqsum_kernel(const float *__restrict__ g, long n, float scale, double *__restrict__ partials) {
+    const long n4 = n >> 2;
+    const long stride = (long)gridDim.x * GN_BLOCK;
+    const float4 *g4 = reinterpret_cast<const float4 *>(g);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    double acc = 0.0;
+    int run = 0;
+    for (long i = (long)blockIdx.x * GN_BLOCK + threadIdx.x; i < n4; i += stride) {
+        float4 v = g4[i];
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        acc0 = __builtin_fmaf(v.x, v.x, acc0); acc1 = __builtin_fmaf(v.y, v.y, acc1);
+        acc2 = __builtin_fmaf(v.z, v.z, acc2); acc3 = __builtin_fmaf(v.w, v.w, acc3);
+        if (++run == 64) {      // short fp32 runs folded into a double: the sum of 1.7e8 squares keeps ~1e-7 relative accuracy
+            acc += (double)acc0 + (double)acc1 + (double)acc2 + (double)acc3;
+            acc0 = acc1 = acc2 = acc3 = 0.f; run = 0;
+        }
+    }
+    acc += (double)acc0 + (double)acc1 + (double)acc2 + (double)acc3;
+    const long t = (n4 << 2) + threadIdx.x;
+    if (blockIdx.x == 0 && t < n) { const double v = (double)(g[t] * scale); acc += v * v; }
+    __shared__ double red[GN_BLOCK];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = GN_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partials[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(GN_BLOCK) void grad_norm_finalize_kernel(const double *__restrict__ partials, int nblocks, float max_norm,
+                                                                       float *__restrict__ out) {
+    __shared__ double red[GN_BLOCK];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nblocks; i += GN_BLOCK) acc += partials[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = GN_BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float total = (float)sqrt(red[0]);
+        out[0] = total;
+        const float coef = max_norm > 0.0f ? max_norm / (total + 1e-6f) : 1.0f;
+        out[1] = coef < 1.0f ? coef : 1.0f;      // a NaN / inf norm gives a NaN coefficient, as torch's (error_if_nonfinite = False)
+        if (coef != coef) out[1] = coef;
+    }
+}
+
+extern "C" size_t xq_grad_norm_workspace_bytes(void) { return (size_t)num_cus() * 8 * sizeof(double); }
+
+extern "C" int xq_grad_norm_clip(const float *g, int64_t n, float grad_scale, float max_norm, void *workspace, size_t workspace_bytes,
+                                 float *out2, xq_stream_t stream) {
+    if (!out2 || !workspace || (n > 0 && !g)) return xq_set_error(XQ_EINVAL, "xq_grad_norm_clip: null pointer");
+    if (n < 0) return xq_set_error(XQ_EINVAL, "%s: bad n (%ld)", "xq_grad_norm_clip", (long)n);
+    if ((((uintptr_t)g) & 15) != 0 || (((uintptr_t)workspace) & 7) != 0) return xq_set_error(XQ_EINVAL, "xq_grad_norm_clip: g must be 16-byte, workspace 8-byte aligned");
+    long blocks = (n / 4 + GN_BLOCK - 1) / GN_BLOCK;
+    const long cap = (long)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    if (workspace_bytes < (size_t)blocks * sizeof(double)) return xq_set_error(XQ_EINVAL, "xq_grad_norm_clip: workspace too small");
+    hipLaunchKernelGGL(grad_sqsum_kernel, dim3((unsigned)blocks), dim3(GN_BLOCK), 0, (hipStream_t)stream, g, (long)n, grad_scale, (double *)workspace);
+    hipLaunchKernelGGL(grad_norm_finalize_kernel, dim3(1), dim3(GN_BLOCK), 0, (hipStream_t)stream, (const double *)workspace, (int)blocks, max_norm, out2);
+    return xq_check_launch("grad_norm_clip kernels");
+}
+
 static int adamw_launch(const char *fn, float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr, float beta1,
                         float beta2, float eps, float weight_decay, int64_t step, const float *coeffs, float ema_decay, float grad_scale,
-                        int zero_grad, xq_stream_t stream) {
+                        int zero_grad, xq_stream_t stream, const float *clip = nullptr) {
     if (n == 0) return XQ_OK;
     if (!p || !g || !m || !v) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     if (n < 0 || (!coeffs && step < 1)) return xq_set_error(XQ_EINVAL, "%s: bad n/step (%ld, %ld)", fn, (long)n, (long)step);
@@ -78,6 +154,7 @@ static int adamw_launch(const char *fn, float *p, float *g, float *m, float *v, 
     AdamArgs a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay;
     a.coeffs = coeffs;
+    a.clip = clip;
     if (coeffs) { a.step_size = 0.0f; a.inv_bc2_sqrt = 0.0f; }
     else {
         const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -109,4 +186,13 @@ extern "C" int xq_adamw_ema_step_dev(float *p, float *g, float *m, float *v, flo
     if (!coeffs) return xq_set_error(XQ_EINVAL, "%s: null coefficient pointer", "xq_adamw_ema_step_dev");
     return adamw_launch("xq_adamw_ema_step_dev", p, g, m, v, ema, p_bf16, n, lr, beta1, beta2, eps, weight_decay, 0, coeffs, ema_decay,
                         grad_scale, zero_grad, stream);
+}
+
+// the general form: device-resident bias-correction factors (coeffs, nullable: then the 1-based `step` is used) and a device-resident clip
+// coefficient (clip2 = the out2 of xq_grad_norm_clip, nullable)
+extern "C" int xq_adamw_ema_step_ex(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int64_t step, const float *coeffs,
+                                    const float *clip2, float ema_decay, float grad_scale, int zero_grad, xq_stream_t stream) {
+    return adamw_launch("xq_adamw_ema_step_ex", p, g, m, v, ema, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, coeffs, ema_decay,
+                        grad_scale, zero_grad, stream, clip2);
 }

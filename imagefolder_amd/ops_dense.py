@@ -299,13 +299,16 @@ class LinearFn(torch.autograd.Function):
             W = weight.detach()
             b = None if bias is None else bias.detach()
             from . import ops_f32
-            if x2.is_cuda and x2.dtype == torch.float32 and not any(ctx.needs_input_grad) and not torch.is_autocast_enabled("cuda") and x2.numel():
+            # (autograd reports needs_input_grad for a parameter under no_grad too: inference is "no gradient mode OR nothing wants one")
+            if x2.is_cuda and x2.dtype == torch.float32 and (not torch.is_grad_enabled() or not any(ctx.needs_input_grad)) \
+                    and not torch.is_autocast_enabled("cuda") and x2.numel():
                 # fp32 inference (the reference-parity path): exact fp32 MFMA product, no library call
                 nn_ops.IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"
                 return ops_f32.linear(x2, W, b).view(*shp[:-1], W.shape[0])
             if nn_ops.F32_TRAIN_LINEAR and x2.numel() and W.dim() == 2 and ops_f32.trainable(x2, W, b):
                 # fp32 training (the parity leg): the same exact fp32 MFMA product, and its two gradients in backward()
                 f32 = True
+                nn_ops._f32_train_note()
                 x2, W = x2.contiguous(), W.contiguous()
                 y = ops_f32._rows_times(x2, W, None if b is None else b.contiguous())
                 nn_ops.IMPL["linear_fp32_training"] = "hip (xq_conv2d_f32_nhwc fwd / dgrad, xq_gemm_f32_tn wgrad — fp32 MFMA)"
@@ -479,6 +482,7 @@ def attention_qkvpacked(qkv, num_heads):
         nn_ops.IMPL["attention_fp32_inference"] = "hip (xq_attention_f32)"
         return ops_f32.attention_qkvpacked(qkv, num_heads)
     if nn_ops.F32_TRAIN_LINEAR and qkv.is_cuda and ops_f32.attention_trainable(qkv, num_heads):
+        nn_ops._f32_train_note()
         nn_ops.IMPL["attention_fp32_training"] = "hip (xq_attention_f32_lse / xq_attention_f32_backward)"
         return ops_f32.AttentionF32Fn.apply(qkv, num_heads)
     nn_ops.IMPL["attention"] = "library (SDPA)"

@@ -253,9 +253,16 @@ class ArenaOptimizer:
 
     def __init__(self, params, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2, eps=1e-8, ema_decay=0.9999, use_ema=True,
                  group=None, chunk_bytes: int = 64 << 20, comm_dtype: Optional[torch.dtype] = None, hooks: bool = True,
-                 always_reduce: bool = False):
+                 always_reduce: bool = False, max_grad_norm: float = 0.0):
         self.lr, self.betas, self.weight_decay, self.eps = lr, betas, weight_decay, eps
         self.ema_decay = ema_decay
+        # xqgan_train.py:456-458,471-473: `if args.max_grad_norm != 0.0: scaler.unscale_(optimizer); clip_grad_norm_(parameters, max_grad_norm)`
+        # — after the all-reduce (DDP has averaged by then: the norm is taken of g / world), before the optimizer.  Here: one norm pass over
+        # the flat gradient arena, the clip coefficient stays on the device and the fused step multiplies it in (no host read, graph-capturable).
+        # `last_grad_norm` (device scalar, what clip_grad_norm_ returns) is valid after step().
+        self.max_grad_norm = float(max_grad_norm or 0.0)
+        self.last_grad_norm = None
+        self._clip = self._clip_ws = None
         params = list(params)
         # torch.optim.AdamW(model.parameters()) — what the reference builds (xqgan_train.py:344-347) — numbers its state by position
         # in the FULL parameter list, frozen ones included (the frozen semantic_model sits between the decoder and sem_linear):
@@ -332,6 +339,16 @@ class ArenaOptimizer:
         if a.p.is_cuda:
             stream = ctypes.c_void_p(torch.cuda.current_stream(a.p.device).cuda_stream)
             with torch.cuda.device(a.p.device):
+                clip = None
+                if self.max_grad_norm > 0.0:
+                    if self._clip is None:
+                        self._clip = torch.zeros(2, dtype=torch.float32, device=a.p.device)
+                        self._clip_ws = torch.empty(int(_lib.lib().xq_grad_norm_workspace_bytes()) // 8, dtype=torch.float64, device=a.p.device)
+                    rc = _lib.lib().xq_grad_norm_clip(ptr(a.g), a.numel, ctypes.c_float(1.0 / self.world), ctypes.c_float(self.max_grad_norm),
+                                                      ptr(self._clip_ws), self._clip_ws.numel() * 8, ptr(self._clip), stream)
+                    check(rc, "xq_grad_norm_clip")
+                    clip = self._clip
+                    self.last_grad_norm = self._clip[0]
                 if torch.cuda.is_current_stream_capturing():
                     # hipGraph capture (CapturedStep): the step count must advance on every REPLAY, so it lives on the device:
                     # counter += 1 and the two bias-correction factors are (captured) tensor ops in double, the kernel reads them
@@ -342,19 +359,19 @@ class ArenaOptimizer:
                         bc1 = 1.0 - torch.pow(torch.full_like(self._step_dev, self.betas[0]), self._step_dev)
                         bc2 = 1.0 - torch.pow(torch.full_like(self._step_dev, self.betas[1]), self._step_dev)
                         self._coeffs.copy_(torch.cat([self.lr / bc1, torch.rsqrt(bc2)]).float())
-                    rc = _lib.lib().xq_adamw_ema_step_dev(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
-                                                          ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
-                                                          ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
-                                                          ctypes.c_float(self.weight_decay), ptr(self._coeffs),
-                                                          ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
-                    check(rc, "xq_adamw_ema_step_dev")
+                    rc = _lib.lib().xq_adamw_ema_step_ex(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
+                                                         ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
+                                                         ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
+                                                         ctypes.c_float(self.weight_decay), 0, ptr(self._coeffs), ptr(clip),
+                                                         ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
+                    check(rc, "xq_adamw_ema_step_ex")
                     return
-                rc = _lib.lib().xq_adamw_ema_step(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
-                                                  ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
-                                                  ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
-                                                  ctypes.c_float(self.weight_decay), a.step_count,
-                                                  ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
-            check(rc, "xq_adamw_ema_step")
+                rc = _lib.lib().xq_adamw_ema_step_ex(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
+                                                     ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
+                                                     ctypes.c_float(self.betas[1]), ctypes.c_float(self.eps),
+                                                     ctypes.c_float(self.weight_decay), a.step_count, None, ptr(clip),
+                                                     ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
+            check(rc, "xq_adamw_ema_step_ex")
         else:
             self._step_host()
 
@@ -369,6 +386,10 @@ class ArenaOptimizer:
         """CPU twin of xq_adamw_ema_step (used by the gloo multi-process tests; same formulas, tensor ops)."""
         a, (b1, b2) = self.arena, self.betas
         g = a.g * (1.0 / self.world)
+        if self.max_grad_norm > 0.0:      # clip_grad_norm_ on the averaged gradient (xqgan_train.py:456-458)
+            total = torch.linalg.vector_norm(g.double()).float()
+            self.last_grad_norm = total
+            g = g * torch.clamp(self.max_grad_norm / (total + 1e-6), max=1.0)
         a.p.mul_(1 - self.lr * self.weight_decay)
         a.m.lerp_(g, 1 - b1)
         a.v.mul_(b2).addcmul_(g, g, value=1 - b2)
@@ -391,14 +412,14 @@ class TokenizerTrainStep:
     def __init__(self, model: torch.nn.Module, gen_loss_fn: Callable, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2,
                  eps=1e-8, ema_decay=0.9999, use_ema=True, amp_dtype: Optional[torch.dtype] = torch.bfloat16,
                  disc_step_fn: Optional[Callable] = None, group=None, chunk_bytes: int = 64 << 20,
-                 comm_dtype: Optional[torch.dtype] = None, hooks: bool = True, always_reduce: bool = False):
+                 comm_dtype: Optional[torch.dtype] = None, hooks: bool = True, always_reduce: bool = False, max_grad_norm: float = 0.0):
         self.model = model
         self.gen_loss_fn = gen_loss_fn
         self.disc_step_fn = disc_step_fn
         self.amp_dtype = amp_dtype
         self.opt = ArenaOptimizer(model.parameters(), lr=lr, betas=betas, weight_decay=weight_decay, eps=eps,
                                   ema_decay=ema_decay, use_ema=use_ema, group=group, chunk_bytes=chunk_bytes,
-                                  comm_dtype=comm_dtype, hooks=hooks, always_reduce=always_reduce)
+                                  comm_dtype=comm_dtype, hooks=hooks, always_reduce=always_reduce, max_grad_norm=max_grad_norm)
         self.arena = self.opt.arena
         self.reducer = self.opt.reducer
         self.world = self.opt.world
@@ -546,14 +567,14 @@ class DiscriminatorStep:
     step (DDP reduces them a second, wasted, time during the generator backward: SURVEY §2.3 C2)."""
 
     def __init__(self, vq_loss, lr=1e-4, betas=(0.9, 0.95), weight_decay=5e-2, amp_dtype=torch.bfloat16, group=None,
-                 always_reduce: bool = False):
+                 always_reduce: bool = False, max_grad_norm: float = 0.0):
         """group: give the discriminator its OWN process group (dist.new_group()) — a separate RCCL communicator and stream.
         On the generator's group its small all-reduce would queue behind the 689 MB gradient transfer that is in flight
         while this step runs, and the wait below would stall the compute stream until that transfer is through."""
         self.vq_loss = vq_loss
         self.amp_dtype = amp_dtype
         self.opt = ArenaOptimizer(vq_loss.discriminator.parameters(), lr=lr, betas=betas, weight_decay=weight_decay,
-                                  use_ema=False, group=group, hooks=False, always_reduce=always_reduce)
+                                  use_ema=False, group=group, hooks=False, always_reduce=always_reduce, max_grad_norm=max_grad_norm)
         self.global_step = 0
         self.fade_blur_schedule = 0
 

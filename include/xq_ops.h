@@ -164,6 +164,21 @@ int xq_adamw_ema_step_dev(float *p, float *g, float *m, float *v, float *ema, vo
                           float beta2, float eps, float weight_decay, const float *coeffs, float ema_decay, float grad_scale,
                           int zero_grad, xq_stream_t stream);
 
+/*
+ * Gradient clipping by global norm without a host read (xqgan_train.py:456-458,471-473: scaler.unscale_ + torch.nn.utils.clip_grad_norm_
+ * (parameters, max_grad_norm) when max_grad_norm != 0; norm_type 2, error_if_nonfinite False).  xq_grad_norm_clip: out2[0] = the 2-norm of
+ * g * grad_scale over the flat gradient arena (grad_scale = 1/world_size: DDP averages before the trainer clips), out2[1] =
+ * min(1, max_norm / (out2[0] + 1e-6)) (max_norm <= 0: 1).  Two launches, fixed summation order (deterministic), double accumulation.
+ * workspace: xq_grad_norm_workspace_bytes() bytes, 8-byte aligned.  xq_adamw_ema_step_ex: xq_adamw_ema_step / _dev in one entry point —
+ * `coeffs` (nullable) as in _dev, else the 1-based `step`; `clip2` (nullable) = the out2 above: the step uses g * grad_scale * clip2[1].
+ */
+size_t xq_grad_norm_workspace_bytes(void);
+int xq_grad_norm_clip(const float *g, int64_t n, float grad_scale, float max_norm, void *workspace, size_t workspace_bytes, float *out2,
+                      xq_stream_t stream);
+int xq_adamw_ema_step_ex(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr, float beta1, float beta2,
+                         float eps, float weight_decay, int64_t step, const float *coeffs, const float *clip2, float ema_decay,
+                         float grad_scale, int zero_grad, xq_stream_t stream);
+
 /* ---- fused row kernels of the ViT blocks (dino_enc/vision_transformer.py:280-339; timm Mlp) ------------------------
  * Activations are [rows][D] row-major; act_bf16 selects their dtype (1 = bf16, 0 = fp32); the residual stream,
  * LayerNorm statistics and all parameter tensors are fp32 (what bf16 autocast does upstream). */

@@ -438,6 +438,91 @@ def gen_train_backward(name, fwd_name, kw, B, alpha, beta, delta, seed):
     print("wrote", name)
 
 
+# BASELINE config 1 (VQ-4096.yaml geometry on the CNN encoder / decoder — the one model the reference runs end to end here WITHOUT any
+# shim: xqgan_model.py:454-704 Encoder / Decoder / ResnetBlock / AttnBlock / Up / Downsample): parameters whose reference gradients are
+# recorded.  conv_in / conv_out of both halves, a GroupNorm scale and shift at three depths, the AttnBlock projections, a strided
+# (Downsample) and an up-sampling conv, a nin_shortcut (1x1), the 1x1 convs around the quantizer, the codebook.
+CNN_KW = dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], enc_type="cnn", dec_type="cnn", semantic_guide="none",
+              detail_guide="none", num_latent_tokens=256, product_quant=1)
+CNN_GRAD_TAPS = ["encoder.conv_in.weight", "encoder.conv_in.bias", "encoder.conv_blocks.0.res.0.norm1.weight", "encoder.conv_blocks.0.res.0.norm1.bias",
+                 "encoder.conv_blocks.0.res.1.conv2.weight", "encoder.conv_blocks.0.downsample.conv.weight", "encoder.conv_blocks.2.res.0.nin_shortcut.weight",
+                 "encoder.conv_blocks.2.res.0.conv1.weight", "encoder.conv_blocks.4.res.0.conv1.weight", "encoder.conv_blocks.4.attn.0.q.weight",
+                 "encoder.conv_blocks.4.attn.1.proj_out.weight", "encoder.conv_blocks.4.attn.0.norm.weight", "encoder.mid.1.k.weight",
+                 "encoder.mid.1.v.bias", "encoder.mid.2.norm2.weight", "encoder.norm_out.weight", "encoder.conv_out.weight", "encoder.conv_out.bias",
+                 "quant_conv.weight", "quant_conv.bias", "quantize.embedding.weight", "post_quant_conv.weight", "post_quant_conv.bias",
+                 "decoder.conv_in.weight", "decoder.mid.1.proj_out.weight", "decoder.mid.1.norm.bias", "decoder.conv_blocks.0.attn.2.proj_out.weight",
+                 "decoder.conv_blocks.0.res.0.conv1.weight", "decoder.conv_blocks.0.upsample.conv.weight", "decoder.conv_blocks.1.res.0.nin_shortcut.weight",
+                 "decoder.conv_blocks.2.res.1.norm2.weight", "decoder.conv_blocks.3.upsample.conv.weight", "decoder.conv_blocks.4.res.2.conv2.weight",
+                 "decoder.conv_blocks.4.res.0.norm1.bias", "decoder.norm_out.weight", "decoder.norm_out.bias", "decoder.conv_out.weight", "decoder.conv_out.bias"]
+
+
+def gen_train_cnn(fwd_name, bwd_name, B, alpha, beta, delta, seed):
+    """Train-mode VQModel.forward (xqgan_model.py:268-365) AND one training backward (xqgan_train.py:439-462 without the GAN / LPIPS terms)
+    of the reference's CNN tokenizer, BASELINE config 1 — Encoder :454-514, Decoder :518-584, ResnetBlock :587-622, AttnBlock :625-659,
+    Upsample :675-686, Downsample :689-704, VectorQuantizer :745-801, add_perturbation (int(B * beta) = 0 samples at the yaml's values).
+    No stochastic layer is live (dropout_p = 0, no DropPath), so there are no draws to record besides the perturbation's (replayed as
+    ranks by the mirror).  Gradients twice: fp32, and under torch.autocast('cpu', bfloat16)."""
+    from oracle.det_init import det_state_dict
+    import contextlib, io
+    R = load_reference()
+    out, fwd = {}, {}
+    for tag, amp in (("f32", False), ("bf16", True)):
+        torch.manual_seed(seed)
+        m = R["VQ_models"]["VQ-16"](**CNN_KW).train()
+        m.load_state_dict(det_state_dict(m.state_dict(), seed))
+        x = torch.rand(B, 3, 256, 256, generator=torch.Generator().manual_seed(4321 + seed)) * 2 - 1
+        draws = {"rand": [], "randint": []}
+        real_rand, real_randint = torch.rand, torch.randint
+
+        def rec_rand(*a, **k):
+            t = real_rand(*a, **k)
+            draws["rand"].append(t.detach().cpu().clone())
+            return t
+
+        def rec_randint(*a, **k):
+            t = real_randint(*a, **k)
+            draws["randint"].append(t.detach().cpu().clone())
+            return t
+        torch.manual_seed(seed + 17)
+        torch.rand, torch.randint = rec_rand, rec_randint
+        try:
+            with contextlib.redirect_stdout(io.StringIO()), torch.autocast("cpu", dtype=torch.bfloat16, enabled=amp):
+                dec, (vq, commit, ent, usages), sem, detail, dep = m(x, 0, alpha, beta, delta)
+                loss = torch.nn.functional.mse_loss(dec.float(), x) + vq + commit + ent + dep
+        finally:
+            torch.rand, torch.randint = real_rand, real_randint
+        assert sem is None and detail is None
+        N = B * CNN_KW["num_latent_tokens"]
+        lp_prob = [t for t in draws["rand"] if tuple(t.shape) == (N,)]
+        lp_idx = [t for t in draws["randint"] if tuple(t.shape) == (N,)]
+        assert len(lp_prob) == len(lp_idx) == 1
+        if not amp:
+            d = dec.detach().float()
+            with torch.no_grad():
+                h = m.quant_conv(m.encoder(x))
+                idx = m.quantize.f_to_idxBl_or_fhat(h, to_fhat=False, v_patch_nums=None)[0]
+            fwd = dict(seed=np.int32(seed), B=np.int32(B), alpha=np.float32(alpha), beta=np.float32(beta), delta=np.int32(delta),
+                       droppath=np.zeros((0, B), np.float32), dropout_rand=np.zeros(0, np.int64), lp_prob=lp_prob[0].numpy(),
+                       lp_idx=lp_idx[0].numpy().astype(np.int64), lp_topk_val=np.zeros((0, 0), np.float32), lp_topk_idx=np.zeros((0, 0), np.int32),
+                       dec_sub=d[:, :, ::4, ::4].contiguous().numpy(), dec_mean=np.float64(d.double().mean()),
+                       dec_l2=np.float64(d.double().square().mean().sqrt()), dec_absmax=np.float32(d.abs().max()), vq=np.float32(float(vq)),
+                       commit=np.float32(float(commit)), entropy=np.float32(float(ent)), usages=np.array(usages, np.float32),
+                       sem=np.float32(0.0), dep=np.float32(float(dep)), idx=idx.numpy().astype(np.int32), f=h.numpy(), meta=np.array(str(meta())))
+        loss.backward()
+        params = dict(m.named_parameters())
+        out[f"loss_{tag}"] = np.float64(loss.item())
+        for n in CNN_GRAD_TAPS:
+            g = params[n].grad.detach().float()
+            out[f"{tag}:{n}"] = grad_subsample(g).numpy().copy()
+            out[f"{tag}:{n}:l2"] = np.float64(g.double().square().sum().sqrt())
+        # the global gradient norm as the trainer's clipping sees it (xqgan_train.py:456-458: clip_grad_norm_(vq_model.parameters(), max_grad_norm))
+        out[f"gnorm_{tag}"] = np.float64(float(torch.nn.utils.clip_grad_norm_(m.parameters(), 1e30)))
+        print(bwd_name, tag, "loss", loss.item(), "vq", float(vq), "commit", float(commit), "usages", usages, "grad norm", out[f"gnorm_{tag}"])
+    np.savez(os.path.join(OUT, fwd_name + ".npz"), **fwd)
+    np.savez_compressed(os.path.join(OUT, bwd_name + ".npz"), fwd_name=np.array(fwd_name), taps=np.array(CNN_GRAD_TAPS), meta=np.array(str(meta())), **out)
+    print("wrote", fwd_name, bwd_name)
+
+
 def gen_model_bf16(name, kw, seed):
     """the same image through the reference under torch.autocast('cpu', bfloat16): what the reference's own reduced-precision
     path does to reconstructions and indices — the yardstick for the MI355X bf16 kernels (tests/test_model_parity.py)."""
@@ -640,6 +725,10 @@ def main():
                                                  product_quant=2, half_sem=True), 2, seed=70)
         gen_tokens("tokens_cfg4_msvr10p2_4096", dict(base, codebook_size=4096, codebook_embed_dim=32, v_patch_nums=[1, 1, 2, 3, 3, 4, 5, 6, 8, 11],
                                                      num_latent_tokens=121, product_quant=2, half_sem=True), 2, seed=71)
+        return
+    if only == "traincnn":
+        # BASELINE config 1: train-mode forward + backward of the reference's CNN tokenizer, unshimmed (yaml / CLI defaults alpha = beta = 0, delta = 100)
+        gen_train_cnn("train_fwd_cfg1_cnn_vq4096", "train_bwd_cfg1_cnn_vq4096", 4, 0.0, 0.0, 100, seed=59)
         return
     if only == "trainbwd":
         for i, (nm, (kw, B, al, be, de)) in enumerate(TRAIN_CASES.items()):

@@ -14,8 +14,9 @@ def _chain_bound(abs_terms_sum, depth):
 
 @pytest.mark.parametrize("M,K,N,bias", [(514, 768, 2304, True), (37, 588, 768, True), (1028, 32, 768, False), (3, 768, 1, True), (130, 100, 70, True)])
 @pytest.mark.parametrize("entry", ["ops_f32", "ops_dense", "nn_ops"])
-def test_linear_fp32_forward_and_gradients(M, K, N, bias, entry):
+def test_linear_fp32_forward_and_gradients(M, K, N, bias, entry, monkeypatch):
     from imagefolder_amd import nn_ops, ops_dense, ops_f32
+    monkeypatch.setattr(nn_ops, "F32_TRAIN_LINEAR", True)      # parity kernels: off by default since round 5
     torch.manual_seed(M + K + N)
     x = torch.randn(2, M // 2 if M % 2 == 0 else M, K, device="cuda") if M % 2 == 0 else torch.randn(M, K, device="cuda")
     x.requires_grad_(True)

@@ -88,7 +88,7 @@ def test_gpu_fp32_indices_and_pixels_match_reference_cpu(oracle, name):
     # every dense op of the fp32 path ran on a hand-written kernel
     assert not lib_calls, f"library ops on the fp32 parity path: {sorted(set(lib_calls))}"
     want = ["conv2d_fp32_inference", "group_norm_silu_fp32_inference", "spatial_attention_fp32_inference"] if CASES[name]["enc_type"] == "cnn" \
-        else ["linear_fp32_inference", "attention_fp32_inference", "linear_fp32_training"]   # (the blocks' Linear layers: LinearFn's fp32 branch)
+        else ["linear_fp32_inference", "attention_fp32_inference"]   # (the blocks' Linear layers: LinearFn's fp32 inference branch, grad mode off)
     for key in want:
         assert nn_ops.IMPL.get(key, "").startswith("hip"), (key, nn_ops.IMPL.get(key))
     # latent within fp32 rounding of the CPU reference

@@ -99,14 +99,14 @@ MSVQ_CASES = golden_names("msvq_")
 @pytest.mark.parametrize("name", MSVQ_CASES)
 def test_msvq_ladder_matches_reference(oracle, name):
     """VectorQuantizer2 ladder (quant.py:64-223 / models/quant.py): oracle vs the reference's outputs."""
-    from conftest import msvq_n_quant, msvq_first_mismatch_mask
+    from conftest import msvq_n_quant, msvq_tie_checked_mask
     g = load_golden(name)
     nq = msvq_n_quant(g)
     o = oracle.msvq_forward(g["f"], g["E"], g["pns"], g["phi_sel"], g["phi_w"], g["phi_b"], 0.5,
                             using_znorm=bool(g["using_znorm"]), n_quant=nq, skip_last_pool=True, want_scales=True)
     idx_all = np.concatenate([i.reshape(-1) for i in o["idx"]])
-    ok = msvq_first_mismatch_mask(g, idx_all)
-    assert ok.mean() >= 0.9, f"only {ok.sum()}/{len(ok)} samples reproduce every scale's indices"
+    # every sample reproduces every scale's indices, or its first mismatching scale is an fp64-verified tie (asserted inside)
+    ok = msvq_tie_checked_mask(oracle, g, idx_all, o["f_hat_scales"])
     B = g["f"].shape[0]
     SN = len(g["pns"])
     # masked training f_hat (straight-through value) and the unmasked inference ladder
@@ -122,6 +122,36 @@ def test_msvq_ladder_matches_reference(oracle, name):
             commit = sum(0.25 * o["sq_sum"][s] / numel / o["ratio"][s] for s in range(SN))
             np.testing.assert_allclose(commit, g["commit_loss"], rtol=2e-5)
         np.testing.assert_allclose(vq, g["vq_loss"], rtol=2e-5)
+
+
+def test_ladder_tie_check_rejects_a_wrong_pick_and_accepts_a_tie(oracle):
+    """the acceptance rule of the ladder tests (conftest.msvq_tie_checked_mask) itself: an index that differs from the reference's on a
+    token whose two codes are NOT equidistant fails; a duplicated codebook row (an exact tie by construction) passes and only exempts
+    that sample's later scales."""
+    from conftest import msvq_n_quant, msvq_tie_checked_mask
+    g = load_golden("msvq_16grid_v512_c16_b4")
+    nq = msvq_n_quant(g)
+    o = oracle.msvq_forward(g["f"], g["E"], g["pns"], g["phi_sel"], g["phi_w"], g["phi_b"], 0.5, using_znorm=bool(g["using_znorm"]),
+                            n_quant=nq, skip_last_pool=True, want_scales=True)
+    idx_all = np.concatenate([i.reshape(-1) for i in o["idx"]]).copy()
+    B, pns = g["f"].shape[0], [int(p) for p in g["pns"]]
+    assert msvq_tie_checked_mask(oracle, g, idx_all, o["f_hat_scales"]).all()
+    # a wrong pick at scale 2 of sample 1
+    off = B * (pns[0] ** 2 + pns[1] ** 2) + 1 * pns[2] ** 2
+    bad = idx_all.copy()
+    bad[off] = (bad[off] + 7) % g["E"].shape[0]
+    with pytest.raises(AssertionError, match="not a tie"):
+        msvq_tie_checked_mask(oracle, g, bad, o["f_hat_scales"])
+    # an exact tie: the code picked there, duplicated into another row of the codebook -> picking the twin is accepted, sample 1 is exempt after
+    g2 = dict(g)
+    E2 = g["E"].copy()
+    twin = (int(idx_all[off]) + 7) % E2.shape[0]
+    E2[twin] = E2[int(idx_all[off])]
+    g2["E"] = E2
+    tie = idx_all.copy()
+    tie[off] = twin
+    ok = msvq_tie_checked_mask(oracle, g2, tie, o["f_hat_scales"])
+    assert ok.tolist() == [True, False, True, True]
 
 
 def test_bicubic_area_phi_building_blocks_vs_aten(oracle):

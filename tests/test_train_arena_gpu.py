@@ -44,6 +44,34 @@ def test_packed_conv_weights_follow_the_optimizer():
     assert (xg.grad.float() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item()
 
 
+def test_gradient_clipping_on_the_device_matches_clip_grad_norm_then_adamw():
+    """xq_grad_norm_clip + xq_adamw_ema_step_ex (no host read between them) == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW
+    (xqgan_train.py:456-459) on the same gradients: ragged tensor sizes (the arena's tail path), a clip that bites, one that does not,
+    and an all-zero gradient (coefficient max_norm / 1e-6 clamps to 1)."""
+    from imagefolder_amd.train import ArenaOptimizer
+    torch.manual_seed(0)
+    shapes = [(768, 770), (3,), (129, 65, 3), (1,), (4097,)]
+    for max_norm, gscale in ((0.7, 1.0), (1e9, 1.0), (0.3, 0.0)):
+        ps = [torch.nn.Parameter(torch.randn(*s, device="cuda")) for s in shapes]
+        qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+        opt = ArenaOptimizer(ps, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.03, eps=1e-8, use_ema=False, max_grad_norm=max_norm)
+        ref = torch.optim.AdamW(qs, lr=2e-3, betas=(0.9, 0.95), weight_decay=0.03, eps=1e-8)
+        for step in range(3):
+            gs = [torch.randn(*s, device="cuda") * (0.01 * (step + 1)) * gscale for s in shapes]
+            for p, o, g in zip(opt.arena.params, opt.arena.offsets, gs):
+                opt.arena.g[o:o + p.numel()].copy_(g.reshape(-1))
+            for q, g in zip(qs, gs):
+                q.grad = g.clone()
+            total = torch.nn.utils.clip_grad_norm_(qs, max_norm)
+            ref.step()
+            opt.step()
+            want = float(torch.linalg.vector_norm(torch.cat([g.reshape(-1) for g in gs]).double()))
+            assert abs(float(opt.last_grad_norm) - want) <= 2e-6 * max(want, 1e-30), (float(opt.last_grad_norm), want, float(total))
+            assert float(opt.arena.g.abs().max()) == 0.0          # zero_grad folded into the step
+        for p, q in zip(ps, qs):
+            assert torch.allclose(p, q, atol=2e-6, rtol=2e-5), float((p - q).abs().max())
+
+
 def test_bf16_shadow_follows_load_state_dict():
     from imagefolder_amd import ops_dense
     from imagefolder_amd.train import ArenaOptimizer

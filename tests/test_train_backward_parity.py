@@ -1,6 +1,10 @@
 """M1 / T1 backward: one training backward of VQModel at model level against the REFERENCE's autograd (xqgan_train.py:439-462,
 xqgan_model.py:268-365), BASELINE configs 2-5 (ViT-B, P = 1 / 2, single scale / 10-scale ladder, quantizer dropout, latent
-perturbation, semantic branch).
+perturbation, semantic branch) and, since round 5, config 1 on the CNN encoder / decoder (xqgan_model.py:454-704; the reference's own
+Encoder / Decoder / ResnetBlock / AttnBlock / Up / Downsample run UNSHIMMED by oracle/make_golden.py gen_train_cnn; 38 tapped tensors: conv_in /
+conv_out of both halves, GroupNorm scales / shifts at five depths, AttnBlock q / k / v / proj_out, the strided and the up-sampling convs, the 1x1
+shortcuts, quant_conv / post_quant_conv, the codebook) — the implicit-GEMM data / weight gradient, GroupNorm backward and spatial-attention
+backward kernels pinned to the reference's autograd instead of to ATen-GPU op by op.
 
 Goldens (oracle/make_golden.py gen_train_backward, tests/golden/train_bwd_*.npz): the unmodified reference model on the host,
 deterministic weights, every random draw recorded; loss = mse(recons, imgs) + vq + commit + entropy + semantic + dependency (the
@@ -51,7 +55,7 @@ def _rel(a, b):
     return float(np.linalg.norm(a.astype(np.float64) - b.astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30))
 
 
-def _run(name, amp_dtype, monkeypatch, lr=1e-4):
+def _run(name, amp_dtype, monkeypatch, lr=1e-4, max_grad_norm=0.0):
     """one TokenizerTrainStep.step of the mirror with the reference's draws replayed; returns ({param: grad}, {param: value after the step})"""
     from imagefolder_amd import latent_perturbation, xqgan_model
     from imagefolder_amd.dino_enc.vision_transformer import DropPath
@@ -83,8 +87,9 @@ def _run(name, amp_dtype, monkeypatch, lr=1e-4):
 
     def gen_loss(out, imgs):
         recons, (vq, commit, entropy, usages), sem, detail, dep = out
-        return torch.nn.functional.mse_loss(recons.float(), imgs) + vq + commit + entropy + sem + dep
-    ts = TokenizerTrainStep(m, gen_loss, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8, use_ema=False, amp_dtype=amp_dtype)
+        return torch.nn.functional.mse_loss(recons.float(), imgs) + vq + commit + entropy + (0.0 if sem is None else sem) + dep
+    ts = TokenizerTrainStep(m, gen_loss, lr=lr, betas=(0.9, 0.95), weight_decay=0.0, eps=1e-8, use_ema=False, amp_dtype=amp_dtype,
+                            max_grad_norm=max_grad_norm)
     names = [n for n, p in m.named_parameters() if p.requires_grad]
     grads = {}
     opt_step = ts.opt.step
@@ -101,25 +106,39 @@ def _run(name, amp_dtype, monkeypatch, lr=1e-4):
     finally:
         DropPath.REPLAY = None
     after = {n: p.detach().clone() for n, p in m.named_parameters() if p.requires_grad}
+    if max_grad_norm:
+        after["__grad_norm__"] = float(ts.opt.last_grad_norm)
     return float(loss), grads, after, seed
 
 
-@pytest.mark.parametrize("name", ["train_bwd_cfg2_vq8192", "train_bwd_cfg3_vp2_16384", "train_bwd_cfg4_msvr10p2_4096", "train_bwd_cfg5_robusttok"])
+@pytest.mark.parametrize("name", ["train_bwd_cfg1_cnn_vq4096", "train_bwd_cfg2_vq8192", "train_bwd_cfg3_vp2_16384", "train_bwd_cfg4_msvr10p2_4096",
+                                  "train_bwd_cfg5_robusttok"])
 def test_model_level_gradients_match_the_reference_autograd(name, monkeypatch):
     gb = load_golden(name)
     taps = [str(t) for t in gb["taps"]]
     assert len(taps) >= 20
+    cnn = name == "train_bwd_cfg1_cnn_vq4096"
     # ---- (a) fp32 ----
     lr = 1e-4
     from imagefolder_amd import nn_ops
-    for key in ("linear_fp32_training", "linear_library", "attention_fp32_training", "attention_library", "attention"):
+    monkeypatch.setattr(nn_ops, "F32_TRAIN_LINEAR", True)      # the parity kernels of csrc/xq_f32.hip (off by default: 1/16 of the bf16 rate)
+    for key in ("linear_fp32_training", "linear_library", "attention_fp32_training", "attention_library", "attention", "conv2d_library",
+                "group_norm_library", "conv2d", "group_norm_silu", "spatial_attention", "conv2d_downsample", "conv2d_upsample"):
         nn_ops.IMPL.pop(key, None)
-    loss32, g32, after32, seed = _run(name, None, monkeypatch, lr=lr)
-    # the Linear layers (forward, data gradient, weight gradient) and the attention (forward, backward) of this leg ran on the hand-written
-    # fp32 kernels, none on the library
-    assert nn_ops.IMPL.get("linear_fp32_training", "").startswith("hip") and "linear_library" not in nn_ops.IMPL
-    assert nn_ops.IMPL.get("attention_fp32_training", "").startswith("hip") and "attention_library" not in nn_ops.IMPL
-    assert not nn_ops.IMPL.get("attention", "").startswith("library")
+    # config 1 also runs the clipping pass (max_grad_norm far above the norm: coefficient 1) to read the GLOBAL gradient norm the trainer's
+    # clip_grad_norm_ sees (xqgan_train.py:456-458) against the reference's
+    loss32, g32, after32, seed = _run(name, None, monkeypatch, lr=lr, max_grad_norm=1e30 if cnn else 0.0)
+    if cnn:
+        np.testing.assert_allclose(after32["__grad_norm__"], float(gb["gnorm_f32"]), rtol=1e-4)
+    if not cnn:
+        # the Linear layers (forward, data gradient, weight gradient) and the attention (forward, backward) of this leg ran on the hand-written
+        # fp32 kernels, none on the library
+        assert nn_ops.IMPL.get("linear_fp32_training", "").startswith("hip") and "linear_library" not in nn_ops.IMPL
+        assert nn_ops.IMPL.get("attention_fp32_training", "").startswith("hip") and "attention_library" not in nn_ops.IMPL
+        assert not nn_ops.IMPL.get("attention", "").startswith("library")
+    # (config 1: the fp32 TRAINING step of the CNN runs the convolutions / GroupNorm on ATen-GPU — this leg pins the module wiring, the
+    #  quantizer's hand-written backward and the 1x1 convs around it to the reference's autograd; the hand-written implicit-GEMM forward /
+    #  data-gradient / weight-gradient, GroupNorm and spatial-attention kernels are what leg (b) runs, asserted there)
     np.testing.assert_allclose(loss32, float(gb["loss_f32"]), rtol=1e-4 if name == "train_bwd_cfg5_robusttok" else 5e-6)
     rows = []
     for n in taps:
@@ -127,7 +146,12 @@ def test_model_level_gradients_match_the_reference_autograd(name, monkeypatch):
         got = _sub(g32[n]).float().cpu().numpy()
         rows.append((n, _rel(got, ref), float(gb[f"f32:{n}:l2"])))
     # ---- (b) bf16 training kernels ----
+    monkeypatch.setattr(nn_ops, "STRICT_HIP", True)      # a dense op of the bf16 step that drops to a library raises
     loss16, g16, _, _ = _run(name, torch.bfloat16, monkeypatch, lr=lr)
+    monkeypatch.setattr(nn_ops, "STRICT_HIP", False)
+    if cnn:      # every dense op of the bf16 step of the CNN ran on a hand-written kernel
+        for key in ("conv2d", "group_norm_silu", "spatial_attention", "conv2d_downsample", "conv2d_upsample", "conv2d_from_rgb", "conv2d_to_rgb"):
+            assert nn_ops.IMPL.get(key, "").startswith("hip"), (key, nn_ops.IMPL.get(key))
     rows16 = []
     for n in taps:
         ref32, ref16 = gb[f"f32:{n}"], gb[f"bf16:{n}"]

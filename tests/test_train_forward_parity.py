@@ -1,5 +1,6 @@
-"""M1: VQModel.forward in train() mode against the reference (xqgan_model.py:268-365), BASELINE configs 2-5 at model level:
-P = 1 and P = 2, single-scale and the 10-scale ladder, quantizer dropout, the semantic branch, latent perturbation.
+"""M1: VQModel.forward in train() mode against the reference (xqgan_model.py:268-365), all five BASELINE configs at model level:
+P = 1 and P = 2, single-scale and the 10-scale ladder, quantizer dropout, the semantic branch, latent perturbation (configs 2-5, ViT-B)
+and config 1 on the CNN encoder / decoder (xqgan_model.py:454-704) — the one model the reference runs here without any shim.
 
 Goldens (oracle/make_golden.py gen_train_forward): the unmodified reference model with deterministic weights on CPU in fp32,
 with EVERY random draw of the pass recorded — the DropPath masks of the 24 transformer blocks, the per-sample quantizer
@@ -29,6 +30,9 @@ CASES = {
                                          num_latent_tokens=121, product_quant=2, codebook_drop=0.1, half_sem=True),
     "train_fwd_cfg5_robusttok": dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], num_latent_tokens=256, product_quant=1,
                                      codebook_drop=0.0, half_sem=False),
+    # BASELINE config 1 (oracle/make_golden.py gen_train_cnn): the reference's CNN VQModel, unshimmed, B = 4, alpha = beta = 0
+    "train_fwd_cfg1_cnn_vq4096": dict(codebook_size=4096, codebook_embed_dim=64, v_patch_nums=[16], num_latent_tokens=256, product_quant=1,
+                                      enc_type="cnn", dec_type="cnn", semantic_guide="none"),
 }
 
 
@@ -79,6 +83,9 @@ def test_train_mode_forward_matches_reference(name, monkeypatch):
     finally:
         DropPath.REPLAY = None
     dec = dec.float().cpu()
+    if sem is None:      # semantic_guide = 'none' (config 1): upstream returns None (xqgan_model.py:341-365)
+        assert CASES[name].get("semantic_guide") == "none"
+        sem = torch.zeros(())
     diff = (dec[:, :, ::4, ::4].numpy() - g["dec_sub"])
     frac = float(np.mean(np.abs(diff) <= 1e-4))
     print(f"{name}: pixels within 1e-4: {100 * frac:.2f} %, max |diff| {np.abs(diff).max():.2e}; vq {float(vq):.6f} / {float(g['vq']):.6f}; "

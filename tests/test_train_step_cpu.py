@@ -106,6 +106,31 @@ def test_host_optimizer_matches_torch_adamw_and_reference_ema():
             assert torch.allclose(ema[n], q, atol=1e-6, rtol=1e-5), n
 
 
+def test_gradient_clipping_matches_clip_grad_norm_then_adamw():
+    """max_grad_norm != 0 (xqgan_train.py:456-458: clip_grad_norm_(vq_model.parameters(), max_grad_norm) between backward and optimizer.step):
+    the host twin of xq_grad_norm_clip + xq_adamw_ema_step_ex against torch's own pair, over steps where the clip is active and where it is not."""
+    from imagefolder_amd.train import TokenizerTrainStep
+    for max_norm in (0.05, 1e6):
+        torch.manual_seed(3)
+        m, ref = Tiny(), Tiny()
+        ts = TokenizerTrainStep(m, _loss, lr=3e-3, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8, ema_decay=0.99, amp_dtype=None, max_grad_norm=max_norm)
+        ps = [p for p in ref.parameters() if p.requires_grad]
+        opt = torch.optim.AdamW(ps, lr=3e-3, betas=(0.9, 0.95), weight_decay=0.05, eps=1e-8)
+        clipped = 0
+        for _ in range(5):
+            x = torch.randn(8, 5)
+            ts.step(x)
+            opt.zero_grad()
+            _loss(ref(x, 0, 0, 0, 0), x).backward()
+            total = torch.nn.utils.clip_grad_norm_(ps, max_norm)
+            clipped += int(float(total) > max_norm)
+            opt.step()
+            assert abs(float(ts.opt.last_grad_norm) - float(total)) <= 1e-5 * float(total)
+        assert clipped == (5 if max_norm < 1 else 0)
+        for p, q in zip(m.parameters(), ref.parameters()):
+            assert torch.allclose(p, q, atol=1e-6, rtol=1e-5)
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
