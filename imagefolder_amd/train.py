@@ -140,7 +140,15 @@ class GradAllReducer:
     that received no gradient this step), `wait()` makes the compute stream wait for all of them and records how long it
     had to (`exposed_ms`, HIP events).  Anything enqueued between start() and wait() — the discriminator step — overlaps.
     comm_dtype=torch.bfloat16 halves the bytes on the links (cast -> all-reduce -> cast back into the fp32 arena); default
-    is the arena's fp32, which is what DDP reduces.  always=True runs the collectives at world size 1 too (tests)."""
+    is the arena's fp32, which is what DDP reduces.  always=True runs the collectives at world size 1 too (tests).
+
+    Launch ORDER (round 5).  Collectives of one communicator must be issued in the same sequence on every rank; the order in which hooks
+    complete chunks is a property of each rank's autograd graph (node sequence numbers), which nothing forces to be equal across ranks.
+    So chunks leave in ONE fixed order, identical on all ranks by construction: a completed chunk is enqueued only once every chunk ahead
+    of it in that order has been (DDP's rule for its buckets).  The order: rank 0's completion order observed during the FIRST armed
+    backward pass (that pass launches nothing from the hooks; its chunks go out in start()), broadcast once — the true backward order of
+    this model, so later steps lose no overlap to the rule; until then, and for chunks no hook ever completes, descending arena order
+    (the backward pass walks the model from its end)."""
 
     def __init__(self, flat_grad: torch.Tensor, group=None, chunk_bytes: int = 64 << 20, params=None, offsets=None,
                  comm_dtype: Optional[torch.dtype] = None, always: bool = False, collect_fn: Optional[Callable] = None):
@@ -169,6 +177,11 @@ class GradAllReducer:
             self._need[c] += 1
         self._left = list(self._need)
         self._launched = [False] * len(self.chunks)
+        self._ready = [False] * len(self.chunks)
+        self._order = list(range(len(self.chunks) - 1, -1, -1))      # fixed launch order (see the class docstring)
+        self._pos = 0
+        self._learned = not (params is not None and len(self.chunks) > 1)   # nothing to learn without hooks
+        self._seen = []                                               # completion order of the learning pass
         self._works = []
         self._armed = False
         self.exposed_ms = []          # one entry per wait(): time the compute stream was blocked by the collectives
@@ -182,9 +195,32 @@ class GradAllReducer:
             if not self._armed:
                 return
             self._left[ci] -= 1
-            if self._left[ci] == 0 and not self._launched[ci]:
-                self._launch(ci)
+            if self._left[ci] == 0 and not self._launched[ci] and not self._ready[ci]:
+                self._ready[ci] = True
+                if not self._learned:
+                    self._seen.append(ci)      # learning pass: record, launch nothing (start() sends everything in the default order)
+                else:
+                    self._drain()
         return hook
+
+    def _drain(self):
+        """enqueue, in the fixed order, every chunk that is complete and has no incomplete chunk ahead of it"""
+        while self._pos < len(self._order) and self._ready[self._order[self._pos]]:
+            ci = self._order[self._pos]
+            self._pos += 1
+            if not self._launched[ci]:
+                self._launch(ci)
+
+    def _adopt_learned_order(self):
+        """after the learning pass: rank 0's completion order (chunks no hook completed appended in descending arena order) becomes
+        everyone's launch order — one small broadcast, once per reducer"""
+        order = list(self._seen) + [c for c in range(len(self.chunks) - 1, -1, -1) if c not in set(self._seen)]
+        t = torch.tensor(order, dtype=torch.int64, device=self.g.device)
+        if self.world > 1:
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        got = [int(v) for v in t.tolist()]
+        assert sorted(got) == list(range(len(self.chunks))), got
+        self._order, self._learned, self._seen = got, True, []
 
     def _launch(self, ci):
         s, e = self.chunks[ci]
@@ -206,15 +242,20 @@ class GradAllReducer:
         assert not self._works, "previous all-reduce not waited for"
         self._left = list(self._need)
         self._launched = [False] * len(self.chunks)
+        self._ready = [False] * len(self.chunks)
+        self._pos = 0
         self._armed = True
 
     def start(self):
         if not self.active:
             return
-        self._armed = False
-        for ci in range(len(self.chunks)):
+        was_armed, self._armed = self._armed, False
+        for ci in self._order:                 # whatever the hooks have not sent, in the fixed order
             if not self._launched[ci]:
                 self._launch(ci)
+        self._pos = len(self._order)
+        if not self._learned and was_armed:
+            self._adopt_learned_order()
 
     def wait(self):
         if not self._works:

@@ -103,7 +103,7 @@ CASES = {
 B_RANK, STEPS, IMG, EPS = 8, 2, 16, 1e-3
 
 
-def _build(case, adaptive, lecam):
+def _build(case, adaptive, lecam, comm_dtype=None):
     """the bundle xqgan_train.py builds (:285-347): VQModel + VQLoss + both optimizers, at a geometry the host runs in seconds"""
     from imagefolder_amd.xqgan_model import VQModel, ModelArgs
     from imagefolder_amd.train import TokenizerTrainStep, DiscriminatorStep
@@ -140,7 +140,7 @@ def _build(case, adaptive, lecam):
         return vq_loss(codebook_loss, sem, detail, dep, imgs, recons, optimizer_idx=0, global_step=state["step"],
                        last_layer=model.decoder.last_layer, fade_blur_schedule=0)
     ts = TokenizerTrainStep(model, gen_loss, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.0, eps=EPS, ema_decay=0.99, use_ema=True,
-                            amp_dtype=None, disc_step_fn=disc, chunk_bytes=64 << 10)
+                            amp_dtype=None, disc_step_fn=disc, chunk_bytes=64 << 10, comm_dtype=comm_dtype)
     return model, vq_loss, ts
 
 
@@ -149,10 +149,10 @@ def _data(world):
     return torch.rand(STEPS, world * B_RANK, 3, IMG, IMG, generator=g) * 2 - 1
 
 
-def _run(case, adaptive, lecam, rank, world):
+def _run(case, adaptive, lecam, rank, world, comm_dtype=None, data_world=2):
     from oracle import cpu_modules
-    model, vq_loss, ts = _build(case, adaptive, lecam)
-    data = _data(2)
+    model, vq_loss, ts = _build(case, adaptive, lecam, comm_dtype)
+    data = _data(data_world)
     usages = None
     first_grads = {}
     opt_step = ts.opt.step
@@ -233,3 +233,111 @@ def test_real_train_step_with_adaptive_weight_and_lecam_keeps_the_ranks_in_step(
             continue
         assert torch.equal(v, r1["sd"][k]), f"ranks diverged: {k}"
         assert torch.isfinite(v.float()).all(), k
+
+
+# ---- round 5: world size 4, bf16 on the links, chunks completing out of arena order — and in a DIFFERENT order on every rank -------------
+def _worker4(rank, world, port, out, case):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(max(1, (os.cpu_count() or 4) // world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sd, usages, ts, grads = _run(case, False, False, rank, world, comm_dtype=torch.bfloat16, data_world=4)
+    r = ts.reducer
+    assert r.active and len(r.chunks) > 3 and r.comm_dtype == torch.bfloat16
+    # the launch order was learned from rank 0's first backward pass and is NOT the arena order (the backward pass reaches the decoder's
+    # chunks before the encoder's, the semantic head's before both)
+    assert r._learned and sorted(r._order) == list(range(len(r.chunks))) and r._order != list(range(len(r.chunks)))
+    torch.save({"sd": sd, "usages": usages, "order": list(r._order)}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_real_train_step_four_ranks_bf16_links_equals_single_process(tmp_path):
+    """world size 4, comm_dtype = bf16 (bench.py --grad-comm bf16), the real model + VQLoss + discriminator step: every rank ends on
+    bit-identical parameters, every rank used the same launch order, and the result stays within bf16 rounding of the gradient of the
+    single-process step on the global batch of 32."""
+    world, port, out = 4, _free_port(), str(tmp_path / "dp4")
+    mp.spawn(_worker4, args=(world, port, out, "vq_p1"), nprocs=world, join=True)
+    rs = [torch.load(out + f".{r}") for r in range(world)]
+    for r in rs[1:]:
+        assert r["order"] == rs[0]["order"]
+        for k, v in rs[0]["sd"].items():
+            assert torch.equal(v, r["sd"][k]), f"ranks diverged: {k}"
+    single, usages, _, _ = _run("vq_p1", False, False, 0, 1, data_world=4)
+    worst = 0.0
+    for k, v in single.items():
+        if v.dtype.is_floating_point and k.startswith("model."):
+            worst = max(worst, (v - rs[0]["sd"][k]).abs().max().item())
+    # Adam (eps 1e-3) moves a weight by at most lr = 1e-3 per step; a bf16-rounded gradient (2^-9 relative) changes that by a small
+    # fraction of it.  Zero would mean the bf16 path did not run.
+    assert 0.0 < worst <= 2.5e-4, worst
+    np.testing.assert_allclose(usages, rs[0]["usages"], atol=0.5)
+
+
+class _Branchy(torch.nn.Module):
+    """three independent branches whose autograd nodes are created in a RANK-DEPENDENT order: the hooks of the gradient all-reduce then
+    complete the chunks in a different sequence on every rank"""
+
+    def __init__(self):
+        super().__init__()
+        torch.manual_seed(5)
+        self.br = torch.nn.ModuleList([torch.nn.Sequential(torch.nn.Linear(6, 40), torch.nn.Tanh(), torch.nn.Linear(40, 6)) for _ in range(3)])
+        self.order = [0, 1, 2]
+
+    def forward(self, x, epoch, alpha, beta, delta):
+        outs = {}
+        for i in self.order:                   # creation order of the nodes = (reverse) order of the backward pass
+            outs[i] = self.br[i](x)
+        return (outs[0] + 2.0 * outs[1] - outs[2],)
+
+
+def _loss_b(out, x):
+    return (out[0] - x).square().mean()
+
+
+def _branchy_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imagefolder_amd.train import TokenizerTrainStep
+    m = _Branchy()
+    m.order = [[0, 1, 2], [2, 1, 0], [1, 0, 2], [2, 0, 1]][rank]
+    ts = TokenizerTrainStep(m, _loss_b, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9, amp_dtype=None, chunk_bytes=256)
+    r = ts.reducer
+    assert len(r.chunks) >= 6
+    seen = []
+    launch = r._launch
+    r._launch = lambda ci: (seen.append(ci), launch(ci))[1]
+    g = torch.Generator().manual_seed(77)
+    data = torch.randn(4, world * 4, 6, generator=g)
+    per_step = []
+    for it in range(4):
+        seen.clear()
+        ts.step(data[it, rank * 4:(rank + 1) * 4])
+        per_step.append(list(seen))
+    torch.save({"sd": {k: v.clone() for k, v in m.state_dict().items()}, "launches": per_step, "order": list(r._order)}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunks_completing_in_a_rank_dependent_order_still_reduce_in_one_order(tmp_path):
+    """the hooks finish the chunks in a different sequence on each of 4 ranks (rank-dependent graph construction order); every rank must
+    still ISSUE its collectives in one common sequence — otherwise chunk c of one rank is summed with chunk c' of another (or the job
+    hangs).  Result == the single-process step on the global batch."""
+    world, port, out = 4, _free_port(), str(tmp_path / "br")
+    mp.spawn(_branchy_worker, args=(world, port, out), nprocs=world, join=True)
+    rs = [torch.load(out + f".{r}") for r in range(world)]
+    for r in rs[1:]:
+        assert r["launches"] == rs[0]["launches"], "ranks issued their collectives in different orders"
+        assert r["order"] == rs[0]["order"]
+    assert rs[0]["launches"][1] == rs[0]["order"] and rs[0]["order"] != sorted(rs[0]["order"])      # steps after the learning pass: the learned order
+    from imagefolder_amd.train import TokenizerTrainStep
+    m = _Branchy()
+    ts = TokenizerTrainStep(m, _loss_b, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9, amp_dtype=None)
+    g = torch.Generator().manual_seed(77)
+    data = torch.randn(4, world * 4, 6, generator=g)
+    for it in range(4):
+        ts.step(data[it])
+    for k, v in m.state_dict().items():
+        for r in rs:
+            assert torch.allclose(v, r["sd"][k], atol=1e-6, rtol=1e-5), k
