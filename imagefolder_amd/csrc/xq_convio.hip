@@ -363,10 +363,12 @@ extern "C" int xq_conv3x3_from3_forward(const void *x_planar, int x_is_bf16, con
     long blocks = (tiles + 3) / 4;
     const long cap = (long)num_cus() * (Cout == 128 ? 3 : 4);      // resident workgroups per CU at 137 / 121 VGPRs; each wave walks its tiles
     if (blocks > cap) blocks = cap;
+    const int pslot = xq::prof_begin(XQ_PROF_CONV_FROM3, (double)total * (3.0 * (x_is_bf16 ? 2.0 : 4.0) + 2.0 * Cout), s);
 #define FROM3M(T, CO) hipLaunchKernelGGL((conv3x3_from3_mfma_kernel<T, CO>), dim3((unsigned)blocks), dim3(256), 0, s, (const T *)x_planar, w_kc, bias, B, H, W, relu, (char *)y_nhwc)
     if (x_is_bf16) { if (Cout == 128) FROM3M(__hip_bfloat16, 128); else FROM3M(__hip_bfloat16, 64); }
     else { if (Cout == 128) FROM3M(float, 128); else FROM3M(float, 64); }
 #undef FROM3M
+    xq::prof_end(pslot, s);
     return xq_check_launch(fn);
 }
 

@@ -405,6 +405,7 @@ extern "C" int xq_res_ln_forward(const float *x, const void *y, const float *gam
     if (rows < 0 || rows_per_sample < 1) return xq_set_error(XQ_EINVAL, "%s: bad rows", fn);
     hipStream_t s = (hipStream_t)stream;
     const int blocks = row_blocks_fwd(rows);
+    const int pslot = xq::prof_begin(XQ_PROF_RES_LN_FWD, (double)rows * D * (4.0 + (y ? (act_bf16 ? 2.0 : 4.0) : 0.0) + (x_new ? 4.0 : 0.0) + (act_bf16 ? 2.0 : 4.0)), s);
 #define FWD_BF16(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const bf16 *)y, \
         gamma, mask, (long)rows, rows_per_sample, lnw, lnb, eps, x_new, (bf16 *)a, mean, rstd)
 #define FWD_F32(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const float *)y, \
@@ -412,6 +413,7 @@ extern "C" int xq_res_ln_forward(const float *x, const void *y, const float *gam
     if (act_bf16) { DISPATCH_D(D, FWD_BF16) } else { DISPATCH_D(D, FWD_F32) }
 #undef FWD_BF16
 #undef FWD_F32
+    xq::prof_end(pslot, s);
     return xq_check_launch(fn);
 }
 
@@ -425,6 +427,8 @@ extern "C" int xq_res_ln_backward(const void *g_a, const float *g_xnew, const fl
     if (y && !g_y) return xq_set_error(XQ_EINVAL, "%s: g_y required when y is given", fn);
     hipStream_t s = (hipStream_t)stream;
     const int blocks = row_blocks(rows);
+    const double asz = act_bf16 ? 2.0 : 4.0;
+    const int pslot = xq::prof_begin(XQ_PROF_RES_LN_BWD, (double)rows * D * ((g_a ? asz : 0.0) + (g_xnew ? 4.0 : 0.0) + 4.0 + (y ? 2.0 * asz : 0.0) + 4.0), s);
 #define BWD_BF16(NV, VEC) hipLaunchKernelGGL((res_ln_bwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const bf16 *)g_a, g_xnew, \
         x_new, mean, rstd, lnw, (const bf16 *)y, gamma, mask, (long)rows, rows_per_sample, g_x, (bf16 *)g_y, partials)
 #define BWD_F32(NV, VEC) hipLaunchKernelGGL((res_ln_bwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const float *)g_a, g_xnew, \
@@ -433,6 +437,7 @@ extern "C" int xq_res_ln_backward(const void *g_a, const float *g_xnew, const fl
 #undef BWD_BF16
 #undef BWD_F32
     launch_finalize(partials, blocks, 4, D, g_lnw, g_lnb, g_gamma, g_ybias, accumulate, s);
+    xq::prof_end(pslot, s);
     return xq_check_launch(fn);
 }
 

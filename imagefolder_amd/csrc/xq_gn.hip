@@ -246,6 +246,7 @@ extern "C" int xq_groupnorm_silu_forward(const void *x, const float *w, const fl
     const int ns = gn_slabs(HW, C, &spx);
     const float n = (float)HW * (float)(C / G);
     const bf16 *xp = (const bf16 *)x;
+    const int pslot = xq::prof_begin(XQ_PROF_GROUPNORM, (double)B * HW * C * 8.0, s);
     hipLaunchKernelGGL((gn_reduce_kernel<0>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
                        workspace, (float *)nullptr);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, workspace, ns, G, n, eps, 0, mean, (float *)nullptr);
@@ -255,6 +256,7 @@ extern "C" int xq_groupnorm_silu_forward(const void *x, const float *w, const fl
     int apx;
     const int ans = gn_apply_slabs(HW, C, &apx);
     hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(ans, B), dim3(256), 0, s, xp, w, bias, mean, rstd, HW, C, G, silu, apx, (bf16 *)y);
+    xq::prof_end(pslot, s);
     return xq_check_launch(fn);
 }
 
@@ -276,6 +278,7 @@ extern "C" int xq_groupnorm_silu_backward(const void *x, const void *dy, const f
     float *part_g = workspace;                               // [B][ns][G][2]
     float *m1 = workspace + (size_t)B * ns * G * 2 + (size_t)B * ns * 2 * C;   // after the (unused here) per-channel area
     float *m2 = m1 + (size_t)B * G;
+    const int pslot = xq::prof_begin(XQ_PROF_GROUPNORM, (double)B * HW * C * 10.0, s);
     hipLaunchKernelGGL((gn_reduce_kernel<2>), dim3(ns, B), dim3(256), 0, s, (const bf16 *)x, (const bf16 *)dy, w, bias, mean, rstd, HW, C, G, silu,
                        spx, part_g, g_wb_partials);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, part_g, ns, G, n, 0.0f, 2, m1, m2);
@@ -283,5 +286,6 @@ extern "C" int xq_groupnorm_silu_backward(const void *x, const void *dy, const f
     const int ans = gn_apply_slabs(HW, C, &apx);
     hipLaunchKernelGGL(gn_apply_bwd_kernel, dim3(ans, B), dim3(256), 0, s, (const bf16 *)x, (const bf16 *)dy, w, bias, mean, rstd, m1, m2, HW, C, G,
                        silu, apx, (bf16 *)dx);
+    xq::prof_end(pslot, s);
     return xq_check_launch(fn);
 }

@@ -168,8 +168,10 @@ static int adamw_launch(const char *fn, float *p, float *g, float *m, float *v, 
     const long cap = (long)num_cus() * 8;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+    const int pslot = xq::prof_begin(XQ_PROF_ADAMW, (double)n * (4.0 * ((ema ? 5 : 4) + (ema ? 4 : 3) + (zero_grad ? 1 : 0)) + (p_bf16 ? 2.0 : 0.0)), (hipStream_t)stream);
     hipLaunchKernelGGL(adamw_ema_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, ema, (__hip_bfloat16 *)p_bf16,
                        (long)n, a);
+    xq::prof_end(pslot, (hipStream_t)stream);
     return xq_check_launch("adamw_ema_kernel");
 }
 

@@ -732,6 +732,8 @@ extern "C" int xq_vq_forward(const float *z, int B, int C, int HW, const float *
     rc = launch_assign(codebook_norm ? XQ_MODE_L2_NORMED : XQ_MODE_L2_RAW, C, z, N, HW, E, V, ws, s);
     if (rc) return rc;
     float *partials = loss_sq ? ws.partials : nullptr;
+    // vq_finish: z read (4C) + z_q written (4C) + the gathered codebook rows (4C, L2-resident) + idx (8) per token
+    const int pslot_f = xq::prof_begin(XQ_PROF_VQ_ELEM, (double)N * (8.0 * C + 8.0) + (double)V * C * 4.0, s);
     switch (C) {
         case 8: launch_finish<8>(codebook_norm != 0, z, N, HW, E, ws.keys, ste, zq, idx, hist, partials, blocks, s); break;
         case 16: launch_finish<16>(codebook_norm != 0, z, N, HW, E, ws.keys, ste, zq, idx, hist, partials, blocks, s); break;
@@ -739,6 +741,7 @@ extern "C" int xq_vq_forward(const float *z, int B, int C, int HW, const float *
         case 64: launch_finish<64>(codebook_norm != 0, z, N, HW, E, ws.keys, ste, zq, idx, hist, partials, blocks, s); break;
     }
     if (loss_sq) hipLaunchKernelGGL(reduce_partials_kernel, dim3(1), dim3(256), 0, s, ws.partials, blocks, loss_sq);
+    xq::prof_end(pslot_f, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "vq_finish_kernel: %s", hipGetErrorString(e)); return XQ_ELAUNCH; }
     return XQ_OK;
@@ -815,12 +818,15 @@ extern "C" int xq_vq_backward(const float *z, int B, int C, int HW, const float 
         bwd_ws_layout(N, C, V, (char *)workspace, &ws);
     }
     const BwdWs *w = scatter ? &ws : nullptr;
+    // vq_backward + codebook gradient: z, g_out read, g_z written (12C B/token) + idx + the V x C gradient written
+    const int pslot_b = xq::prof_begin(XQ_PROF_VQ_ELEM, (double)N * (12.0 * C + 8.0) + (double)V * C * 4.0, s);
     switch (C) {
         case 8: launch_bwd<8>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
         case 16: launch_bwd<16>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
         case 32: launch_bwd<32>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
         case 64: launch_bwd<64>(codebook_norm != 0, z, N, HW, E, V, idx, g_out, g_vq, g_commit, beta, g_z, g_E, w, s); break;
     }
+    xq::prof_end(pslot_b, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "vq_backward_kernel: %s", hipGetErrorString(e)); return XQ_ELAUNCH; }
     return XQ_OK;

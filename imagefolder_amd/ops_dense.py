@@ -263,6 +263,15 @@ class LinearFn(torch.autograd.Function):
     (parity path) and shapes outside the kernels' contract: library GEMMs.
     bias_grad_external: the bias gradient is delivered by the fused kernel that consumes/produces g_y."""
 
+    # grad mode of the CALLER (inside forward() autograd has switched it off; and it reports needs_input_grad for a parameter under
+    # no_grad too): what tells fp32 inference — the exact-fp32 kernel, nothing saved — from an fp32 training step
+    _caller_grad = True
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        LinearFn._caller_grad = torch.is_grad_enabled()
+        return super(LinearFn, cls).apply(*args, **kwargs)
+
     @staticmethod
     def forward(ctx, x, weight, bias, bias_grad_external):
         from . import nn_ops
@@ -299,8 +308,8 @@ class LinearFn(torch.autograd.Function):
             W = weight.detach()
             b = None if bias is None else bias.detach()
             from . import ops_f32
-            # (autograd reports needs_input_grad for a parameter under no_grad too: inference is "no gradient mode OR nothing wants one")
-            if x2.is_cuda and x2.dtype == torch.float32 and (not torch.is_grad_enabled() or not any(ctx.needs_input_grad)) \
+            # (inference is "the caller runs without gradient mode OR nothing wants one")
+            if x2.is_cuda and x2.dtype == torch.float32 and (not LinearFn._caller_grad or not any(ctx.needs_input_grad)) \
                     and not torch.is_autocast_enabled("cuda") and x2.numel():
                 # fp32 inference (the reference-parity path): exact fp32 MFMA product, no library call
                 nn_ops.IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"

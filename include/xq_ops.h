@@ -500,6 +500,13 @@ int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_
 #define XQ_PROF_CONV3X3 1    /* conv3x3_kernel: 2*B*H*W*9*Cin*Cout flops per launch                               */
 #define XQ_PROF_ATTN_FWD 2   /* attn_fwd_kernel: 4*B*H*N*N*64 flops per launch (2 tile products)                  */
 #define XQ_PROF_ATTN_BWD 3   /* delta + dK/dV + dQ kernels: 10*B*H*N*N*64 algorithmic flops (5 products; 7 are run) */
+/* HBM-bound kernels (round 5; work = ALGORITHMIC BYTES per launch, bench.py prices them against 8 TB/s): */
+#define XQ_PROF_RES_LN_FWD 5 /* res_ln_fwd_kernel: rows*D*(4 + y + 4 + a) bytes (x read, branch output read, x_new write, LN output write; y/a 2 B bf16) */
+#define XQ_PROF_RES_LN_BWD 6 /* res_ln_bwd_kernel (+ its partials' finalize): rows*D*(a + 4 + 4 + y + 4 + y) bytes (g_a, g_xnew, x_new, y read; g_x, g_y write) */
+#define XQ_PROF_ADAMW 7      /* adamw_ema_kernel: n*(20 read + 20 written [+ 2 bf16 shadow]) bytes */
+#define XQ_PROF_GROUPNORM 8  /* GroupNorm+SiLU NHWC bf16: forward 3 reads + 1 write (8 B/elem), backward 4 reads + 1 write (10 B/elem) */
+#define XQ_PROF_VQ_ELEM 9    /* vq_finish_kernel / vq_backward_kernel + vq_codebook_grad_kernel: 4C B/token per tensor touched + V*C*4 */
+#define XQ_PROF_CONV_FROM3 10 /* conv3x3_from3_mfma_kernel: B*H*W*(3*in + Cout*2) bytes */
 int xq_prof_enable(int on);
 int xq_prof_collect_kind(int kind, double *ms_total, int *launches, double *work_total);
 int xq_prof_collect(double *assign_ms_total, int *assign_launches);

@@ -67,10 +67,11 @@ def test_weight_gradient_is_deterministic_and_handles_empty_batches():
 
 
 @pytest.mark.parametrize("B,N,H,hd", [(2, 257, 12, 64), (3, 70, 6, 64), (1, 197, 3, 32), (2, 5, 2, 64)])
-def test_attention_fp32_forward_and_gradients(B, N, H, hd):
+def test_attention_fp32_forward_and_gradients(B, N, H, hd, monkeypatch):
     """ops_f32.AttentionF32Fn (attention_f32_kernel + lse, attention_f32_bwd_q / _kv kernels) against float64 softmax attention and its
     autograd on the same packed projection; run twice: bit-identical (no atomics)."""
     from imagefolder_amd import nn_ops, ops_dense, ops_f32
+    monkeypatch.setattr(nn_ops, "F32_TRAIN_LINEAR", True)      # parity kernels: off by default since round 5
     torch.manual_seed(B + N + H)
     C = H * hd
     qkv = (torch.randn(B, N, 3 * C, device="cuda") * 0.7).requires_grad_(True)

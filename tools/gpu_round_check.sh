@@ -63,6 +63,12 @@ if has sq; then
   timeout 300 rocprofv3 --pmc $SQ --output-format csv -d /tmp/pmc_attn_$TAG -- python tools/bench_attn.py > $OUT/pmc_attn.log 2>&1
   python tools/pmc_sq_table.py /tmp/pmc_attn_$TAG attn_ > $OUT/attn_pmc_sq.txt 2>&1; cut -c1-200 $OUT/attn_pmc_sq.txt
 fi
+if has sqassign; then
+  # the codebook search (north_star: "MFMA utilisation on the codebook GEMM"): same SQ counters over the quantizer-stage workload of bench.py
+  SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU GRBM_GUI_ACTIVE"
+  timeout 300 rocprofv3 --pmc $SQ --output-format csv -d /tmp/pmc_assign_$TAG -- python bench.py --workload quantizer --steps 6 --warmup 2 --no-cpu-baseline --no-mfu > $OUT/pmc_assign.log 2>&1
+  python tools/pmc_sq_table.py /tmp/pmc_assign_$TAG assign_kernel > $OUT/assign_pmc_sq.txt 2>&1; cut -c1-200 $OUT/assign_pmc_sq.txt
+fi
 if has configs; then
   for CFG in VP2-16384 MSVR10P2-4096 RobustTok; do
     timeout 300 python bench.py --config $CFG --steps 8 --warmup 3 --no-cpu-baseline --no-mfu >> $OUT/bench_configs.jsonl 2>> $OUT/bench_configs.err
