@@ -450,7 +450,7 @@ def main():
     kinds = {}
     for kind, name in ((1, "conv3x3_kernel (v_mfma_f32_32x32x16_bf16 implicit GEMM, LPIPS-VGG / CNN convs)"),
                        (2, "attn_fwd_kernel (v_mfma_f32_32x32x16_bf16)"),
-                       (3, "attn_delta + attn_bwd_dkdv + attn_bwd_dq kernels (v_mfma_f32_32x32x16_bf16)"),
+                       (3, "attn_bwd_dq (+ delta prologue) + attn_bwd_dkdv kernels (v_mfma_f32_32x32x16_bf16)"),
                        (4, "gemm_pring / gemm_ring / gemm_simple kernels (v_mfma_f32_32x32x16_bf16; nn.Linear fwd NT, dgrad NN, wgrad TN)")):
         k_ms, k_n, k_work = ctypes.c_double(0.0), ctypes.c_int(0), ctypes.c_double(0.0)
         lib.xq_prof_collect_kind(kind, ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_work))
@@ -554,7 +554,7 @@ def main():
         if full and CFG["name"] == "VQ-8192" and B == 128:   # the profile was taken on this workload
             for e in entries:
                 keys = (["conv3x3"] if e["kernel"].startswith("conv3x3") else ["attn_fwd"] if e["kernel"].startswith("attn_fwd")
-                        else ["attn_bwd_dkdv", "attn_bwd_dq"] if e["kernel"].startswith("attn_delta")
+                        else ["attn_bwd_dkdv", "attn_bwd_dq"] if e["kernel"].startswith("attn_bwd_dq")
                         else ["gemm"] if e["kernel"].startswith("gemm") else ["assign"])
                 if all(k in traffic for k in keys):
                     e["traffic"] = sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)

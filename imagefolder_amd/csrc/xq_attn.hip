@@ -267,38 +267,15 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_kernel(const short *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// delta[b, h, n] = sum_d dO[b, n, h, d] * O[b, n, h, d]   (8 lanes per row, 16 bytes each)
-// ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_delta_kernel(const short *__restrict__ o, const short *__restrict__ dout, int B, int N, int H,
-                                                         float *__restrict__ delta) {
-    const long row = (long)blockIdx.x * 32 + (threadIdx.x >> 3);   // row = (b*N + n)*H + h
-    const long rows = (long)B * N * H;
-    const int part = threadIdx.x & 7;
-    float acc = 0.0f;
-    if (row < rows) {
-        const uint4 a = *reinterpret_cast<const uint4 *>(o + row * 64 + 8 * part);
-        const uint4 d = *reinterpret_cast<const uint4 *>(dout + row * 64 + 8 * part);
-        acc = bf_lo(a.x) * bf_lo(d.x) + bf_hi(a.x) * bf_hi(d.x) + bf_lo(a.y) * bf_lo(d.y) + bf_hi(a.y) * bf_hi(d.y) +
-              bf_lo(a.z) * bf_lo(d.z) + bf_hi(a.z) * bf_hi(d.z) + bf_lo(a.w) * bf_lo(d.w) + bf_hi(a.w) * bf_hi(d.w);
-    }
-    acc += __shfl_xor(acc, 1);
-    acc += __shfl_xor(acc, 2);
-    acc += __shfl_xor(acc, 4);
-    if (row < rows && part == 0) {
-        const long bn = row / H;
-        const int h = (int)(row - bn * H);
-        const long b = bn / N;
-        const int n = (int)(bn - b * N);
-        delta[(b * H + h) * N + n] = acc;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
 // dQ: one query per lane (as the forward).  Per 64-key tile: S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP - delta) scale,
 // dQ^T += K^T dS^T.  LDS per buffer: K and V row-major (K^T fragments through transpose reads).
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__restrict__ qkv, const short *__restrict__ dout,
-                                                          const float *__restrict__ lse, const float *__restrict__ delta, int B, int N, int H,
+// Round 5: delta[b, h, n] = sum_d dO * O is computed HERE, in the prologue — each lane holds 32 of its query's 64 dO values already (the B operand
+// of dP^T = V dO^T), the matching O values come in with four more 16-byte loads, the two half-rows meet in one cross-half shuffle — and
+// written out for the dK/dV kernel, which runs after this one: the stand-alone attn_delta_kernel (pure VALU, 1.0 ms per train step in 36
+// launches, 82.8 % of its cycles waiting: profiles/r04_attn_pmc_sq.txt) is gone from the backward pass.
+__global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__restrict__ qkv, const short *__restrict__ out, const short *__restrict__ dout,
+                                                          const float *__restrict__ lse, float *__restrict__ delta, int B, int N, int H,
                                                           float scale, short *__restrict__ dqkv, int nqb) {
     __shared__ __attribute__((aligned(16))) short Ks[2][64 * AT_RP];
     __shared__ __attribute__((aligned(16))) short Vs[2][64 * AT_RP];
@@ -330,7 +307,25 @@ __global__ __launch_bounds__(256, 3) void attn_bwd_dq_kernel(const short *__rest
         df3 = *reinterpret_cast<const bf16x8 *>(dp + 48);
     }
     const float lse2 = lse[((long)b * H + h) * N + qc] * 1.4426950408889634f;
-    const float dq_ = delta[((long)b * H + h) * N + qc];
+    float dq_;
+    {
+        const short *op_ = out + ((long)b * N + qc) * (H * 64) + h * 64 + 8 * hh;
+        const uint4 o0_ = *reinterpret_cast<const uint4 *>(op_), o1_ = *reinterpret_cast<const uint4 *>(op_ + 16);
+        const uint4 o2_ = *reinterpret_cast<const uint4 *>(op_ + 32), o3_ = *reinterpret_cast<const uint4 *>(op_ + 48);
+        float acc_ = 0.0f;
+#define DQ_DOT(O_, D_)                                                                                                                  \
+        {                                                                                                                               \
+            const uint4 d_ = __builtin_bit_cast(uint4, D_);                                                                             \
+            acc_ = fmaf(bf_lo(O_.x), bf_lo(d_.x), acc_); acc_ = fmaf(bf_hi(O_.x), bf_hi(d_.x), acc_);                                   \
+            acc_ = fmaf(bf_lo(O_.y), bf_lo(d_.y), acc_); acc_ = fmaf(bf_hi(O_.y), bf_hi(d_.y), acc_);                                   \
+            acc_ = fmaf(bf_lo(O_.z), bf_lo(d_.z), acc_); acc_ = fmaf(bf_hi(O_.z), bf_hi(d_.z), acc_);                                   \
+            acc_ = fmaf(bf_lo(O_.w), bf_lo(d_.w), acc_); acc_ = fmaf(bf_hi(O_.w), bf_hi(d_.w), acc_);                                   \
+        }
+        DQ_DOT(o0_, df0) DQ_DOT(o1_, df1) DQ_DOT(o2_, df2) DQ_DOT(o3_, df3)
+#undef DQ_DOT
+        dq_ = acc_ + __shfl_xor(acc_, 32);
+        if (hh == 0 && qn < N) delta[((long)b * H + h) * N + qn] = dq_;
+    }
 
     const int kkey = tid >> 3, kpart = tid & 7;
     uint4 rk0, rk1, rv0, rv1;
@@ -600,15 +595,13 @@ extern "C" int xq_attn_backward(const void *qkv, const void *out, const void *do
     if (B == 0) return XQ_OK;
     if (!qkv || !out || !dout || !lse || !dqkv || !delta) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     hipStream_t s = (hipStream_t)stream;
-    const long rows = (long)B * N * H;
     const int pslot = prof_begin(XQ_PROF_ATTN_BWD, 10.0 * B * H * (double)N * N * 64.0, s);
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, s, (const short *)out, (const short *)dout, B, N, H,
-                       delta);
     const int nb = (N + 127) / 128, G8 = (B * H + 7) / 8 * 8;
+    // dQ first: its prologue computes delta and writes it for the dK/dV kernel behind it
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)out, (const short *)dout, lse,
+                       delta, B, N, H, scale, (short *)dqkv, nb);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N,
                        H, scale, (short *)dqkv, nb);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)(G8 * nb)), dim3(256), 0, s, (const short *)qkv, (const short *)dout, lse, delta, B, N, H,
-                       scale, (short *)dqkv, nb);
     prof_end(pslot, s);
     return xq_check_launch(fn);
 }

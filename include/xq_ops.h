@@ -330,7 +330,8 @@ int xq_sn_weight_grad(const float *g, const float *u, const float *v, const floa
  * sum-exp of the scaled scores (kept for the backward). */
 int xq_attn_forward(const void *qkv, int B, int N, int H, int head_dim, float scale, void *out, float *lse, xq_stream_t stream);
 
-/* dout bf16 [B][N][H*64] -> dqkv bf16 [B][N][3][H][64] (every element written).  delta: fp32 [B][H][N] scratch. */
+/* dout bf16 [B][N][H*64] -> dqkv bf16 [B][N][3][H][64] (every element written).  delta: fp32 [B][H][N] scratch (round 5: written by the dQ
+ * kernel's prologue — dO_i . O_i from the dO fragments it holds anyway — and read by the dK/dV kernel launched behind it; no delta kernel). */
 int xq_attn_backward(const void *qkv, const void *out, const void *dout, const float *lse, int B, int N, int H, int head_dim,
                      float scale, void *dqkv, float *delta, xq_stream_t stream);
 
@@ -499,7 +500,7 @@ int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_t P, int64_
 #define XQ_PROF_ASSIGN 0     /* assign_kernel: 2*N*Vpad*C flops per launch                                        */
 #define XQ_PROF_CONV3X3 1    /* conv3x3_kernel: 2*B*H*W*9*Cin*Cout flops per launch                               */
 #define XQ_PROF_ATTN_FWD 2   /* attn_fwd_kernel: 4*B*H*N*N*64 flops per launch (2 tile products)                  */
-#define XQ_PROF_ATTN_BWD 3   /* delta + dK/dV + dQ kernels: 10*B*H*N*N*64 algorithmic flops (5 products; 7 are run) */
+#define XQ_PROF_ATTN_BWD 3   /* dQ (+ delta in its prologue) + dK/dV kernels: 10*B*H*N*N*64 algorithmic flops (5 products; 7 are run) */
 /* HBM-bound kernels (round 5; work = ALGORITHMIC BYTES per launch, bench.py prices them against 8 TB/s): */
 #define XQ_PROF_RES_LN_FWD 5 /* res_ln_fwd_kernel: rows*D*(4 + y + 4 + a) bytes (x read, branch output read, x_new write, LN output write; y/a 2 B bf16) */
 #define XQ_PROF_RES_LN_BWD 6 /* res_ln_bwd_kernel (+ its partials' finalize): rows*D*(a + 4 + 4 + y + 4 + y) bytes (g_a, g_xnew, x_new, y read; g_x, g_y write) */

@@ -31,6 +31,26 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    # call sites: torch.profiler's with_stack comes back empty on this ROCm build, so one extra step runs under a dispatch mode that
+    # notes, for every ATen op (name, input shapes), the innermost imagefolder_amd / bench frame of the Python stack
+    import traceback
+    from torch.utils._python_dispatch import TorchDispatchMode
+    sites = collections.defaultdict(collections.Counter)
+
+    class Sites(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = "aten::" + func._overloadpacket.__name__ if hasattr(func, "_overloadpacket") else str(func)
+            shp = str([list(a.shape) if isinstance(a, torch.Tensor) else [] for a in args])[:70]
+            fr = "?"
+            for f in reversed(traceback.extract_stack(limit=40)):
+                if ("imagefolder_amd" in f.filename or f.filename.endswith("bench.py")) and "prof_glue" not in f.filename:
+                    fr = f"{os.path.basename(f.filename)}:{f.lineno} {f.name}"
+                    break
+            sites[(name, shp)][fr] += 1
+            return func(*args, **(kwargs or {}))
+    with Sites():
+        step()
+    torch.cuda.synchronize()
     steps = 2
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
         for _ in range(steps):
@@ -47,7 +67,9 @@ def main():
                 frame = fr.split("/")[-1].strip()
                 break
         shapes = str(ev.input_shapes)[:70] if ev.input_shapes else ""
-        k = (ev.name, shapes, frame[:70])
+        if frame == "?" and (ev.name, shapes) in sites:
+            frame = "; ".join(f"{fr} x{n}" for fr, n in sites[(ev.name, shapes)].most_common(3))
+        k = (ev.name, shapes, frame[:110])
         acc[k][0] += dt
         acc[k][1] += 1
     rows = sorted(acc.items(), key=lambda kv: -kv[1][0])
