@@ -370,12 +370,11 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
     __hip_bfloat16 *y = (__hip_bfloat16 *)Y;
     const int pslot = prof_begin(XQ_PROF_CONV3X3, 2.0 * (double)M * 9.0 * Cin * Cout, s);
     if (Cin == 64 && Cout == 64 && !c64_disabled()) {      // weights resident in LDS, one halo load per 16 x 32 output tile
-        static bool attr_done = false;
-        if (!attr_done) {
+        static unsigned long long attr_devs = 0;      // per device (a process driving several GPUs)
+        if (first_call_on_this_device(&attr_devs)) {
             if (hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void *>(conv3x3_c64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, C64_LDS) != hipSuccess)
                 return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-            attr_done = true;
         }
         const int ty = (H + C64_TH - 1) / C64_TH, tx = (W + C64_TW - 1) / C64_TW;
         const long ntiles = (long)B * ty * tx;

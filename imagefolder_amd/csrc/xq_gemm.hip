@@ -1051,11 +1051,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 
 template <void (*KERNEL)(const GemmArgs)>
 int set_lds(int bytes) {
-    static bool done = false;   // one static per kernel instantiation
-    if (!done) {
+    static unsigned long long devs = 0;   // one static per kernel instantiation; one bit per device
+    if (first_call_on_this_device(&devs)) {
         if (hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
             return -1;
-        done = true;
     }
     return 0;
 }

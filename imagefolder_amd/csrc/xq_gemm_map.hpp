@@ -18,7 +18,7 @@
 // The XOR is applied to the SOURCE address of the LDS-DMA (its destination is lane-linear by construction) and again on the read.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define GM_HD __host__ __device__ __forceinline__
 #else
 #define GM_HD inline

@@ -9,6 +9,9 @@ extern thread_local char g_err[512];
 int xq_set_error(int code, const char *fmt, const char *a = "", long b = 0, long c = 0);
 int xq_check_launch(const char *what);
 int num_cus();
+// true the first time it is called with `mask` on the CURRENT device (<= 64 devices per process): guards the once-per-device calls of
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) — a process-wide `static bool` set the attribute on the first device only (round-4 advisor)
+bool first_call_on_this_device(unsigned long long *mask);
 int check_common(const char *fn, const void *z, int B, int C, int HW, const void *E, int V);
 
 static inline int chunk_codes(int C) { return C == 8 ? 256 : (C <= 64 ? 128 : 64); }

@@ -44,6 +44,13 @@ int xq_check_launch(const char *what) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return XQ_ELAUNCH;
 }
+bool first_call_on_this_device(unsigned long long *mask) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev > 63) return true;      // unknown device: just do the call again (it is idempotent)
+    const unsigned long long bit = 1ull << dev;
+    const unsigned long long old = __atomic_fetch_or(mask, bit, __ATOMIC_RELAXED);
+    return (old & bit) == 0;
+}
 extern "C" const char *xq_last_error(void) { return g_err; }
 extern "C" int xq_abi_version(void) { return XQ_ABI_VERSION; }
 
@@ -636,11 +643,9 @@ static int launch_assign_t(const float *z, long N, int HW, const float *E, int V
         const int cps = (n_chunks + want - 1) / want;
         const int splits = (n_chunks + cps - 1) / cps;
         const size_t lds = 2 * (size_t)TL::BUF_BYTES;
-        static bool attr_set = false;
-        if (!attr_set) {
+        static unsigned long long attr_devs = 0;      // per device and per instantiation
+        if (first_call_on_this_device(&attr_devs))
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&assign_kernel<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
-        }
         const int pslot = prof_begin(XQ_PROF_ASSIGN, 2.0 * (double)N * Vpad * C, s);
         hipLaunchKernelGGL((assign_kernel<C, MODE>), dim3(tok_blocks, splits), dim3(ASSIGN_THREADS), lds, s, z, N, HW, ws.wb, ws.ee,
                            n_chunks, cps, ws.keys);
@@ -778,11 +783,10 @@ static void launch_bwd(bool normed, const float *z, long N, int HW, const float 
     const size_t lds = ws ? (size_t)BWD_CHUNK * 4 + BWD_CHUNK * 2 * 2 + 16 + (size_t)BWD_CHUNK * (C + 1) * 4 : 0;
     if (ws) {
         (void)hipMemsetAsync(ws->first, 0, ws->first_bytes, s);
-        static bool attr_set = false;       // C = 64 needs 68 KiB of dynamic LDS
-        if (!attr_set) {
+        static unsigned long long attr_devs = 0;       // C = 64 needs 68 KiB of dynamic LDS; per device
+        if (first_call_on_this_device(&attr_devs)) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_backward_kernel<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&vq_backward_kernel<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_set = true;
         }
     }
     if (normed)

@@ -673,8 +673,8 @@ class LpipsVggFn(torch.autograd.Function):
             else:
                 c.relu = False                                    # the ReLU mask is already in g
                 y_prev = layers[li - 1][2].saved_tensors[2] if li > 0 and layers[li - 1][0] == "conv" else None
-                fused = (FUSED_RELU_MASK and y_prev is not None and fn is Conv3x3Fn and y_prev.dtype == torch.bfloat16
-                         and y_prev.is_contiguous(memory_format=torch.channels_last))
+                fused = (FUSED_RELU_MASK and y_prev is not None and fn is Conv3x3Fn and getattr(c, "mode", None) == "s1"
+                         and y_prev.dtype == torch.bfloat16 and y_prev.is_contiguous(memory_format=torch.channels_last))
                 c.out_mask = y_prev if fused else None            # conv -> conv inside a slice: mask by the ReLU output below,
                 g = fn.backward(c, g)[0]                          # in the data-gradient kernel's store ...
                 c.out_mask = None
@@ -852,7 +852,10 @@ class Conv3x3Fn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wpd = _packed_conv_weight(weight, True)
             # hand-driven walks (LpipsVggFn) hang the ReLU output of the layer below on the context: its mask goes into the store of g_x
-            mask = getattr(ctx, "out_mask", None) if mode == "s1" and FUSED_RELU_MASK else None
+            handed = getattr(ctx, "out_mask", None)
+            mask = handed if mode == "s1" and FUSED_RELU_MASK else None
+            if handed is not None and mask is None:      # a caller that skips its own ReLU pass relies on this store applying the mask
+                raise RuntimeError(f"Conv3x3Fn.backward: an out_mask was handed to a '{mode}' convolution / with FUSED_RELU_MASK off — it would be dropped")
             if mode == "s1":
                 if _use_gemm_engine(B * H * W, Cin):
                     g_x = conv3x3_gemm(g, wpd, None, Cin, out_mask=mask)

@@ -334,7 +334,7 @@ class ArenaOptimizer:
         return out
 
     @torch.no_grad()
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, allow_partial: bool = False):
         a = self.arena
         st = {int(k): v for k, v in sd["state"].items()}
         groups = sd["param_groups"]
@@ -345,8 +345,22 @@ class ArenaOptimizer:
         unknown = sorted(set(st) - set(self._torch_index))
         if unknown:
             raise ValueError(f"optimizer state for parameter positions {unknown[:8]}... that are not trainable here")
-        # torch.optim.AdamW creates state only for parameters that have received a gradient: a trainable parameter without an entry
-        # (never used upstream, or frozen when the checkpoint was written) starts from zero moments, as torch itself would load it
+        # torch.optim.AdamW creates state only for parameters that have received a gradient, so a checkpoint may lack entries for trainable
+        # parameters (never used upstream, or frozen when it was written).  Those start from zero moments here — but NOT as torch would
+        # continue them: the arena keeps ONE step count, so such a parameter is bias-corrected with the loaded step N where torch would
+        # restart its own count at 0 (its first updates come out scaled by about (1 - beta1) / sqrt(1 - beta2) relative to torch's).  With
+        # step > 0 that is only accepted on request (allow_partial=True), and always reported.
+        missing = [ti for ti in self._torch_index if ti not in st]
+        loaded_steps = {int(float(e["step"])) for e in st.values()}
+        if missing and loaded_steps and max(loaded_steps) > 0:
+            msg = (f"optimizer state has no entry for {len(missing)} trainable parameter position(s) {missing[:8]}{'...' if len(missing) > 8 else ''} "
+                   f"while the others are at step {max(loaded_steps)}")
+            if not allow_partial:
+                raise ValueError(msg + ": truncated / mismatched checkpoint? (allow_partial=True loads it with zero moments for those, "
+                                 "bias-corrected with the shared step count)")
+            import warnings
+            warnings.warn("ArenaOptimizer.load_state_dict: " + msg + "; they start from zero moments under the SHARED step count "
+                          "(torch would restart their own counts at 0)", RuntimeWarning, stacklevel=2)
         steps = set()
         for ti, p, o in zip(self._torch_index, a.params, a.offsets):
             e = st.get(ti)

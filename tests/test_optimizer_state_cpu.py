@@ -107,11 +107,15 @@ def test_frozen_parameters_keep_their_positions_in_the_checkpoint_layout():
     _steps(mt, ot, 2, 5, arena=False)
     for pb, pt in zip(mb.parameters(), mt.parameters()):
         assert torch.allclose(pb, pt, rtol=1e-5, atol=1e-6)
-    # a trainable parameter WITHOUT an entry is what torch.optim.AdamW writes for a parameter that never received a gradient: it loads
-    # (as in torch) and starts from zero moments
+    # a trainable parameter WITHOUT an entry is what torch.optim.AdamW writes for a parameter that never received a gradient.  torch loads it
+    # and restarts that parameter's own step count; the arena has ONE step count, so with step > 0 such a checkpoint is refused unless the
+    # caller asks for it (allow_partial), and then reported: zero moments, bias-corrected with the shared step
     partial = {"state": {k: v for k, v in st["state"].items() if k != 4}, "param_groups": st["param_groups"]}
     torch.optim.AdamW(_WithFrozenTeacher(3).parameters(), **kw).load_state_dict(partial)
-    ob.load_state_dict(partial)
+    with pytest.raises(ValueError, match="no entry for 1 trainable parameter"):
+        ob.load_state_dict(partial)
+    with pytest.warns(RuntimeWarning, match="zero moments under the SHARED step count"):
+        ob.load_state_dict(partial, allow_partial=True)
     assert ob.arena.step_count == int(st["state"][0]["step"])      # (state_dict() hands out the live step tensors: 5 by now)
     assert ob.arena.m[o_head:o_head + 15].abs().max() == 0 and ob.arena.v[o_head:o_head + 15].abs().max() == 0
     o_bias = ob.arena.offsets[3]
