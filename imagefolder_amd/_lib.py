@@ -59,6 +59,9 @@ SIGNATURES = {
     "xq_colsum_partials": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_vec_normalize": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_float, vp, vp, vp]),
     "xq_sn_weight_grad": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int64, vp, vp]),
+    "xq_sn_batched_workspace_floats": (ctypes.c_int, [ctypes.c_int] * 4),
+    "xq_sn_batched_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "xq_sn_batched_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "xq_row_partials_blocks": (ctypes.c_int, [ctypes.c_int64]),
     "xq_res_ln_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float,
                                          ctypes.c_int, vp, vp, vp, vp, vp]),

@@ -459,6 +459,170 @@ __global__ __launch_bounds__(256) void sn_weight_grad_kernel(const float *__rest
     }
 }
 
+// ---- round 5: the same, BATCHED over H same-shaped weights.  The five DinoDisc heads hold the same three convolutions each
+//      (discriminator_dino.py:209-216), so a discriminator forward normalises 3 x 5 weights of 3 shapes: per-weight that was 5 x 7 launches
+//      forward and 5 x 4 backward per shape (45 convolution calls = ~430 launches of 4 - 9 us per train step, 2.7 ms).  Here one launch chain
+//      per SHAPE: gemv^T over all heads -> [normalise v in the prologue] gemv over all heads -> [normalise u, sigma in the prologue] W / sigma
+//      written straight in the layout (and the bf16 copy) the convolution's GEMM reads.  W: fp32 [H][R][Cin * taps] — a Conv1d weight
+//      (out, in, taps) flattened as torch's spectral_norm does (dim 0 kept); out: [H][R][taps][Cin] (the unfolded convolution's
+//      reduction order; taps = 1: unchanged).  Every dot is a fixed-order reduction: deterministic.
+//   sn_b_gemvt : t[h][c] = sum_r W[h][r][c] u[h][r]                          grid (ceil(C / 64), H)
+//   sn_b_gemvn : v = t / max(|t|, eps) (each block for itself; block 0 of a head publishes it); s[h][r] = sum_c W[h][r][c] v[c]   grid (R, H)
+//   sn_b_scale : sigma = |s|, u = s / max(|s|, eps) (block 0 of a head publishes both); out = W / sigma in the GEMM layout  grid (blocks, H)
+__global__ __launch_bounds__(256) void sn_b_gemvt_kernel(const float *__restrict__ W, const float *__restrict__ u, int R, int C, float *__restrict__ t) {
+    // 64 columns per block; wave g walks rows g, g + 4, ... (one 256-byte row segment per load), the four partial sums meet in LDS in a fixed order
+    const int h = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+    __shared__ float part[4][64];
+    const float *Wh = W + (long)h * R * C, *uh = u + (long)h * R;
+    float acc = 0.0f;
+    if (col < C)
+        for (int r = rg; r < R; r += 4) acc = __builtin_fmaf(Wh[(long)r * C + col], uh[r], acc);
+    part[rg][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (threadIdx.x < 64 && col < C) t[(long)h * C + col] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+}
+
+// block-wide sum of squares of x[0..n) in a fixed order (thread-strided chains, wave sums, four partials)
+__device__ __forceinline__ float block_sumsq_256(const float *__restrict__ x, int n, float *red /* [4] */) {
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < n; i += 256) s = __builtin_fmaf(x[i], x[i], s);
+    s = wave_sum(s);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sn_b_gemvn_kernel(const float *__restrict__ W, const float *__restrict__ t, int R, int C, float eps,
+                                                         float *__restrict__ v_buf, float *__restrict__ v_out, float *__restrict__ s) {
+    const int h = blockIdx.y, r = blockIdx.x;
+    __shared__ float red[4];
+    const float *th = t + (long)h * C;
+    const float nrm = __builtin_sqrtf(block_sumsq_256(th, C, red));
+    const float d = nrm > eps ? nrm : eps;                 // F.normalize: x / max(|x|, eps)
+    const float *Wr = W + ((long)h * R + r) * C;
+    float acc = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const float vc = th[c] / d;
+        acc = __builtin_fmaf(Wr[c], vc, acc);
+        if (r == 0) { v_buf[(long)h * C + c] = vc; v_out[(long)h * C + c] = vc; }
+    }
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) s[(long)h * R + r] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sn_b_scale_kernel(const float *__restrict__ W, const float *__restrict__ s, int R, int Cin, int taps, float eps,
+                                                         float *__restrict__ u_buf, float *__restrict__ u_out, float *__restrict__ sigma,
+                                                         float *__restrict__ out32, __hip_bfloat16 *__restrict__ out16) {
+    const int h = blockIdx.y;
+    __shared__ float red[4];
+    const float *sh = s + (long)h * R;
+    const float nrm = __builtin_sqrtf(block_sumsq_256(sh, R, red));
+    const float d = nrm > eps ? nrm : eps;
+    // u^T W v = |W v|^2 / max(|W v|, eps) = |W v| unless W v underflows eps (as the per-weight path: the norm IS sigma)
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < R; i += 256) { const float ui = sh[i] / d; u_buf[(long)h * R + i] = ui; u_out[(long)h * R + i] = ui; }
+        if (threadIdx.x == 0) sigma[h] = nrm;
+    }
+    const int C = Cin * taps;
+    const long n = (long)R * C, base = (long)h * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        // i indexes the OUTPUT [r][tap][cin]; the source is [r][cin][tap]
+        const long r = i / C;
+        const int rem = (int)(i - r * C), tap = rem / Cin, cin = rem - tap * Cin;
+        const float val = W[base + r * C + (long)cin * taps + tap] / nrm;
+        out32[base + i] = val;
+        if (out16) out16[base + i] = __float2bfloat16(val);
+    }
+}
+
+// backward of out = W / sigma (u, v constant): g_W = g / sigma - (<g, W> / sigma^2) u v^T.  g arrives in the OUTPUT layout [r][tap][cin], g_W leaves
+// in the weight's layout [r][cin][tap].  sn_b_dot: per-block partial sums of g . W (matching elements) -> partials[h][nblk];
+// sn_b_grad: every block folds its head's partials in the same order, then writes its share of g_W.
+__global__ __launch_bounds__(256) void sn_b_dot_kernel(const float *__restrict__ g, const float *__restrict__ W, int R, int Cin, int taps,
+                                                       float *__restrict__ partials) {
+    const int h = blockIdx.y, C = Cin * taps;
+    const long n = (long)R * C, base = (long)h * n;
+    float acc = 0.0f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / C;
+        const int rem = (int)(i - r * C), tap = rem / Cin, cin = rem - tap * Cin;
+        acc = __builtin_fmaf(g[base + i], W[base + r * C + (long)cin * taps + tap], acc);
+    }
+    __shared__ float red[4];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[(long)h * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sn_b_grad_kernel(const float *__restrict__ g, const float *__restrict__ u, const float *__restrict__ v,
+                                                        const float *__restrict__ sigma, const float *__restrict__ partials, int nparts, int R, int Cin,
+                                                        int taps, float *__restrict__ gW) {
+    const int h = blockIdx.y, C = Cin * taps;
+    __shared__ float dot_s;
+    if (threadIdx.x == 0) {
+        float dsum = 0.0f;
+        for (int i = 0; i < nparts; ++i) dsum += partials[(long)h * nparts + i];
+        dot_s = dsum;
+    }
+    __syncthreads();
+    const float inv = 1.0f / sigma[h];
+    const float coef = dot_s * inv * inv;
+    const long n = (long)R * C, base = (long)h * n;
+    const float *uh = u + (long)h * R, *vh = v + (long)h * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        // i indexes g_W [r][cin][tap]; the matching gradient element sits at [r][tap][cin]
+        const long r = i / C;
+        const int rem = (int)(i - r * C), cin = rem / taps, tap = rem - cin * taps;
+        gW[base + i] = g[base + r * C + (long)tap * Cin + cin] * inv - coef * uh[r] * vh[rem];
+    }
+}
+
+static int sn_b_blocks(long n) {
+    long b = (n + 255) / 256;
+    const long cap = (long)num_cus() * 2;
+    if (b > cap) b = cap;
+    return (int)(b < 1 ? 1 : b);
+}
+
+extern "C" int xq_sn_batched_workspace_floats(int H, int R, int Cin, int taps) {
+    return H * (Cin * taps + R) + H * sn_b_blocks((long)R * Cin * taps);     // t, s, dot partials
+}
+
+extern "C" int xq_sn_batched_forward(const float *W, int H, int R, int Cin, int taps, float eps, float *u_buf, float *v_buf, float *u_out, float *v_out,
+                                     float *sigma, float *workspace, float *out32, void *out16, xq_stream_t stream) {
+    const char *fn = "xq_sn_batched_forward";
+    if (H <= 0) return XQ_OK;
+    if (R < 1 || Cin < 1 || taps < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (!W || !u_buf || !v_buf || !u_out || !v_out || !sigma || !workspace || !out32) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = Cin * taps;
+    float *t = workspace, *sv = workspace + (long)H * C;
+    hipLaunchKernelGGL(sn_b_gemvt_kernel, dim3((C + 63) / 64, H), dim3(256), 0, s, W, u_buf, R, C, t);
+    hipLaunchKernelGGL(sn_b_gemvn_kernel, dim3(R, H), dim3(256), 0, s, W, t, R, C, eps, v_buf, v_out, sv);
+    hipLaunchKernelGGL(sn_b_scale_kernel, dim3(sn_b_blocks((long)R * C), H), dim3(256), 0, s, W, sv, R, Cin, taps, eps, u_buf, u_out, sigma, out32,
+                       (__hip_bfloat16 *)out16);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_sn_batched_backward(const float *g, const float *W, const float *u, const float *v, const float *sigma, int H, int R, int Cin, int taps,
+                                      float *workspace, float *gW, xq_stream_t stream) {
+    const char *fn = "xq_sn_batched_backward";
+    if (H <= 0) return XQ_OK;
+    if (R < 1 || Cin < 1 || taps < 1) return xq_set_error(XQ_EINVAL, "%s: bad shape", fn);
+    if (!g || !W || !u || !v || !sigma || !workspace || !gW) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    hipStream_t s = (hipStream_t)stream;
+    const int C = Cin * taps, nb = sn_b_blocks((long)R * C);
+    float *partials = workspace + (long)H * (C + R);
+    hipLaunchKernelGGL(sn_b_dot_kernel, dim3(nb, H), dim3(256), 0, s, g, W, R, Cin, taps, partials);
+    hipLaunchKernelGGL(sn_b_grad_kernel, dim3(nb, H), dim3(256), 0, s, g, u, v, sigma, partials, nb, R, Cin, taps, gW);
+    return xq_check_launch(fn);
+}
+
 extern "C" int xq_vec_normalize(const float *x, int n, float eps, float *out, float *norm_out, xq_stream_t stream) {
     if (n <= 0) return XQ_OK;
     if (!x || !out) return xq_set_error(XQ_EINVAL, "%s: null pointer", "xq_vec_normalize");

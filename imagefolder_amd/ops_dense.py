@@ -1141,6 +1141,65 @@ class SpectralNormWeightFn(torch.autograd.Function):
         return out.view(g.shape), None, None, None
 
 
+class SpectralNormBatchFn(torch.autograd.Function):
+    """SpectralNormWeightFn for H same-shaped Conv1d weights at once (the five DinoDisc heads hold the same three convolutions each,
+    discriminator_dino.py:209-216): one power iteration per weight on the STACKED module buffers u_stack [H][R] / v_stack [H][Cin * taps]
+    (updated in place, as torch's spectral_norm updates each module's buffers), sigma_h = u_h^T W_h v_h, outputs W_h / sigma_h — 3 kernel
+    launches + one stacking copy for all H instead of 7 launches per weight; backward 2 + 1 instead of 4 per weight.  The outputs come in the
+    layout the convolution's GEMM reads ([R][taps][Cin]: the unfolded circular convolution reduces over (tap, channel)), with their bf16
+    copies attached as `_xq_w16` (what ops_dense._w16 hands LinearFn), so neither the permute nor the cast of the per-weight path runs."""
+
+    @staticmethod
+    def forward(ctx, eps, u_stack, v_stack, *Ws):
+        H = len(Ws)
+        R, Cin, taps = Ws[0].shape
+        Wst = torch.stack([w.detach() for w in Ws])                       # [H][R][Cin][taps] fp32, one copy launch
+        dev = Wst.device
+        lib, st = _lib.lib(), _stream(Wst)
+        C = Cin * taps
+        u_out = torch.empty(H, R, dtype=torch.float32, device=dev)
+        v_out = torch.empty(H, C, dtype=torch.float32, device=dev)
+        sigma = torch.empty(H, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.xq_sn_batched_workspace_floats(H, R, Cin, taps)), dtype=torch.float32, device=dev)
+        out32 = torch.empty(H, R, C, dtype=torch.float32, device=dev)
+        out16 = torch.empty(H, R, C, dtype=torch.bfloat16, device=dev)
+        with torch.cuda.device(dev):
+            rc = lib.xq_sn_batched_forward(ptr(Wst), H, R, Cin, taps, ctypes.c_float(eps), ptr(u_stack), ptr(v_stack), ptr(u_out), ptr(v_out),
+                                           ptr(sigma), ptr(ws), ptr(out32), ptr(out16), st)
+        check(rc, "xq_sn_batched_forward")
+        ctx.save_for_backward(Wst, u_out, v_out, sigma)
+        ctx.shape = (H, R, Cin, taps)
+        ctx.mark_non_differentiable(out16)
+        return (out16,) + tuple(out32[h] for h in range(H))
+
+    @staticmethod
+    def backward(ctx, _g16, *gs):
+        Wst, u, v, sigma = ctx.saved_tensors
+        H, R, Cin, taps = ctx.shape
+        if not any(ctx.needs_input_grad[3:]):
+            return (None,) * (3 + H)
+        C = Cin * taps
+        g = torch.stack([gh.reshape(R, C).float() if gh is not None else torch.zeros(R, C, dtype=torch.float32, device=Wst.device) for gh in gs])
+        lib = _lib.lib()
+        ws = torch.empty(int(lib.xq_sn_batched_workspace_floats(H, R, Cin, taps)), dtype=torch.float32, device=Wst.device)
+        gW = torch.empty_like(Wst)
+        with torch.cuda.device(Wst.device):
+            rc = lib.xq_sn_batched_backward(ptr(g), ptr(Wst), ptr(u), ptr(v), ptr(sigma), H, R, Cin, taps, ptr(ws), ptr(gW), _stream(Wst))
+        check(rc, "xq_sn_batched_backward")
+        return (None, None, None) + tuple(gW[h] for h in range(H))
+
+
+def spectral_norm_batched(convs, u_stack, v_stack, eps=1e-12):
+    """normalised weights of H same-shaped spectrally normalised Conv1d modules (training mode): list of fp32 [R][taps * Cin] tensors in the
+    GEMM layout, each with its bf16 copy attached (`_xq_w16`)"""
+    outs = SpectralNormBatchFn.apply(eps, u_stack, v_stack, *[c.weight_orig for c in convs])
+    out16, ws = outs[0], list(outs[1:])
+    for h, w in enumerate(ws):
+        w._xq_w16 = out16[h]
+        w._xq_w16_version = w._version
+    return ws
+
+
 class BNLocalLReLUFn(torch.autograd.Function):
     """out = LeakyReLU(BatchNormLocal(y)) [+ skip, * ratio] on token-major y (B, L, C): statistics per virtual batch of
     `virtual_bs` samples and channel over its virtual_bs * L tokens (discriminator_dino.py:127-154, :113-119, :157-166)."""
@@ -1174,13 +1233,14 @@ class BNLocalLReLUFn(torch.autograd.Function):
         g = g.detach().to(yc.dtype).contiguous()
         g_y = torch.empty_like(yc)
         g_skip = torch.empty_like(yc) if has_skip else None
-        gw = torch.empty(G, C, dtype=torch.float32, device=yc.device)
-        gb = torch.empty_like(gw)
+        gwb = torch.empty(2, G, C, dtype=torch.float32, device=yc.device)      # per-group partials of (g_w, g_b): ONE reduction launch for both
+        gw, gb = gwb[0], gwb[1]
         with torch.cuda.device(yc.device):
             rc = _lib.lib().xq_bnlocal_lrelu_backward(ptr(g), ptr(yc), ptr(w), ptr(b), ptr(mean), ptr(rstd), G, R, C, _act_flag(yc.dtype),
                                                       slope, ratio, int(has_skip), ptr(g_y), ptr(g_skip), ptr(gw), ptr(gb), _stream(yc))
         check(rc, "xq_bnlocal_lrelu_backward")
-        return (g_y, gw.sum(0) if has_w else None, gb.sum(0) if has_b else None, g_skip, None, None, None, None)
+        sums = gwb.sum(1) if (has_w or has_b) else None
+        return (g_y, sums[0] if has_w else None, sums[1] if has_b else None, g_skip, None, None, None, None)
 
 
 class Unfold1dCircularFn(torch.autograd.Function):
@@ -1245,9 +1305,10 @@ def disc_head_supported(a, head):
     return a.is_cuda and a.shape[1] % 64 == 0 and conv9.padding_mode == 'circular' and conv9.kernel_size[0] <= a.shape[2]
 
 
-def disc_head(head, a):
+def disc_head(head, a, nw=None):
     """One DinoDisc head (discriminator_dino.py:209-216: make_block(ks=1) -> ResidualBlock(make_block(ks=9)) -> SpectralConv1d(C, 1))
-    on a = (B, C, L) activations, evaluated token-major with the fused kernels; returns the (B, L) logits."""
+    on a = (B, C, L) activations, evaluated token-major with the fused kernels; returns the (B, L) logits.
+    nw: the head's three spectrally normalised weights in GEMM layout (spectral_norm_batched over all heads), or None: per weight."""
     blk1, res, last = head[0], head[1], head[2]
     conv1, bn1 = blk1[0], blk1[1]
     conv9, bn9 = res.fn[0], res.fn[1]
@@ -1255,18 +1316,18 @@ def disc_head(head, a):
     B, C, L = a.shape
     x0 = a.transpose(1, 2).to(act).contiguous()                        # (B, L, C) token-major
     K = conv9.kernel_size[0]
-    y1 = LinearFn.apply(x0, conv1._normalised_weight()[:, :, 0], conv1.bias, False)
+    y1 = LinearFn.apply(x0, nw[0] if nw is not None else conv1._normalised_weight()[:, :, 0], conv1.bias, False)
     h1 = BNLocalLReLUFn.apply(y1, getattr(bn1, "weight", None), getattr(bn1, "bias", None), None, bn1.virtual_bs, bn1.eps,
                               blk1[2].negative_slope, 1.0)
     cols = Unfold1dCircularFn.apply(h1, K)
-    W9 = conv9._normalised_weight().permute(0, 2, 1).reshape(conv9.out_channels, K * C)   # [Cout][tap][Cin], as the cols
+    W9 = nw[1] if nw is not None else conv9._normalised_weight().permute(0, 2, 1).reshape(conv9.out_channels, K * C)   # [Cout][tap][Cin], as the cols
     y2 = LinearFn.apply(cols, W9, conv9.bias, False)
     h2 = BNLocalLReLUFn.apply(y2, getattr(bn9, "weight", None), getattr(bn9, "bias", None), h1, bn9.virtual_bs, bn9.eps,
                               res.fn[2].negative_slope, float(res.ratio))
     # the 1-channel logit conv is a matrix-vector product: fp32 gemv outside autocast (a bf16 GEMM with N = 1 takes
     # milliseconds on this stack, the same pathology as the spectral-norm power iteration)
     with torch.autocast("cuda", enabled=False):
-        logit = RowDotFn.apply(h2.reshape(B * L, C), last._normalised_weight()[0, :, 0].float())
+        logit = RowDotFn.apply(h2.reshape(B * L, C), nw[2][0] if nw is not None else last._normalised_weight()[0, :, 0].float())
         if last.bias is not None:
             logit = logit + last.bias.float()
     return logit.reshape(B, L).to(act)

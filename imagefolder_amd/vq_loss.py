@@ -68,6 +68,8 @@ def lecam_reg(real_pred, fake_pred, lecam_ema):
 FUSED_VGG_BACKWARD = __import__("os").environ.get("XQ_FUSED_VGG", "1") == "1"
 FUSED_DIFFAUG = __import__("os").environ.get("XQ_FUSED_DIFFAUG", "1") == "1"
 FUSED_SPECTRAL_NORM = __import__("os").environ.get("XQ_FUSED_SN", "1") == "1"
+# round 5: the power iterations of the five heads' same-shaped convolutions as one batched launch chain per shape (XQ_BATCHED_SN=0: per weight)
+BATCHED_SPECTRAL_NORM = __import__("os").environ.get("XQ_BATCHED_SN", "1") == "1"
 # discriminator update: reconstruction and input share one pass over the frozen DINO-S trunk (DinoDisc.forward_pair)
 PAIRED_DISC_TRUNK = __import__("os").environ.get("XQ_PAIRED_DISC", "1") == "1"
 # class-token readout of the discriminator trunk as one kernel per tap (ops_dense.ClsReadoutFn)
@@ -472,13 +474,49 @@ class DinoDisc(nn.Module):
     def forward(self, x_in_pm1, grad_ckpt=False):
         return self._heads(self.dino_proxy[0](x_in_pm1.float()))
 
+    def _stacked_buffer(self, convs, name, slot):
+        """the H modules' `name` buffers (weight_u / weight_v) as rows of ONE tensor: the batched power iteration updates them in place.  Each
+        module keeps its buffer (a view of the stack: state_dict / load_state_dict unaffected); anything that re-homes a buffer (.to(),
+        a fresh registration) is noticed by its data pointer and the stack is rebuilt."""
+        st = self._sn_stacks.get(slot)
+        if st is None or any(c._buffers[name].data_ptr() != st[i].data_ptr() or c._buffers[name].device != st.device for i, c in enumerate(convs)):
+            st = torch.stack([c._buffers[name].detach().float() for c in convs]).contiguous()
+            for i, c in enumerate(convs):
+                c._buffers[name] = st[i]
+            self._sn_stacks[slot] = st
+        return st
+
+    def _batched_normalised_weights(self):
+        """[(w1, w9, wl) per head]: the 3 x H spectrally normalised weights of a training forward from three batched launch chains
+        (ops_dense.spectral_norm_batched), or None when the per-weight path has to run (eval mode, CPU, the switch off)"""
+        heads = list(self.heads)
+        groups = [[h[0][0] for h in heads], [h[1].fn[0] for h in heads], [h[2] for h in heads]]
+        c0 = groups[0][0]
+        if not (FUSED_SPECTRAL_NORM and BATCHED_SPECTRAL_NORM and self.training and c0.weight_orig.is_cuda and c0.weight_orig.dtype == torch.float32
+                and len(heads) > 1):
+            return None
+        for grp in groups:
+            if any(tuple(c.weight_orig.shape) != tuple(grp[0].weight_orig.shape) or not c.training for c in grp):
+                return None
+        from . import ops_dense
+        if not hasattr(self, "_sn_stacks"):
+            self._sn_stacks = {}
+        per_group = []
+        with torch.autocast(device_type="cuda", enabled=False):
+            for gi, grp in enumerate(groups):
+                u = self._stacked_buffer(grp, "weight_u", (gi, "u"))
+                v = self._stacked_buffer(grp, "weight_v", (gi, "v"))
+                per_group.append(ops_dense.spectral_norm_batched(grp, u, v, 1e-12))
+        return [tuple(per_group[gi][hi] for gi in range(3)) for hi in range(len(heads))]
+
     def _heads(self, acts):
         B = acts[0].shape[0]
         from . import nn_ops
         if acts[0].is_cuda and nn_ops.FUSED_BLOCKS:
             from . import ops_dense
             if all(ops_dense.disc_head_supported(a, h) for h, a in zip(self.heads, acts)):
-                return torch.cat([ops_dense.disc_head(h, a) for h, a in zip(self.heads, acts)], dim=1)
+                nws = self._batched_normalised_weights()
+                return torch.cat([ops_dense.disc_head(h, a, None if nws is None else nws[i]) for i, (h, a) in enumerate(zip(self.heads, acts))], dim=1)
         return torch.cat([h(a).view(B, -1) for h, a in zip(self.heads, acts)], dim=1)
 
     def forward_pair(self, make_first, make_second):

@@ -322,6 +322,19 @@ int xq_vec_normalize(const float *x, int n, float eps, float *out, float *norm_o
 int xq_sn_weight_grad(const float *g, const float *u, const float *v, const float *sigma, const float *dot, int64_t rows, int64_t cols,
                       float *out, xq_stream_t stream);
 
+/* The same, batched over H same-shaped weights (round 5: the five DinoDisc heads hold the same three convolutions; one launch chain per
+ * shape instead of one per weight).  W fp32 [H][R][Cin * taps]: Conv1d weights (out, in, taps) flattened as torch's spectral_norm does.
+ * forward: one power iteration per weight — u_buf [H][R] / v_buf [H][Cin * taps] (the modules' buffers, stacked) are read and UPDATED in
+ * place, u_out / v_out receive the same new vectors (kept for the backward: a later forward moves the buffers on), sigma [H] = u^T W v;
+ * out32 fp32 [H][R][taps][Cin] = W / sigma in the reduction order of the unfolded convolution's GEMM (taps = 1: the weight's own layout),
+ * out16 (nullable) its bf16 copy.  backward: g fp32 in the layout of out32 -> gW fp32 in the layout of W,
+ * gW = g / sigma - (<g, W> / sigma^2) u v^T.  workspace: xq_sn_batched_workspace_floats(H, R, Cin, taps) floats (both calls). */
+int xq_sn_batched_workspace_floats(int H, int R, int Cin, int taps);
+int xq_sn_batched_forward(const float *W, int H, int R, int Cin, int taps, float eps, float *u_buf, float *v_buf, float *u_out, float *v_out,
+                          float *sigma, float *workspace, float *out32, void *out16, xq_stream_t stream);
+int xq_sn_batched_backward(const float *g, const float *W, const float *u, const float *v, const float *sigma, int H, int R, int Cin, int taps,
+                           float *workspace, float *gW, xq_stream_t stream);
+
 /* ---- multi-head self-attention on the packed qkv projection (dino_enc/vision_transformer.py:175-195: qkv.reshape(B,N,3,H,hd)
  *      .permute(2,0,3,1,4) -> F.scaled_dot_product_attention -> transpose(1,2).reshape(B,N,C); discriminator_dino.py:28).
  *      bf16 MFMA, fp32 softmax statistics, head_dim 64 only, no mask, no dropout. ------------------------------------------ */
