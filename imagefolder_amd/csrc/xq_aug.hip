@@ -17,6 +17,8 @@
 #include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
 
+#include <hip/hip_bf16.h>
+
 using namespace xq;
 
 namespace {
@@ -185,5 +187,143 @@ extern "C" int xq_diffaug_backward(const float *g, const float *rand01, int B, i
     long bx = ((long)H * W + 255) / 256;
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(aug_apply_bwd_kernel, dim3((unsigned)bx, B), dim3(256), 0, s, g, a, workspace, gx);
+    return xq_check_launch(fn);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 5: input side of the frozen DINO-S trunk of the discriminator (discriminator_dino.py:327-337 + its PatchEmbed :262-276) in one pass
+// per direction.  Upstream: x_scale * x + x_shift (ImageNet normalisation of the [-1, 1] image), then a random 224-crop OR
+// F.interpolate(size = 224, mode = 'area'), then the 16 x 16 patch convolution — here a GEMM over patchified pixels, so the chain was
+// mul, add_, adaptive_avg_pool2d (its backward: an atomicAdd scatter, 0.38 ms) / a crop copy, the patchify permute-copy and a bf16 cast:
+// five passes over a 100 MB image batch per call, three calls per train step.  dino_prep_fwd writes the bf16 patch matrix
+// cols[(b, gy, gx)][(c, dy, dx)] directly; dino_prep_bwd turns the GEMM's data gradient back into the image gradient by GATHER (every input
+// pixel sums the <= 2 x 2 output windows that cover it: deterministic).  Area windows as ATen's adaptive pooling: [floor(o H / S), ceil((o + 1) H / S)).
+// ---------------------------------------------------------------------------------------------------------------------------------------
+struct PrepArgs {
+    int B, H, W, S, P, G;      // image B x 3 x H x W; S x S crop / resize; P x P patches, G = S / P per side
+    int mode, oi, oj;          // 0: crop at (oi, oj); 1: area resize
+    float scale[3], shift[3];
+};
+
+__device__ __forceinline__ void area_win(int o, int in, int out, int &lo, int &hi) {
+    lo = (int)(((long)o * in) / out);
+    hi = (int)((((long)o + 1) * in + out - 1) / out);
+}
+
+__global__ __launch_bounds__(256) void dino_prep_fwd_kernel(const float *__restrict__ x, PrepArgs a, __hip_bfloat16 *__restrict__ cols) {
+    const int P8 = a.P / 8;
+    const long total = (long)a.B * a.G * a.G * 3 * a.P * P8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int d8 = (int)(i % P8);
+        long t = i / P8;
+        const int dy = (int)(t % a.P); t /= a.P;
+        const int c = (int)(t % 3); t /= 3;
+        const int gx = (int)(t % a.G); t /= a.G;
+        const int gy = (int)(t % a.G);
+        const long b = t / a.G;
+        const int Y = gy * a.P + dy, X0 = gx * a.P + 8 * d8;
+        const float *xp = x + (b * 3 + c) * (long)a.H * a.W;
+        float v[8];
+        if (a.mode == 0) {
+            const float *row = xp + (long)(Y + a.oi) * a.W + X0 + a.oj;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = row[e];
+        } else {
+            int ylo, yhi;
+            area_win(Y, a.H, a.S, ylo, yhi);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int xlo, xhi;
+                area_win(X0 + e, a.W, a.S, xlo, xhi);
+                float acc = 0.0f;
+                for (int yy = ylo; yy < yhi; ++yy)
+                    for (int xx = xlo; xx < xhi; ++xx) acc += xp[(long)yy * a.W + xx];
+                v[e] = acc / (float)((yhi - ylo) * (xhi - xlo));
+            }
+        }
+        struct alignas(16) B8 { __hip_bfloat16 h[8]; } o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.h[e] = __float2bfloat16(__builtin_fmaf(a.scale[c], v[e], a.shift[c]));
+        *reinterpret_cast<B8 *>(cols + i * 8) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void dino_prep_bwd_kernel(const __hip_bfloat16 *__restrict__ gcols, PrepArgs a, float *__restrict__ gx) {
+    const long total = (long)a.B * 3 * a.H * a.W;
+    const int K = 3 * a.P * a.P;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int ix = (int)(i % a.W);
+        long t = i / a.W;
+        const int iy = (int)(t % a.H); t /= a.H;
+        const int c = (int)(t % 3);
+        const long b = t / 3;
+        float acc = 0.0f;
+        auto g_at = [&](int Y, int X) -> float {       // gradient of crop / resized pixel (Y, X) of plane c
+            const int gy = Y / a.P, dy = Y - gy * a.P, gxx = X / a.P, dx = X - gxx * a.P;
+            return __bfloat162float(gcols[((b * a.G + gy) * a.G + gxx) * (long)K + (c * a.P + dy) * a.P + dx]);
+        };
+        if (a.mode == 0) {
+            const int Y = iy - a.oi, X = ix - a.oj;
+            if (Y >= 0 && Y < a.S && X >= 0 && X < a.S) acc = g_at(Y, X);
+        } else {
+            // output rows whose window holds iy: around floor(iy S / H)
+            const int oy0 = (int)(((long)iy * a.S) / a.H), ox0 = (int)(((long)ix * a.S) / a.W);
+            for (int oy = oy0 - 1; oy <= oy0 + 1; ++oy) {
+                if (oy < 0 || oy >= a.S) continue;
+                int ylo, yhi;
+                area_win(oy, a.H, a.S, ylo, yhi);
+                if (iy < ylo || iy >= yhi) continue;
+                for (int ox = ox0 - 1; ox <= ox0 + 1; ++ox) {
+                    if (ox < 0 || ox >= a.S) continue;
+                    int xlo, xhi;
+                    area_win(ox, a.W, a.S, xlo, xhi);
+                    if (ix < xlo || ix >= xhi) continue;
+                    acc += g_at(oy, ox) / (float)((yhi - ylo) * (xhi - xlo));
+                }
+            }
+        }
+        gx[i] = acc * a.scale[c];
+    }
+}
+
+static int prep_args(const char *fn, int B, int H, int W, int S, int P, int mode, int oi, int oj, const float *scale3, const float *shift3, PrepArgs *a) {
+    if (B < 0 || H < 1 || W < 1 || S < 1 || P < 8 || P % 8 || S % P) return xq_set_error(XQ_EINVAL, "%s: bad geometry (patch %% 8, size %% patch)", fn);
+    if (mode == 0 && (oi < 0 || oj < 0 || oi + S > H || oj + S > W)) return xq_set_error(XQ_EINVAL, "%s: crop outside the image", fn);
+    if (mode == 1 && (S > H || S > W || 2L * S < H || 2L * S < W))
+        return xq_set_error(XQ_EINVAL, "%s: area mode handles down-scaling by less than 2 (windows of <= 2 x 2 pixels: the backward visits 3 x 3 candidates)", fn);
+    if (mode != 0 && mode != 1) return xq_set_error(XQ_EINVAL, "%s: mode 0 (crop) or 1 (area)", fn);
+    if (!scale3 || !shift3) return xq_set_error(XQ_EINVAL, "%s: null scale / shift (HOST pointers, 3 floats each)", fn);
+    a->B = B; a->H = H; a->W = W; a->S = S; a->P = P; a->G = S / P; a->mode = mode; a->oi = oi; a->oj = oj;
+    for (int c = 0; c < 3; ++c) { a->scale[c] = scale3[c]; a->shift[c] = shift3[c]; }
+    return XQ_OK;
+}
+
+extern "C" int xq_dino_prep_patches_forward(const float *x, int B, int H, int W, int S, int P, int mode, int oi, int oj, const float *scale3_host,
+                                            const float *shift3_host, void *cols_bf16, xq_stream_t stream) {
+    const char *fn = "xq_dino_prep_patches_forward";
+    PrepArgs a;
+    if (int rc = prep_args(fn, B, H, W, S, P, mode, oi, oj, scale3_host, shift3_host, &a)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!x || !cols_bf16) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * a.G * a.G * 3 * P * (P / 8);
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(dino_prep_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, a, (__hip_bfloat16 *)cols_bf16);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_dino_prep_patches_backward(const void *gcols_bf16, int B, int H, int W, int S, int P, int mode, int oi, int oj,
+                                             const float *scale3_host, const float *shift3_host, float *gx, xq_stream_t stream) {
+    const char *fn = "xq_dino_prep_patches_backward";
+    PrepArgs a;
+    if (int rc = prep_args(fn, B, H, W, S, P, mode, oi, oj, scale3_host, shift3_host, &a)) return rc;
+    if (B == 0) return XQ_OK;
+    if (!gcols_bf16 || !gx) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * 3 * H * W;
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(dino_prep_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)gcols_bf16, a, gx);
     return xq_check_launch(fn);
 }

@@ -1141,6 +1141,36 @@ class SpectralNormWeightFn(torch.autograd.Function):
         return out.view(g.shape), None, None, None
 
 
+class DinoPrepPatchFn(torch.autograd.Function):
+    """[-1, 1] image (B, 3, H, W) fp32 -> bf16 patch matrix (B * G * G, 3 * P * P) of the frozen DINO-S trunk's patch embedding: ImageNet
+    normalisation, random S-crop at (oi, oj) (mode 0) or area resize to S (mode 1), patchify and cast in ONE kernel; the backward gathers the
+    patch-embedding GEMM's data gradient back into the image (discriminator_dino.py:327-337, :262-276; csrc/xq_aug.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, mode, oi, oj, S, P, scale3, shift3):
+        B, _, H, W = x.shape
+        xc = x.detach().float().contiguous()
+        G = S // P
+        cols = torch.empty(B * G * G, 3 * P * P, dtype=torch.bfloat16, device=x.device)
+        sc, sh = (ctypes.c_float * 3)(*scale3), (ctypes.c_float * 3)(*shift3)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().xq_dino_prep_patches_forward(ptr(xc), B, H, W, S, P, mode, oi, oj, sc, sh, ptr(cols), _stream(xc))
+        check(rc, "xq_dino_prep_patches_forward")
+        ctx.cfg = (B, H, W, S, P, mode, oi, oj, tuple(scale3), tuple(shift3), x.dtype)
+        return cols
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, S, P, mode, oi, oj, scale3, shift3, in_dtype = ctx.cfg
+        g = g.detach().to(torch.bfloat16).contiguous()
+        gx = torch.empty(B, 3, H, W, dtype=torch.float32, device=g.device)
+        sc, sh = (ctypes.c_float * 3)(*scale3), (ctypes.c_float * 3)(*shift3)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().xq_dino_prep_patches_backward(ptr(g), B, H, W, S, P, mode, oi, oj, sc, sh, ptr(gx), _stream(g))
+        check(rc, "xq_dino_prep_patches_backward")
+        return gx.to(in_dtype), None, None, None, None, None, None, None
+
+
 class SpectralNormBatchFn(torch.autograd.Function):
     """SpectralNormWeightFn for H same-shaped Conv1d weights at once (the five DinoDisc heads hold the same three convolutions each,
     discriminator_dino.py:209-216): one power iteration per weight on the STACKED module buffers u_stack [H][R] / v_stack [H][Cin * taps]

@@ -70,6 +70,8 @@ FUSED_DIFFAUG = __import__("os").environ.get("XQ_FUSED_DIFFAUG", "1") == "1"
 FUSED_SPECTRAL_NORM = __import__("os").environ.get("XQ_FUSED_SN", "1") == "1"
 # round 5: the power iterations of the five heads' same-shaped convolutions as one batched launch chain per shape (XQ_BATCHED_SN=0: per weight)
 BATCHED_SPECTRAL_NORM = __import__("os").environ.get("XQ_BATCHED_SN", "1") == "1"
+# round 5: ImageNet normalisation + crop / area resize + patchify + cast of the DINO-S trunk's input as one kernel per direction
+FUSED_DINO_PREP = __import__("os").environ.get("XQ_FUSED_DINO_PREP", "1") == "1"
 # discriminator update: reconstruction and input share one pass over the frozen DINO-S trunk (DinoDisc.forward_pair)
 PAIRED_DISC_TRUNK = __import__("os").environ.get("XQ_PAIRED_DISC", "1") == "1"
 # class-token readout of the discriminator trunk as one kernel per tap (ops_dense.ClsReadoutFn)
@@ -336,13 +338,45 @@ class FrozenDINOSmallNoDrop(nn.Module):
                 x = F.interpolate(x, size=(self.img_size, self.img_size), mode='area' if H > self.img_size else 'bicubic')
         return x
 
-    def forward(self, x, grad_ckpt=False) -> List[torch.Tensor]:
-        return self.trunk(self.preprocess(x))
+    def preprocess_patches(self, x):
+        """`preprocess` + the patchify of the patch embedding in one kernel (ops_dense.DinoPrepPatchFn): the bf16 patch matrix
+        (B * 196, 768) the patch-embedding GEMM reads, or None when that path does not apply (CPU, fp32 parity runs, up-scaling) — the
+        caller then runs `preprocess`.  Draws the same host random numbers in the same order as `preprocess`."""
+        if not (FUSED_DINO_PREP and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and torch.is_autocast_enabled("cuda")
+                and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return None
+        H, W = x.shape[-2], x.shape[-1]
+        S = self.img_size
+        if not (H > S and W > S and H < 2 * S and W < 2 * S):
+            return None
+        from . import nn_ops, ops_dense
+        if not (nn_ops.FUSED_BLOCKS and ops_dense.GEMM_IMPL == "hip"):
+            return None
+        if random.random() <= 0.5:                                  # random 224-crop (:332-333)
+            mode = 0
+            i = int(torch.randint(0, H - S + 1, (1,)).item())
+            j = int(torch.randint(0, W - S + 1, (1,)).item())
+        else:
+            mode, i, j = 1, 0, 0
+        key = (self.x_scale._version, self.x_shift._version, self.x_scale.data_ptr())
+        if getattr(self, "_prep_consts", (None,))[0] != key:       # host copies of the two normalisation constants (read once)
+            self._prep_consts = (key, tuple(float(v) for v in self.x_scale.detach().flatten().cpu()),
+                                 tuple(float(v) for v in self.x_shift.detach().flatten().cpu()))
+        return ops_dense.DinoPrepPatchFn.apply(x, mode, i, j, S, self.patch_size, self._prep_consts[1], self._prep_consts[2])
 
-    def trunk(self, x) -> List[torch.Tensor]:
-        """patch embedding + the frozen blocks on a preprocessed (B, 3, 224, 224) batch; every op acts per sample"""
+    def forward(self, x, grad_ckpt=False) -> List[torch.Tensor]:
+        cols = self.preprocess_patches(x)
+        return self.trunk(self.preprocess(x)) if cols is None else self.trunk(None, cols=cols)
+
+    def trunk(self, x, cols=None) -> List[torch.Tensor]:
+        """patch embedding + the frozen blocks on a preprocessed (B, 3, 224, 224) batch — or on its patch matrix `cols` (preprocess_patches);
+        every op acts per sample"""
         from . import nn_ops
-        x = nn_ops.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.patch_size)  # conv as GEMM
+        if cols is not None:
+            n_tok = self.patch_nums * self.patch_nums
+            x = nn_ops.linear(cols, nn_ops._weight_2d(self.patch_embed.proj.weight), self.patch_embed.proj.bias).view(cols.shape[0] // n_tok, n_tok, -1)
+        else:
+            x = nn_ops.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.patch_size)  # conv as GEMM
         with torch.autocast(device_type=x.device.type, enabled=False):
             x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x.float()), dim=1) + self.pos_embed
         if x.is_cuda and nn_ops.FUSED_BLOCKS:
@@ -527,11 +561,20 @@ class DinoDisc(nn.Module):
         statistics are per call upstream, run per batch in upstream's order.  `make_*` are called in order (augmentation draws, then
         the crop draw of that batch), so the random streams are consumed exactly as by two separate forwards."""
         d = self.dino_proxy[0]
-        xa = d.preprocess(make_first().float())
-        xb = d.preprocess(make_second().float())
-        Ba = xa.shape[0]
+        ia = make_first().float()
+        ca = d.preprocess_patches(ia)
+        xa = d.preprocess(ia) if ca is None else None
+        ib = make_second().float()
+        cb = d.preprocess_patches(ib)
+        xb = d.preprocess(ib) if cb is None else None
+        Ba = ia.shape[0]
         with torch.no_grad():
-            acts = d.trunk(torch.cat([xa, xb], dim=0))
+            if ca is not None and cb is not None:
+                acts = d.trunk(None, cols=torch.cat([ca, cb], dim=0))
+            else:                                                    # (mixed: one of the two took the unfused route — patchify it the library way)
+                if xa is None or xb is None:
+                    raise RuntimeError("DinoDisc.forward_pair: the two batches took different preprocessing routes")
+                acts = d.trunk(torch.cat([xa, xb], dim=0))
         return self._heads([a[:Ba] for a in acts]), self._heads([a[Ba:] for a in acts])
 
 

@@ -303,6 +303,16 @@ int xq_diffaug_forward(const float *x, const float *rand01, int B, int H, int W,
 int xq_diffaug_backward(const float *g, const float *rand01, int B, int H, int W, int dh, int dw, int ch, int cw, int trans, int color, int cut,
                         float *gx, float *workspace, xq_stream_t stream);
 
+/* Input side of the frozen DINO-S trunk of the discriminator in one pass per direction (round 5; discriminator_dino.py:327-337 + PatchEmbed
+ * :262-276): ImageNet normalisation scale_c * x + shift_c of the [-1, 1] image (scale3 / shift3: HOST pointers, 3 floats), the S x S crop at
+ * (oi, oj) (mode 0) or the area resize to S x S (mode 1: F.interpolate(mode = 'area') = adaptive average pooling, windows
+ * [floor(o H / S), ceil((o + 1) H / S)); S <= H, W < 2 S), and the patchify of the P x P patch convolution: cols bf16 [(b, gy, gx)][(c, dy, dx)],
+ * the A operand of the patch-embedding GEMM.  backward: the GEMM's data gradient gcols (same layout, bf16) -> gx fp32 [B][3][H][W], by gather. */
+int xq_dino_prep_patches_forward(const float *x, int B, int H, int W, int S, int P, int mode, int oi, int oj, const float *scale3_host,
+                                 const float *shift3_host, void *cols_bf16, xq_stream_t stream);
+int xq_dino_prep_patches_backward(const void *gcols_bf16, int B, int H, int W, int S, int P, int mode, int oi, int oj, const float *scale3_host,
+                                  const float *shift3_host, float *gx, xq_stream_t stream);
+
 /* out [D] = sum over the nrows rows of partials [nrows][D] (fp32), fixed order: finishes the fc1 bias gradient from the column partials of
  * xq_gemm_bf16_nn_gelu_bwd */
 int xq_colsum_partials(const float *partials, int nrows, int D, float *out, xq_stream_t stream);

@@ -562,6 +562,36 @@ def test_batched_spectral_norm_equals_the_per_weight_path(shape, H):
         assert (grads[i] - rgrads[i]).abs().max().item() <= 2e-5 * max(1.0, rgrads[i].abs().max().item())
 
 
+@pytest.mark.parametrize("crop", [True, False])
+def test_fused_dino_input_preparation_equals_the_op_chain(crop, monkeypatch):
+    """ops_dense.DinoPrepPatchFn (xq_dino_prep_patches_forward / _backward: normalise, crop | area-resize, patchify, cast in one kernel) ==
+    FrozenDINOSmallNoDrop.preprocess + the patchify of nn_ops.patch_embed: the bf16 patch matrix, and the image gradient for the same
+    cotangent (the area branch's backward is a gather here, an atomicAdd scatter in ATen)."""
+    import random
+    from imagefolder_amd import vq_loss as vl
+    d = vl.FrozenDINOSmallNoDrop(depth=1, key_depths=(0,)).cuda()
+    B, P = 3, d.patch_size
+    x = (torch.rand(B, 3, 256, 256, device="cuda", generator=torch.Generator("cuda").manual_seed(4)) * 2 - 1)
+    monkeypatch.setattr(random, "random", lambda: 0.25 if crop else 0.75)
+    gen_state = torch.get_rng_state()
+    xi = x.clone().requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        cols = d.preprocess_patches(xi)
+    assert cols is not None and cols.dtype == torch.bfloat16 and tuple(cols.shape) == (B * 196, 3 * P * P)
+    torch.set_rng_state(gen_state)                              # the crop offsets come from the host generator: replay them
+    xr = x.clone().requires_grad_(True)
+    img = d.preprocess(xr)
+    gh = img.shape[-1] // P
+    ref = img.reshape(B, 3, gh, P, gh, P).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gh, 3 * P * P)
+    assert (cols.float() - ref.detach()).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())     # one bf16 rounding
+    g = torch.randn(cols.shape, device="cuda", generator=torch.Generator("cuda").manual_seed(5)).to(torch.bfloat16)
+    (gx,) = torch.autograd.grad(cols, xi, g)
+    (gr,) = torch.autograd.grad(ref, xr, g.float())
+    assert (gx - gr).abs().max().item() <= 1e-5 * max(1.0, gr.abs().max().item())
+    if crop:
+        assert float((gx == 0).float().mean()) > 0.2            # pixels outside the crop receive no gradient
+
+
 def test_dinodisc_heads_with_batched_spectral_norm_equal_the_per_weight_heads(monkeypatch):
     """DinoDisc._heads with the batched power iterations (stacked u / v buffers, weights handed over in GEMM layout) == the per-weight
     evaluation: logits, every head parameter's gradient, and the modules' weight_u / weight_v buffers (still what state_dict() saves)."""
