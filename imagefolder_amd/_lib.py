@@ -65,6 +65,8 @@ SIGNATURES = {
     "xq_sn_batched_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "xq_sn_batched_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "xq_row_partials_blocks": (ctypes.c_int, [ctypes.c_int64]),
+    "xq_token_assemble_forward": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 7 + [vp, vp]),
+    "xq_token_assemble_backward": (ctypes.c_int, [vp] + [ctypes.c_int] * 6 + [vp, vp, vp]),
     "xq_res_ln_forward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_float,
                                          ctypes.c_int, vp, vp, vp, vp, vp]),
     "xq_res_ln_backward": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int,

@@ -689,3 +689,98 @@ extern "C" int xq_colsum_partials(const float *partials, int nrows, int D, float
                        nullptr, nullptr, nullptr, 0);
     return xq_check_launch("xq_colsum_partials");
 }
+
+// ================================================================================================
+// Round 5: token assembly in front of a block stack (dino_enc/dinov2.py:149-179 encoder, :313-349 decoder; vision_transformer.py:818-851
+// _pos_embed): x[b][t] = table[t] + (start <= t < start + n ? data[b][t - start] : 0), where `table` (N x D fp32) is everything that
+// does not depend on the sample — class token, position table (resampled for the latent grid), learnable latent / mask tokens, level
+// embedding, assembled by the module's own op chain on a batch of ONE — and `data` are the per-sample tokens (patch embeddings in the
+// encoder and the teacher, quantised latents in the decoder).  Upstream then casts x to the autocast dtype; with round_bf16 the output is
+// that rounding, kept in fp32 (what the first LayerNorm / residual kernels read): the op chain's cat / add / cat / add / cast / cast-back
+// passes over a (B, N, D) tensor — six to eight of them per stack and direction, ~2.6 ms of a 180 ms step — become one pass.
+// Backward: g_data = the slice of g (in data's dtype), g_table[t] = sum_b g[b][t] in ascending b (deterministic) — one pass as well.
+// ================================================================================================
+template <typename TD>
+__global__ __launch_bounds__(256) void token_assemble_fwd_kernel(const float *__restrict__ table, const TD *__restrict__ data, int B, int N, int n, int start,
+                                                                 int D, int round_bf16, float *__restrict__ out) {
+    const int dv = D / 4;
+    const long total = (long)B * N * dv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int d4 = (int)(i % dv);
+        const long bt = i / dv;
+        const int t = (int)(bt % N);
+        const long b = bt / N;
+        float4 v = *reinterpret_cast<const float4 *>(table + (long)t * D + 4 * d4);
+        if (t >= start && t < start + n) {
+            float e[4];
+            load_vec<TD, 4>(data + ((b * n + (t - start)) * (long)D + 4 * d4), e);
+            v.x += e[0]; v.y += e[1]; v.z += e[2]; v.w += e[3];
+        }
+        if (round_bf16) {
+            v.x = __bfloat162float(__float2bfloat16(v.x)); v.y = __bfloat162float(__float2bfloat16(v.y));
+            v.z = __bfloat162float(__float2bfloat16(v.z)); v.w = __bfloat162float(__float2bfloat16(v.w));
+        }
+        *reinterpret_cast<float4 *>(out + i * 4) = v;
+    }
+}
+
+template <typename TD>
+__global__ __launch_bounds__(256) void token_assemble_bwd_kernel(const float *__restrict__ g, int B, int N, int n, int start, int D, TD *__restrict__ g_data,
+                                                                 float *__restrict__ g_table) {
+    const int dv = D / 4;
+    const long total = (long)N * dv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int d4 = (int)(i % dv);
+        const int t = (int)(i / dv);
+        const bool has = g_data != nullptr && t >= start && t < start + n;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int b0 = 0; b0 < B; b0 += 4) {      // four samples in flight per trip, added in ascending order
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + u < B ? b0 + u : b0;
+                v[u] = *reinterpret_cast<const float4 *>(g + (((long)b * N + t) * D + 4 * d4));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (b0 + u < B) {
+                    acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+                    if (has) {
+                        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                        store_vec<TD, 4>(g_data + (((long)(b0 + u) * n + (t - start)) * D + 4 * d4), e);
+                    }
+                }
+        }
+        if (g_table) *reinterpret_cast<float4 *>(g_table + (long)t * D + 4 * d4) = acc;
+    }
+}
+
+extern "C" int xq_token_assemble_forward(const float *table, const void *data, int data_bf16, int B, int N, int n, int start, int D, int round_bf16,
+                                         float *out, xq_stream_t stream) {
+    const char *fn = "xq_token_assemble_forward";
+    if (B < 0 || N < 1 || n < 0 || start < 0 || start + n > N || D < 4 || D % 4) return xq_set_error(XQ_EINVAL, "%s: bad geometry (D %% 4, start + n <= N)", fn);
+    if (B == 0) return XQ_OK;
+    if (!table || !out || (n > 0 && !data)) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)B * N * (D / 4);
+    long blocks = (total + 255) / 256;
+    const long cap = (long)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipStream_t s = (hipStream_t)stream;
+    if (data_bf16) hipLaunchKernelGGL((token_assemble_fwd_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, s, table, (const bf16 *)data, B, N, n, start, D, round_bf16, out);
+    else hipLaunchKernelGGL((token_assemble_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, table, (const float *)data, B, N, n, start, D, round_bf16, out);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_token_assemble_backward(const float *g, int data_bf16, int B, int N, int n, int start, int D, void *g_data, float *g_table,
+                                          xq_stream_t stream) {
+    const char *fn = "xq_token_assemble_backward";
+    if (B < 0 || N < 1 || n < 0 || start < 0 || start + n > N || D < 4 || D % 4) return xq_set_error(XQ_EINVAL, "%s: bad geometry (D %% 4, start + n <= N)", fn);
+    if (B == 0 || (!g_data && !g_table)) return XQ_OK;
+    if (!g) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long total = (long)N * (D / 4);
+    const long blocks = (total + 255) / 256;
+    hipStream_t s = (hipStream_t)stream;
+    if (data_bf16) hipLaunchKernelGGL((token_assemble_bwd_kernel<bf16>), dim3((unsigned)blocks), dim3(256), 0, s, g, B, N, n, start, D, (bf16 *)g_data, g_table);
+    else hipLaunchKernelGGL((token_assemble_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, s, g, B, N, n, start, D, (float *)g_data, g_table);
+    return xq_check_launch(fn);
+}

@@ -71,10 +71,10 @@ class DINOv2Encoder(nn.Module):
     def no_weight_decay(self):
         return ['model.pos_embed', 'model.cls_token', 'model.dist_token', 'latent_tokens', 'latent_pos_embed']
 
-    def forward(self, x, masks=None):
+    def _assemble(self, x):
+        """patch tokens (B, n, D) fp32 -> the sequence entering the blocks: [cls | patches | latent tokens] + position / level embeddings
+        (upstream :149-175, fp32, autocast off)"""
         m = self.model
-        x = m.patch_embed(x)
-        # position-embedding section runs in fp32 like upstream (dinov2.py:151 disables autocast here)
         with torch.autocast(device_type=x.device.type, enabled=False):
             x = m._pos_embed(x.float())
             if self.num_latent_tokens:
@@ -89,8 +89,23 @@ class DINOv2Encoder(nn.Module):
                     x = x + self.lvl_embed(self.lvl1LC)  # (1, L, D) broadcast over the batch (upstream expands the index first)
                 else:
                     x = torch.cat([x, z + self.latent_pos_embed], dim=1)
-        if torch.is_autocast_enabled() and x.is_cuda:
-            x = x.to(torch.get_autocast_dtype('cuda'))  # upstream probes the matmul dtype (:177-179)
+        return x
+
+    def forward(self, x, masks=None):
+        m = self.model
+        x = m.patch_embed(x)
+        from .. import ops_dense
+        if ops_dense.token_assemble_supported(x, x.shape[-1]):
+            # everything of the sequence that does not depend on the sample — class token, position tables, the learnable latent tokens, level
+            # embedding — from the op chain above on a batch of ONE (autograd intact: their gradients flow through it), the patch tokens added
+            # in one kernel that also applies upstream's cast to the autocast dtype (:177-179), as a rounding kept in fp32
+            table = self._assemble(torch.zeros(1, x.shape[1], x.shape[2], dtype=torch.float32, device=x.device))
+            x = ops_dense.TokenAssembleFn.apply(x, table, m.num_prefix_tokens, True)
+        else:
+            # position-embedding section runs in fp32 like upstream (dinov2.py:151 disables autocast here)
+            x = self._assemble(x)
+            if torch.is_autocast_enabled() and x.is_cuda:
+                x = x.to(torch.get_autocast_dtype('cuda'))  # upstream probes the matmul dtype (:177-179)
         x = nn_ops.vit_blocks(m.blocks, x, m.norm)
         if self.num_latent_tokens:
             return x[:, -self.num_latent_tokens:]
@@ -147,7 +162,8 @@ class DINOv2Decoder(nn.Module):
     def last_layer(self):
         return self.to_pixel.model.weight
 
-    def forward(self, z):
+    def _assemble(self, z):
+        """latent tokens (B, L, D) -> [cls | mask tokens | (cls') | latent tokens] + position / level embeddings (upstream :313-344, fp32)"""
         m = self.model
         x = self.mask_token.expand(z.size(0), self.num_img_tokens, -1)
         with torch.autocast(device_type=z.device.type, enabled=False):
@@ -161,8 +177,21 @@ class DINOv2Decoder(nn.Module):
             x = torch.cat([x, z], dim=1)
             if self.abs_pos_embed:
                 x = x + self.lvl_embed(self.lvl1LC)  # (1, L, D) broadcast over the batch (upstream expands the index first)
-        if torch.is_autocast_enabled() and x.is_cuda:
-            x = x.to(torch.get_autocast_dtype('cuda'))
+        return x
+
+    def forward(self, z):
+        m = self.model
+        from .. import ops_dense
+        if z.dim() == 3 and ops_dense.token_assemble_supported(z, z.shape[-1]):
+            # the sample-independent part (class tokens, mask tokens, position tables, level embedding) from the op chain on a batch of ONE
+            # zero latent; the quantised latents land behind it in one kernel (TokenAssembleFn, see DINOv2Encoder.forward)
+            table = self._assemble(torch.zeros(1, z.shape[1], z.shape[2], dtype=torch.float32, device=z.device))
+            start = self.num_img_tokens + m.num_prefix_tokens + (m.num_prefix_tokens if self.abs_pos_embed else 0)
+            x = ops_dense.TokenAssembleFn.apply(z, table, start, True)
+        else:
+            x = self._assemble(z)
+            if torch.is_autocast_enabled() and x.is_cuda:
+                x = x.to(torch.get_autocast_dtype('cuda'))
         x = nn_ops.vit_blocks(m.blocks, x, m.norm)
         x = x[:, self.num_prefix_tokens:self.num_img_tokens + self.num_prefix_tokens]
         return self.to_pixel(x)

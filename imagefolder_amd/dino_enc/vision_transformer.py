@@ -227,7 +227,24 @@ class VisionTransformer(nn.Module):
 
     def forward_features(self, x):
         x = self.patch_embed(x)
-        x = self._pos_embed(x)
+        from .. import ops_dense
+        if x.dim() == 3 and ops_dense.token_assemble_supported(x, x.shape[-1]):
+            # [cls | patches] + position table in one kernel (ops_dense.TokenAssembleFn); the sample-independent part comes from _pos_embed
+            # on ONE zero sample — for the frozen semantic teacher it is a constant, cached per parameter version
+            key = (self.cls_token._version, self.pos_embed._version, self.pos_embed.data_ptr(), x.shape[1])
+            frozen = not (self.cls_token.requires_grad or self.pos_embed.requires_grad)
+            cached = getattr(self, "_xq_token_table", None)
+            if frozen and cached is not None and cached[0] == key:
+                table = cached[1]
+            else:
+                table = self._pos_embed(torch.zeros(1, x.shape[1], x.shape[2], dtype=torch.float32, device=x.device))
+                if frozen:
+                    self._xq_token_table = (key, table.detach())
+            # (no cast to the autocast dtype here: upstream's plain VisionTransformer hands the fp32 sum to the blocks, whose LayerNorm
+            # autocast runs in fp32 — the kernel's rounding switch stays off)
+            x = ops_dense.TokenAssembleFn.apply(x, table, self.num_prefix_tokens, False)
+        else:
+            x = self._pos_embed(x)
         return nn_ops.vit_blocks(self.blocks, x, self.norm)
 
     def forward(self, x):

@@ -78,6 +78,48 @@ class LayerNormFn(torch.autograd.Function):
         return g_x.to(ctx.in_dtype), g_w, g_b, None, None
 
 
+class TokenAssembleFn(torch.autograd.Function):
+    """x[b, t] = table[t] + (start <= t < start + n ? data[b, t - start] : 0), rounded to bf16 and kept in fp32 (csrc/xq_dense.hip
+    token_assemble_*): the token sequence entering a block stack from its sample-independent part `table` (1, N, D) and the per-sample
+    tokens `data` (B, n, D) — one pass instead of the cat / add / cat / add / cast / cast-back chain, and one pass back."""
+
+    @staticmethod
+    def forward(ctx, data, table, start, round_bf16):
+        B, n, D = data.shape
+        N = table.shape[-2]
+        dc = data.detach()
+        if dc.dtype not in (torch.float32, torch.bfloat16):
+            dc = dc.float()
+        dc = dc.contiguous()
+        tc = table.detach().float().reshape(N, D).contiguous()
+        out = torch.empty(B, N, D, dtype=torch.float32, device=data.device)
+        with torch.cuda.device(data.device):
+            rc = _lib.lib().xq_token_assemble_forward(ptr(tc), ptr(dc), int(dc.dtype == torch.bfloat16), B, N, n, int(start), D, int(bool(round_bf16)),
+                                                      ptr(out), _stream(dc))
+        check(rc, "xq_token_assemble_forward")
+        ctx.cfg = (B, N, n, int(start), D, dc.dtype, data.dtype, tuple(table.shape), table.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, N, n, start, D, ddt, data_dtype, tshape, tdtype = ctx.cfg
+        g = g.detach().float().contiguous()
+        need_d, need_t = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        g_data = torch.empty(B, n, D, dtype=ddt, device=g.device) if need_d else None
+        g_table = torch.empty(N, D, dtype=torch.float32, device=g.device) if need_t else None
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().xq_token_assemble_backward(ptr(g), int(ddt == torch.bfloat16), B, N, n, start, D, ptr(g_data), ptr(g_table), _stream(g))
+        check(rc, "xq_token_assemble_backward")
+        return (g_data.to(data_dtype) if need_d else None, g_table.view(tshape).to(tdtype) if need_t else None, None, None)
+
+
+def token_assemble_supported(data, D):
+    """the fused token assembly serves the bf16-autocast GPU path (the training step); fp32 parity runs and the CPU mirror keep the op chain"""
+    from . import nn_ops
+    return (FUSED_TOKEN_ASSEMBLY and nn_ops.FUSED_BLOCKS and data.is_cuda and data.dim() == 3 and D % 4 == 0 and torch.is_autocast_enabled("cuda")
+            and torch.get_autocast_dtype("cuda") == torch.bfloat16 and data.dtype in (torch.float32, torch.bfloat16))
+
+
 class ResLNFn(torch.autograd.Function):
     """x_new = x + mask * (gamma * y);  a = LayerNorm(x_new).  `ybias` (the bias of the Linear that produced y) is an
     input only so that its gradient (column sums of g_y) can be returned from the fused backward."""
@@ -185,6 +227,7 @@ def _w16(weight):
     return weight.detach().to(torch.bfloat16)
 
 
+FUSED_TOKEN_ASSEMBLY = __import__("os").environ.get("XQ_FUSED_TOKENS", "1") == "1"      # round 5: TokenAssembleFn in front of the block stacks
 _SPLIT_K = 16  # slices of the token axis for the weight-gradient GEMM
 
 

@@ -187,6 +187,16 @@ int xq_adamw_ema_step_ex(float *p, float *g, float *m, float *v, float *ema, voi
  * level of the column sums that follow them (size the workspace with it: rows x quantities x width floats) */
 int xq_row_partials_blocks(int64_t rows);
 
+/* Token assembly in front of a block stack (round 5; dino_enc/dinov2.py:149-179,313-349, vision_transformer.py:818-851):
+ * out[b][t] = table[t] + (start <= t < start + n ? data[b][t - start] : 0), table fp32 [N][D] = the sample-independent part (class token,
+ * position table, learnable latent / mask tokens, level embedding), data fp32 / bf16 [B][n][D] = the per-sample tokens; round_bf16: the value
+ * is rounded to bf16 (upstream's cast to the autocast dtype) and kept in fp32.  backward: g fp32 [B][N][D] -> g_data (nullable, data's dtype)
+ * = the slice, g_table (nullable) [N][D] = sum over b in ascending order. */
+int xq_token_assemble_forward(const float *table, const void *data, int data_bf16, int B, int N, int n, int start, int D, int round_bf16,
+                              float *out, xq_stream_t stream);
+int xq_token_assemble_backward(const float *g, int data_bf16, int B, int N, int n, int start, int D, void *g_data, float *g_table,
+                               xq_stream_t stream);
+
 /* x_new = x + mask[row / rows_per_sample] * (gamma * y)   (LayerScale :291, DropPath, residual :337-338; y/gamma/mask
  * nullable); a = LayerNorm(x_new; lnw, lnb, eps) (:310,323; final norm :959).  x_new (nullable when y is null),
  * mean/rstd [rows] fp32 are saved for the backward.  D in {64,128,256,384,512,768,1024}. */

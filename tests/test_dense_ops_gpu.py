@@ -562,6 +562,68 @@ def test_batched_spectral_norm_equals_the_per_weight_path(shape, H):
         assert (grads[i] - rgrads[i]).abs().max().item() <= 2e-5 * max(1.0, rgrads[i].abs().max().item())
 
 
+@pytest.mark.parametrize("B,N,n,start,D,dt", [(5, 513, 256, 1, 768, torch.bfloat16), (3, 514, 256, 258, 768, torch.float32), (2, 7, 3, 4, 64, torch.bfloat16),
+                                              (130, 9, 9, 0, 8, torch.float32)])
+def test_token_assembly_kernel(B, N, n, start, D, dt):
+    """ops_dense.TokenAssembleFn: out[b, t] = bf16-round(table[t] + data[b, t - start]) kept in fp32; backward = slice + batch sum"""
+    from imagefolder_amd import ops_dense
+    gen = torch.Generator("cuda").manual_seed(B + N)
+    table = torch.randn(1, N, D, device="cuda", generator=gen).requires_grad_(True)
+    data = torch.randn(B, n, D, device="cuda", generator=gen).to(dt).requires_grad_(True)
+    for rnd in (True, False):
+        out = ops_dense.TokenAssembleFn.apply(data, table, start, rnd)
+        ref = table.detach().expand(B, N, D).clone()
+        ref[:, start:start + n] += data.detach().float()
+        if rnd:
+            ref = ref.to(torch.bfloat16).float()
+        assert out.dtype == torch.float32 and torch.equal(out, ref)
+    g = torch.randn(B, N, D, device="cuda", generator=gen)
+    gd, gt = torch.autograd.grad(out, (data, table), g)
+    assert gd.dtype == dt and torch.equal(gd, g[:, start:start + n].to(dt))
+    want = g.double().sum(0, keepdim=True)
+    assert (gt.double() - want).abs().max().item() <= 1e-5 * max(1.0, want.abs().max().item()) and gt.shape == table.shape
+
+
+def test_encoder_decoder_token_assembly_equals_the_op_chain(monkeypatch):
+    """DINOv2Encoder / DINOv2Decoder with TokenAssembleFn in front of the blocks == the cat / add / cast op chain: tokens entering the
+    blocks bit for bit (the same bf16 rounding of the same fp32 sums up to the association of the adds), outputs and the gradients of the
+    sample-independent parameters (class token, position table, latent / mask tokens, level embedding) to bf16 accuracy."""
+    from imagefolder_amd import ops_dense
+    from imagefolder_amd.dino_enc.dinov2 import DINOv2Encoder, DINOv2Decoder
+    kw = dict(model_name='vit_base_patch14_dinov2.lvd142m', pretrained=False, tuning_method='full', num_latent_tokens=16, abs_pos_embed=True,
+              model_kwargs={'img_size': 64, 'patch_size': 8, 'drop_path_rate': 0.0, 'embed_dim': 64, 'depth': 2, 'num_heads': 1})  # (patches = patch_size ** 2: upstream's lvl1LC sizing)
+    torch.manual_seed(0)
+    try:
+        enc = DINOv2Encoder(in_channels=3, product_quant=1, **kw).cuda().train()
+        dec = DINOv2Decoder(in_channels=3, **kw).cuda().train()
+    except TypeError as e:
+        pytest.skip(f"constructor signature differs: {e}")
+    for m in (enc, dec):
+        for n_, p in m.named_parameters():
+            if any(k in n_ for k in ("cls_token", "pos_embed", "latent_tokens", "mask_token", "lvl_embed")):
+                torch.nn.init.normal_(p, std=0.5)
+    x = torch.rand(6, 3, 64, 64, device="cuda") * 2 - 1
+    z = torch.randn(6, 16, 64, device="cuda")
+    res = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops_dense, "FUSED_TOKEN_ASSEMBLY", fused)
+        for m in (enc, dec):
+            m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            ye = enc(x)
+            yd = dec(z)
+        (ye.float().square().mean() + yd.float().square().mean()).backward()
+        res[fused] = (ye.float().detach(), yd.float().detach(),
+                      {n_: p.grad.detach().clone() for m in (enc, dec) for n_, p in m.named_parameters()
+                       if p.grad is not None and any(k in n_ for k in ("cls_token", "pos_embed", "latent_tokens", "mask_token", "lvl_embed"))})
+    for a, b in zip(res[True][:2], res[False][:2]):
+        assert (a - b).abs().max().item() <= 3e-2 * max(1.0, b.abs().max().item())
+    assert len(res[True][2]) >= 6 and res[True][2].keys() == res[False][2].keys()
+    for k_, gb in res[False][2].items():
+        ga = res[True][2][k_]
+        assert (ga - gb).norm().item() <= 3e-2 * max(gb.norm().item(), 1e-6), (k_, (ga - gb).norm().item(), gb.norm().item())
+
+
 @pytest.mark.parametrize("crop", [True, False])
 def test_fused_dino_input_preparation_equals_the_op_chain(crop, monkeypatch):
     """ops_dense.DinoPrepPatchFn (xq_dino_prep_patches_forward / _backward: normalise, crop | area-resize, patchify, cast in one kernel) ==
