@@ -614,11 +614,11 @@ def test_encoder_decoder_token_assembly_equals_the_op_chain(monkeypatch):
             yd = dec(z)
         (ye.float().square().mean() + yd.float().square().mean()).backward()
         res[fused] = (ye.float().detach(), yd.float().detach(),
-                      {n_: p.grad.detach().clone() for m in (enc, dec) for n_, p in m.named_parameters()
+                      {tag + n_: p.grad.detach().clone() for tag, m in (("enc.", enc), ("dec.", dec)) for n_, p in m.named_parameters()
                        if p.grad is not None and any(k in n_ for k in ("cls_token", "pos_embed", "latent_tokens", "mask_token", "lvl_embed"))})
     for a, b in zip(res[True][:2], res[False][:2]):
         assert (a - b).abs().max().item() <= 3e-2 * max(1.0, b.abs().max().item())
-    assert len(res[True][2]) >= 6 and res[True][2].keys() == res[False][2].keys()
+    assert len(res[True][2]) == 8 and res[True][2].keys() == res[False][2].keys()
     for k_, gb in res[False][2].items():
         ga = res[True][2][k_]
         assert (ga - gb).norm().item() <= 3e-2 * max(gb.norm().item(), 1e-6), (k_, (ga - gb).norm().item(), gb.norm().item())
@@ -677,11 +677,14 @@ def test_dinodisc_heads_with_batched_spectral_norm_equal_the_per_weight_heads(mo
     for k_ in sd:
         if k_.endswith(("weight_u", "weight_v")):
             assert (sd[k_] - st[k_]).abs().max().item() <= 2e-5, k_
+    gmax = max(q.grad.abs().max().item() for q in twin.parameters() if q.grad is not None)
     for (n, p), (_, q) in zip(d.named_parameters(), twin.named_parameters()):
         if p.grad is None:
             assert q.grad is None, n
             continue
-        scale = max(q.grad.abs().max().item(), 1e-6)
+        # (a convolution bias in front of a BatchNormLocal has a gradient of exactly zero in exact arithmetic: what both sides hold there is
+        #  rounding noise ~1e-6 of the other gradients — compared on the scale of the largest gradient, not on its own)
+        scale = max(q.grad.abs().max().item(), 1e-3 * gmax)
         assert (p.grad - q.grad).abs().max().item() <= 5e-2 * scale, (n, (p.grad - q.grad).abs().max().item(), scale)
     # the stacks follow the module through .to(): buffers re-homed, next forward rebuilds them
     d.float()
