@@ -211,17 +211,18 @@ __device__ __forceinline__ void area_win(int o, int in, int out, int &lo, int &h
 }
 
 __global__ __launch_bounds__(256) void dino_prep_fwd_kernel(const float *__restrict__ x, PrepArgs a, __hip_bfloat16 *__restrict__ cols) {
-    const int P8 = a.P / 8;
-    const long total = (long)a.B * a.G * a.G * 3 * a.P * P8;
+    // one thread = 8 consecutive pixels of one row of the S x S crop / resized image; consecutive threads walk along the row, so the image
+    // reads are coalesced (the 16-byte patch-matrix stores of a row land 2 per patch, 3 P P bf16 apart — they merge in L2 with the other
+    // rows of the patch).  (First version: consecutive threads walked (dx chunk, dy, c) of one patch — 32-byte image reads, 132 us per call.)
+    const int S8 = a.S / 8, K = 3 * a.P * a.P;
+    const long total = (long)a.B * 3 * a.S * S8;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int d8 = (int)(i % P8);
-        long t = i / P8;
-        const int dy = (int)(t % a.P); t /= a.P;
-        const int c = (int)(t % 3); t /= 3;
-        const int gx = (int)(t % a.G); t /= a.G;
-        const int gy = (int)(t % a.G);
-        const long b = t / a.G;
-        const int Y = gy * a.P + dy, X0 = gx * a.P + 8 * d8;
+        const int x8 = (int)(i % S8);
+        long t = i / S8;
+        const int Y = (int)(t % a.S); t /= a.S;
+        const int c = (int)(t % 3);
+        const long b = t / 3;
+        const int X0 = 8 * x8;
         const float *xp = x + (b * 3 + c) * (long)a.H * a.W;
         float v[8];
         if (a.mode == 0) {
@@ -244,7 +245,8 @@ __global__ __launch_bounds__(256) void dino_prep_fwd_kernel(const float *__restr
         struct alignas(16) B8 { __hip_bfloat16 h[8]; } o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o.h[e] = __float2bfloat16(__builtin_fmaf(a.scale[c], v[e], a.shift[c]));
-        *reinterpret_cast<B8 *>(cols + i * 8) = o;
+        const int gy = Y / a.P, dy = Y - gy * a.P, gx = X0 / a.P, dx = X0 - gx * a.P;      // P % 8 == 0: the 8 pixels lie in one patch
+        *reinterpret_cast<B8 *>(cols + ((b * a.G + gy) * a.G + gx) * (long)K + (c * a.P + dy) * a.P + dx) = o;
     }
 }
 
@@ -305,7 +307,7 @@ extern "C" int xq_dino_prep_patches_forward(const float *x, int B, int H, int W,
     if (int rc = prep_args(fn, B, H, W, S, P, mode, oi, oj, scale3_host, shift3_host, &a)) return rc;
     if (B == 0) return XQ_OK;
     if (!x || !cols_bf16) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
-    const long total = (long)B * a.G * a.G * 3 * P * (P / 8);
+    const long total = (long)B * 3 * S * (S / 8);
     long blocks = (total + 255) / 256;
     const long cap = (long)num_cus() * 16;
     if (blocks > cap) blocks = cap;
@@ -325,5 +327,60 @@ extern "C" int xq_dino_prep_patches_backward(const void *gcols_bf16, int B, int 
     const long cap = (long)num_cus() * 16;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(dino_prep_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)gcols_bf16, a, gx);
+    return xq_check_launch(fn);
+}
+
+// out (bf16 planar) = scale_c * x + shift_c for a (B, 3, H, W) fp32 image batch: the input scaling of LPIPS ((x - shift) / scale, lpips.py:59-64)
+// and the cast autocast applies in front of the first VGG convolution, in one pass (were sub, div, cast: three); backward g_x = scale_c * g.
+__global__ __launch_bounds__(256) void image_affine_fwd_kernel(const float *__restrict__ x, long plane4, float s0, float s1, float s2, float h0,
+                                                               float h1, float h2, __hip_bfloat16 *__restrict__ out, long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c = (int)((i / plane4) % 3);
+        const float sc = c == 0 ? s0 : (c == 1 ? s1 : s2), sh = c == 0 ? h0 : (c == 1 ? h1 : h2);
+        const float4 v = *reinterpret_cast<const float4 *>(x + i * 4);
+        struct alignas(8) B4 { __hip_bfloat16 a, b, c, d; } o = {__float2bfloat16(__builtin_fmaf(sc, v.x, sh)), __float2bfloat16(__builtin_fmaf(sc, v.y, sh)),
+                                                                 __float2bfloat16(__builtin_fmaf(sc, v.z, sh)), __float2bfloat16(__builtin_fmaf(sc, v.w, sh))};
+        *reinterpret_cast<B4 *>(out + i * 4) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void image_affine_bwd_kernel(const __hip_bfloat16 *__restrict__ g, long plane4, float s0, float s1, float s2,
+                                                               float *__restrict__ gx, long total4) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        const int c = (int)((i / plane4) % 3);
+        const float sc = c == 0 ? s0 : (c == 1 ? s1 : s2);
+        struct alignas(8) B4 { __hip_bfloat16 a, b, c, d; };
+        const B4 v = *reinterpret_cast<const B4 *>(g + i * 4);
+        *reinterpret_cast<float4 *>(gx + i * 4) = make_float4(sc * __bfloat162float(v.a), sc * __bfloat162float(v.b), sc * __bfloat162float(v.c),
+                                                              sc * __bfloat162float(v.d));
+    }
+}
+
+extern "C" int xq_image_affine_bf16_forward(const float *x, int B, int H, int W, const float *scale3_host, const float *shift3_host, void *out_bf16,
+                                            xq_stream_t stream) {
+    const char *fn = "xq_image_affine_bf16_forward";
+    if (B < 0 || H < 1 || W < 1 || ((long)H * W) % 4) return xq_set_error(XQ_EINVAL, "%s: bad geometry (H * W %% 4)", fn);
+    if (B == 0) return XQ_OK;
+    if (!x || !out_bf16 || !scale3_host || !shift3_host) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long plane4 = (long)H * W / 4, total4 = plane4 * 3 * B;
+    long blocks = (total4 + 255) / 256;
+    const long cap = (long)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(image_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, plane4, scale3_host[0], scale3_host[1],
+                       scale3_host[2], shift3_host[0], shift3_host[1], shift3_host[2], (__hip_bfloat16 *)out_bf16, total4);
+    return xq_check_launch(fn);
+}
+
+extern "C" int xq_image_affine_bf16_backward(const void *g_bf16, int B, int H, int W, const float *scale3_host, float *gx, xq_stream_t stream) {
+    const char *fn = "xq_image_affine_bf16_backward";
+    if (B < 0 || H < 1 || W < 1 || ((long)H * W) % 4) return xq_set_error(XQ_EINVAL, "%s: bad geometry (H * W %% 4)", fn);
+    if (B == 0) return XQ_OK;
+    if (!g_bf16 || !gx || !scale3_host) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    const long plane4 = (long)H * W / 4, total4 = plane4 * 3 * B;
+    long blocks = (total4 + 255) / 256;
+    const long cap = (long)num_cus() * 16;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(image_affine_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)g_bf16, plane4, scale3_host[0],
+                       scale3_host[1], scale3_host[2], gx, total4);
     return xq_check_launch(fn);
 }

@@ -60,8 +60,9 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size, bias=bias)
         self.norm = nn.Identity()
 
-    def forward(self, x):
-        return nn_ops.patch_embed(x, self.proj.weight, self.proj.bias, self.patch_size[0])
+    def forward(self, x, affine=None):
+        """affine = (scale3, shift3): a per-channel input normalisation folded into the patchify kernel (nn_ops.patch_embed)"""
+        return nn_ops.patch_embed(x, self.proj.weight, self.proj.bias, self.patch_size[0], affine=affine)
 
 
 class Mlp(nn.Module):
@@ -225,8 +226,8 @@ class VisionTransformer(nn.Module):
         x = torch.cat([self.cls_token.expand(x.shape[0], -1, -1), x], dim=1)
         return x + pos_embed
 
-    def forward_features(self, x):
-        x = self.patch_embed(x)
+    def forward_features(self, x, input_affine=None):
+        x = self.patch_embed(x) if input_affine is None else self.patch_embed(x, affine=input_affine)
         from .. import ops_dense
         if x.dim() == 3 and ops_dense.token_assemble_supported(x, x.shape[-1]):
             # [cls | patches] + position table in one kernel (ops_dense.TokenAssembleFn); the sample-independent part comes from _pos_embed
@@ -247,8 +248,8 @@ class VisionTransformer(nn.Module):
             x = self._pos_embed(x)
         return nn_ops.vit_blocks(self.blocks, x, self.norm)
 
-    def forward(self, x):
-        x = self.forward_features(x)
+    def forward(self, x, input_affine=None):
+        x = self.forward_features(x, input_affine=input_affine)
         return x[:, 0]  # global_pool == 'token', head == Identity
 
 

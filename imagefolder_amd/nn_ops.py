@@ -155,13 +155,25 @@ def _weight_2d(weight):
     return w2
 
 
-def patch_embed(x, weight, bias, patch):
+def patch_embed(x, weight, bias, patch, affine=None):
     """Conv2d(kernel = stride = patch) + flatten(2).transpose(1, 2): (B,3,H,W) -> (B, (H/p)*(W/p), D).
     A non-overlapping conv is a GEMM over patchified pixels: (B*gh*gw, 3*p*p) @ W^T.  (MIOpen has no tuned bf16
     solver for this shape on gfx950 and falls back to naive_conv_* kernels: 35 % of the step in profiles/r01.)"""
     IMPL["patch_embed"] = "linear over patchified pixels (see `linear`)"
     B, Cin, H, W = x.shape
     gh, gw = H // patch, W // patch
+    if affine is not None or (x.is_cuda and Cin == 3 and H == W and patch % 8 == 0 and H % patch == 0):
+        from . import ops_dense
+        if ops_dense.image_prep_supported(x) and H == W and patch % 8 == 0 and H % patch == 0:
+            # patchify (+ an input normalisation, `affine` = (scale3, shift3)) + the cast to the GEMM's bf16 in one kernel (DinoPrepPatchFn in its
+            # crop mode over the whole image) instead of a permute-copy and a cast (and the mul / add passes of the normalisation)
+            sc, sh = affine if affine is not None else ((1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
+            cols = ops_dense.DinoPrepPatchFn.apply(x, 0, 0, 0, H, patch, tuple(sc), tuple(sh))
+            return linear(cols, _weight_2d(weight), bias).view(B, gh * gw, -1)
+    if affine is not None:
+        sc = torch.tensor(affine[0], dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+        sh = torch.tensor(affine[1], dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
+        x = x * sc + sh
     cols = x.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cin * patch * patch)
     return linear(cols, _weight_2d(weight), bias)
 

@@ -227,6 +227,7 @@ def _w16(weight):
     return weight.detach().to(torch.bfloat16)
 
 
+FUSED_IMAGE_PREP = __import__("os").environ.get("XQ_FUSED_IMAGE_PREP", "1") == "1"      # round 5: affine + cast / + patchify of input images in one kernel
 FUSED_TOKEN_ASSEMBLY = __import__("os").environ.get("XQ_FUSED_TOKENS", "1") == "1"      # round 5: TokenAssembleFn in front of the block stacks
 _SPLIT_K = 16  # slices of the token axis for the weight-gradient GEMM
 
@@ -1212,6 +1213,41 @@ class DinoPrepPatchFn(torch.autograd.Function):
             rc = _lib.lib().xq_dino_prep_patches_backward(ptr(g), B, H, W, S, P, mode, oi, oj, sc, sh, ptr(gx), _stream(g))
         check(rc, "xq_dino_prep_patches_backward")
         return gx.to(in_dtype), None, None, None, None, None, None, None
+
+
+class ImageAffineBf16Fn(torch.autograd.Function):
+    """bf16(scale_c * x + shift_c) of an fp32 image batch (B, 3, H, W) in one pass (csrc/xq_aug.hip image_affine_*): the LPIPS input scaling
+    + autocast's cast in front of conv1_1 (lpips.py:59-64); backward g_x = scale_c * g."""
+
+    @staticmethod
+    def forward(ctx, x, scale3, shift3):
+        B, _, H, W = x.shape
+        xc = x.detach().float().contiguous()
+        out = torch.empty(B, 3, H, W, dtype=torch.bfloat16, device=x.device)
+        sc, sh = (ctypes.c_float * 3)(*scale3), (ctypes.c_float * 3)(*shift3)
+        with torch.cuda.device(x.device):
+            rc = _lib.lib().xq_image_affine_bf16_forward(ptr(xc), B, H, W, sc, sh, ptr(out), _stream(xc))
+        check(rc, "xq_image_affine_bf16_forward")
+        ctx.cfg = (B, H, W, tuple(scale3), x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, H, W, scale3, in_dtype = ctx.cfg
+        g = g.detach().to(torch.bfloat16).contiguous()
+        gx = torch.empty(B, 3, H, W, dtype=torch.float32, device=g.device)
+        sc = (ctypes.c_float * 3)(*scale3)
+        with torch.cuda.device(g.device):
+            rc = _lib.lib().xq_image_affine_bf16_backward(ptr(g), B, H, W, sc, ptr(gx), _stream(g))
+        check(rc, "xq_image_affine_bf16_backward")
+        return gx.to(in_dtype), None, None
+
+
+def image_prep_supported(x):
+    """the fused image-side preparation kernels (ImageAffineBf16Fn, DinoPrepPatchFn) serve the bf16-autocast GPU path"""
+    from . import nn_ops
+    return (FUSED_IMAGE_PREP and nn_ops.FUSED_BLOCKS and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and (x.shape[2] * x.shape[3]) % 4 == 0)
 
 
 class SpectralNormBatchFn(torch.autograd.Function):

@@ -104,7 +104,7 @@ class _VGG16Slices(nn.Module):
     def forward(self, x):
         # channels-last activations: MIOpen's bf16 implicit-GEMM solvers are NHWC (igemm_*_nhwc_bf16); with NCHW bf16
         # it falls back to naive_conv_* kernels on gfx950 (profiles/r01_full_step_naive_conv_stats.txt: 0.75 s/step)
-        if x.is_cuda:
+        if x.is_cuda and x.shape[1] != 3:      # (the 3-channel image goes into conv1_1 planar: converting it would be two wasted copies)
             x = x.contiguous(memory_format=torch.channels_last)
         from . import nn_ops
         outs = []
@@ -158,10 +158,22 @@ class LPIPS(nn.Module):
         """`input` is the data (no gradient), `target` the reconstruction — the order VQLoss calls it in (vq_loss.py:169)."""
         if target.is_cuda and not input.requires_grad:
             from . import ops_dense
-            with torch.no_grad():
-                f0 = self.net((input - self.shift) / self.scale)
+            if ops_dense.image_prep_supported(target) and input.dtype == torch.float32:
+                # (x - shift) / scale and autocast's cast in front of conv1_1 as one pass per image batch (ops_dense.ImageAffineBf16Fn)
+                key = (self.shift._version, self.scale._version, self.scale.data_ptr())
+                if getattr(self, "_affine_consts", (None,))[0] != key:
+                    sc = [1.0 / float(v) for v in self.scale.detach().flatten().cpu()]
+                    sh = [-float(m) * k for m, k in zip(self.shift.detach().flatten().cpu(), sc)]
+                    self._affine_consts = (key, tuple(sc), tuple(sh))
+                _, sc, sh = self._affine_consts
+                with torch.no_grad():
+                    f0 = self.net(ops_dense.ImageAffineBf16Fn.apply(input, sc, sh))
+                x1 = ops_dense.ImageAffineBf16Fn.apply(target, sc, sh)
+            else:
+                with torch.no_grad():
+                    f0 = self.net((input - self.shift) / self.scale)
+                x1 = (target - self.shift) / self.scale
             lins = [getattr(self, f"lin{k}").model[-1].weight for k in range(len(self.chns))]
-            x1 = (target - self.shift) / self.scale
             if FUSED_VGG_BACKWARD and torch.is_autocast_enabled("cuda") and all(f.dtype == torch.bfloat16 for f in f0):
                 # the trunk + the five level comparisons as one node with a hand-driven backward (ops_dense.LpipsVggFn)
                 return ops_dense.LpipsVggFn.apply(x1, self.net, f0, lins).view(-1, 1, 1, 1)

@@ -367,11 +367,27 @@ class VQModel(nn.Module):
 
         if self.semantic_guide != 'none':
             with torch.no_grad():
-                inp = self.normalize(self.denormalize(input))
-                if self.guide_type_1 == 'class':
-                    z_s = self.semantic_model(inp)[..., None, None]
+                from . import ops_dense
+                if ops_dense.image_prep_supported(input):
+                    # normalize(denormalize(x)) = x * (s1 / s2) + (m1 - m2) / s2 per channel: folded into the teacher's patchify kernel
+                    # (four element-wise passes over the image batch + the permute-copy + the cast -> one kernel)
+                    dn, nm = self.denormalize, self.normalize
+                    key = (dn.mean._version, dn.std._version, nm.mean._version, nm.std._version, nm.std.data_ptr())
+                    if getattr(self, "_sem_affine", (None,))[0] != key:
+                        s1, m1 = dn.std.flatten().tolist(), dn.mean.flatten().tolist()
+                        s2, m2 = nm.std.flatten().tolist(), nm.mean.flatten().tolist()
+                        self._sem_affine = (key, (tuple(a / b_ for a, b_ in zip(s1, s2)), tuple((a - c_) / b_ for a, c_, b_ in zip(m1, m2, s2))))
+                    aff = self._sem_affine[1]
+                    if self.guide_type_1 == 'class':
+                        z_s = self.semantic_model(input, input_affine=aff)[..., None, None]
+                    else:
+                        z_s = self.semantic_model.forward_features(input, input_affine=aff)[:, 1:, :].reshape(b, 768, 16, 16)
                 else:
-                    z_s = self.semantic_model.forward_features(inp)[:, 1:, :].reshape(b, 768, 16, 16)
+                    inp = self.normalize(self.denormalize(input))
+                    if self.guide_type_1 == 'class':
+                        z_s = self.semantic_model(inp)[..., None, None]
+                    else:
+                        z_s = self.semantic_model.forward_features(inp)[:, 1:, :].reshape(b, 768, 16, 16)
             if self.enc_type == 'dinov2':
                 z_s = nn_ops.conv1x1(z_s, self.quant_conv.weight, self.quant_conv.bias).contiguous()
                 z_s = torch.mean(z_s, dim=(2, 3)).contiguous()

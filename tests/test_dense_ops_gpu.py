@@ -624,6 +624,42 @@ def test_encoder_decoder_token_assembly_equals_the_op_chain(monkeypatch):
         assert (ga - gb).norm().item() <= 3e-2 * max(gb.norm().item(), 1e-6), (k_, (ga - gb).norm().item(), gb.norm().item())
 
 
+def test_image_affine_cast_and_fused_patchify_equal_the_op_chains(monkeypatch):
+    """ops_dense.ImageAffineBf16Fn == bf16((x - shift) / scale) (the LPIPS scaling layer + autocast's cast), and nn_ops.patch_embed with the
+    patchify (+ input normalisation) folded into one kernel == permute-copy + cast (+ mul / add): values to one bf16 rounding, gradients to fp32."""
+    from imagefolder_amd import nn_ops, ops_dense
+    gen = torch.Generator("cuda").manual_seed(8)
+    x = (torch.rand(3, 3, 64, 64, device="cuda", generator=gen) * 2 - 1).requires_grad_(True)
+    shift, scale = torch.tensor([-.030, -.088, -.188], device="cuda").view(1, 3, 1, 1), torch.tensor([.458, .448, .450], device="cuda").view(1, 3, 1, 1)
+    sc = [1.0 / v for v in scale.flatten().tolist()]
+    sh = [-m * k for m, k in zip(shift.flatten().tolist(), sc)]
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ops_dense.ImageAffineBf16Fn.apply(x, sc, sh)
+    ref = (x.detach() - shift) / scale
+    assert y.dtype == torch.bfloat16 and (y.float() - ref).abs().max().item() <= 2.0 ** -7 * ref.abs().max().item()
+    g = torch.randn(y.shape, device="cuda", generator=gen).to(torch.bfloat16)
+    (gx,) = torch.autograd.grad(y, x, g)
+    assert (gx - g.float() / scale).abs().max().item() <= 1e-6 * (g.float() / scale).abs().max().item()
+    # patch embedding: fused patchify (with and without an input affine) against the op chain
+    w = torch.randn(64, 3, 8, 8, device="cuda", generator=gen) * 0.05
+    b = torch.randn(64, device="cuda", generator=gen) * 0.1
+    aff = ((2.0, 0.5, 1.5), (0.1, -0.2, 0.3))
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops_dense, "FUSED_IMAGE_PREP", fused)
+        for a in (None, aff):
+            xi = x.detach().clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                o = nn_ops.patch_embed(xi, w, b, 8, affine=a)
+            (gi,) = torch.autograd.grad(o.float().square().mean(), xi)
+            outs[(fused, a is None)] = (o.float().detach(), gi)
+    for plain in (True, False):
+        (o1, g1), (o0, g0) = outs[(True, plain)], outs[(False, plain)]
+        assert o1.shape == o0.shape == (3, 64, 64)
+        assert (o1 - o0).abs().max().item() <= 3e-2 * max(1.0, o0.abs().max().item())
+        assert (g1 - g0).norm().item() <= 3e-2 * g0.norm().item()
+
+
 @pytest.mark.parametrize("crop", [True, False])
 def test_fused_dino_input_preparation_equals_the_op_chain(crop, monkeypatch):
     """ops_dense.DinoPrepPatchFn (xq_dino_prep_patches_forward / _backward: normalise, crop | area-resize, patchify, cast in one kernel) ==
