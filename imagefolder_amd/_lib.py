@@ -56,8 +56,8 @@ SIGNATURES = {
     "xq_diffaug_backward": (ctypes.c_int, [vp, vp] + [ctypes.c_int] * 10 + [vp, vp, vp]),
     "xq_dino_prep_patches_forward": (ctypes.c_int, [vp] + [ctypes.c_int] * 8 + [c_f32p, c_f32p, vp, vp]),
     "xq_dino_prep_patches_backward": (ctypes.c_int, [vp] + [ctypes.c_int] * 8 + [c_f32p, c_f32p, vp, vp]),
-    "xq_image_affine_bf16_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, vp, vp]),
-    "xq_image_affine_bf16_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, vp, vp]),
+    "xq_image_affine_bf16_forward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, c_f32p, vp, vp]),
+    "xq_image_affine_bf16_backward": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, c_f32p, vp, ctypes.c_int, vp]),
     "xq_rowdot_forward": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_rowdot_backward": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
     "xq_colsum_partials": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, vp]),

@@ -205,9 +205,9 @@ struct PrepArgs {
     float scale[3], shift[3];
 };
 
-__device__ __forceinline__ void area_win(int o, int in, int out, int &lo, int &hi) {
-    lo = (int)(((long)o * in) / out);
-    hi = (int)((((long)o + 1) * in + out - 1) / out);
+__device__ __forceinline__ void area_win(int o, int in, int out, int &lo, int &hi) {      // (o + 1) * in < 2^31: checked by the launcher
+    lo = (o * in) / out;
+    hi = ((o + 1) * in + out - 1) / out;
 }
 
 __global__ __launch_bounds__(256) void dino_prep_fwd_kernel(const float *__restrict__ x, PrepArgs a, __hip_bfloat16 *__restrict__ cols) {
@@ -260,29 +260,40 @@ __global__ __launch_bounds__(256) void dino_prep_bwd_kernel(const __hip_bfloat16
         const int c = (int)(t % 3);
         const long b = t / 3;
         float acc = 0.0f;
+        const __hip_bfloat16 *gb = gcols + b * (long)a.G * a.G * K + (long)c * a.P * a.P;
         auto g_at = [&](int Y, int X) -> float {       // gradient of crop / resized pixel (Y, X) of plane c
             const int gy = Y / a.P, dy = Y - gy * a.P, gxx = X / a.P, dx = X - gxx * a.P;
-            return __bfloat162float(gcols[((b * a.G + gy) * a.G + gxx) * (long)K + (c * a.P + dy) * a.P + dx]);
+            return __bfloat162float(gb[(long)(gy * a.G + gxx) * K + dy * a.P + dx]);
         };
         if (a.mode == 0) {
             const int Y = iy - a.oi, X = ix - a.oj;
             if (Y >= 0 && Y < a.S && X >= 0 && X < a.S) acc = g_at(Y, X);
         } else {
-            // output rows whose window holds iy: around floor(iy S / H)
-            const int oy0 = (int)(((long)iy * a.S) / a.H), ox0 = (int)(((long)ix * a.S) / a.W);
-            for (int oy = oy0 - 1; oy <= oy0 + 1; ++oy) {
-                if (oy < 0 || oy >= a.S) continue;
-                int ylo, yhi;
-                area_win(oy, a.H, a.S, ylo, yhi);
-                if (iy < ylo || iy >= yhi) continue;
-                for (int ox = ox0 - 1; ox <= ox0 + 1; ++ox) {
-                    if (ox < 0 || ox >= a.S) continue;
-                    int xlo, xhi;
-                    area_win(ox, a.W, a.S, xlo, xhi);
-                    if (ix < xlo || ix >= xhi) continue;
-                    acc += g_at(oy, ox) / (float)((yhi - ylo) * (xhi - xlo));
+            // the (<= 3 candidate, <= 2 live) output rows / columns whose window holds iy / ix, with the reciprocal window lengths: the area
+            // weight 1 / (wh * ww) is separable, so the two axes are resolved once each instead of per (row, column) pair
+            int oyv[3], oxv[3];
+            float wyv[3], wxv[3];
+            const int oy0 = (iy * a.S) / a.H, ox0 = (ix * a.S) / a.W;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int o = oy0 - 1 + k, lo, hi;
+                wyv[k] = 0.0f; oyv[k] = 0;
+                if (o >= 0 && o < a.S) {
+                    area_win(o, a.H, a.S, lo, hi);
+                    if (iy >= lo && iy < hi) { wyv[k] = 1.0f / (float)(hi - lo); oyv[k] = o; }
+                }
+                o = ox0 - 1 + k;
+                wxv[k] = 0.0f; oxv[k] = 0;
+                if (o >= 0 && o < a.S) {
+                    area_win(o, a.W, a.S, lo, hi);
+                    if (ix >= lo && ix < hi) { wxv[k] = 1.0f / (float)(hi - lo); oxv[k] = o; }
                 }
             }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (wyv[p] != 0.0f && wxv[q] != 0.0f) acc = __builtin_fmaf(wyv[p] * wxv[q], g_at(oyv[p], oxv[q]), acc);
         }
         gx[i] = acc * a.scale[c];
     }
@@ -294,6 +305,7 @@ static int prep_args(const char *fn, int B, int H, int W, int S, int P, int mode
     if (mode == 1 && (S > H || S > W || 2L * S < H || 2L * S < W))
         return xq_set_error(XQ_EINVAL, "%s: area mode handles down-scaling by less than 2 (windows of <= 2 x 2 pixels: the backward visits 3 x 3 candidates)", fn);
     if (mode != 0 && mode != 1) return xq_set_error(XQ_EINVAL, "%s: mode 0 (crop) or 1 (area)", fn);
+    if ((long)(S + 1) * (H > W ? H : W) >= 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: image too large for 32-bit window arithmetic", fn);
     if (!scale3 || !shift3) return xq_set_error(XQ_EINVAL, "%s: null scale / shift (HOST pointers, 3 floats each)", fn);
     a->B = B; a->H = H; a->W = W; a->S = S; a->P = P; a->G = S / P; a->mode = mode; a->oi = oi; a->oj = oj;
     for (int c = 0; c < 3; ++c) { a->scale[c] = scale3[c]; a->shift[c] = shift3[c]; }
@@ -332,31 +344,43 @@ extern "C" int xq_dino_prep_patches_backward(const void *gcols_bf16, int B, int 
 
 // out (bf16 planar) = scale_c * x + shift_c for a (B, 3, H, W) fp32 image batch: the input scaling of LPIPS ((x - shift) / scale, lpips.py:59-64)
 // and the cast autocast applies in front of the first VGG convolution, in one pass (were sub, div, cast: three); backward g_x = scale_c * g.
-__global__ __launch_bounds__(256) void image_affine_fwd_kernel(const float *__restrict__ x, long plane4, float s0, float s1, float s2, float h0,
+struct alignas(8) Bf4 { __hip_bfloat16 a, b, c, d; };
+__device__ __forceinline__ float4 load4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float4 load4(const __hip_bfloat16 *p) {
+    const Bf4 v = *reinterpret_cast<const Bf4 *>(p);
+    return make_float4(__bfloat162float(v.a), __bfloat162float(v.b), __bfloat162float(v.c), __bfloat162float(v.d));
+}
+__device__ __forceinline__ void store4(float *p, float4 v) { *reinterpret_cast<float4 *>(p) = v; }
+__device__ __forceinline__ void store4(__hip_bfloat16 *p, float4 v) {
+    const Bf4 o = {__float2bfloat16(v.x), __float2bfloat16(v.y), __float2bfloat16(v.z), __float2bfloat16(v.w)};
+    *reinterpret_cast<Bf4 *>(p) = o;
+}
+
+template <typename TI>
+__global__ __launch_bounds__(256) void image_affine_fwd_kernel(const TI *__restrict__ x, long plane4, float s0, float s1, float s2, float h0,
                                                                float h1, float h2, __hip_bfloat16 *__restrict__ out, long total4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const int c = (int)((i / plane4) % 3);
         const float sc = c == 0 ? s0 : (c == 1 ? s1 : s2), sh = c == 0 ? h0 : (c == 1 ? h1 : h2);
-        const float4 v = *reinterpret_cast<const float4 *>(x + i * 4);
+        const float4 v = load4(x + i * 4);
         struct alignas(8) B4 { __hip_bfloat16 a, b, c, d; } o = {__float2bfloat16(__builtin_fmaf(sc, v.x, sh)), __float2bfloat16(__builtin_fmaf(sc, v.y, sh)),
                                                                  __float2bfloat16(__builtin_fmaf(sc, v.z, sh)), __float2bfloat16(__builtin_fmaf(sc, v.w, sh))};
         *reinterpret_cast<B4 *>(out + i * 4) = o;
     }
 }
 
+template <typename TO>
 __global__ __launch_bounds__(256) void image_affine_bwd_kernel(const __hip_bfloat16 *__restrict__ g, long plane4, float s0, float s1, float s2,
-                                                               float *__restrict__ gx, long total4) {
+                                                               TO *__restrict__ gx, long total4) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
         const int c = (int)((i / plane4) % 3);
         const float sc = c == 0 ? s0 : (c == 1 ? s1 : s2);
-        struct alignas(8) B4 { __hip_bfloat16 a, b, c, d; };
-        const B4 v = *reinterpret_cast<const B4 *>(g + i * 4);
-        *reinterpret_cast<float4 *>(gx + i * 4) = make_float4(sc * __bfloat162float(v.a), sc * __bfloat162float(v.b), sc * __bfloat162float(v.c),
-                                                              sc * __bfloat162float(v.d));
+        const float4 v = load4(g + i * 4);
+        store4(gx + i * 4, make_float4(sc * v.x, sc * v.y, sc * v.z, sc * v.w));
     }
 }
 
-extern "C" int xq_image_affine_bf16_forward(const float *x, int B, int H, int W, const float *scale3_host, const float *shift3_host, void *out_bf16,
+extern "C" int xq_image_affine_bf16_forward(const void *x, int x_is_bf16, int B, int H, int W, const float *scale3_host, const float *shift3_host, void *out_bf16,
                                             xq_stream_t stream) {
     const char *fn = "xq_image_affine_bf16_forward";
     if (B < 0 || H < 1 || W < 1 || ((long)H * W) % 4) return xq_set_error(XQ_EINVAL, "%s: bad geometry (H * W %% 4)", fn);
@@ -366,12 +390,17 @@ extern "C" int xq_image_affine_bf16_forward(const float *x, int B, int H, int W,
     long blocks = (total4 + 255) / 256;
     const long cap = (long)num_cus() * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(image_affine_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, plane4, scale3_host[0], scale3_host[1],
-                       scale3_host[2], shift3_host[0], shift3_host[1], shift3_host[2], (__hip_bfloat16 *)out_bf16, total4);
+    if (x_is_bf16)
+        hipLaunchKernelGGL((image_affine_fwd_kernel<__hip_bfloat16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)x, plane4,
+                           scale3_host[0], scale3_host[1], scale3_host[2], shift3_host[0], shift3_host[1], shift3_host[2], (__hip_bfloat16 *)out_bf16, total4);
+    else
+        hipLaunchKernelGGL((image_affine_fwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float *)x, plane4,
+                           scale3_host[0], scale3_host[1], scale3_host[2], shift3_host[0], shift3_host[1], shift3_host[2], (__hip_bfloat16 *)out_bf16, total4);
     return xq_check_launch(fn);
 }
 
-extern "C" int xq_image_affine_bf16_backward(const void *g_bf16, int B, int H, int W, const float *scale3_host, float *gx, xq_stream_t stream) {
+extern "C" int xq_image_affine_bf16_backward(const void *g_bf16, int B, int H, int W, const float *scale3_host, void *gx, int gx_is_bf16,
+                                             xq_stream_t stream) {
     const char *fn = "xq_image_affine_bf16_backward";
     if (B < 0 || H < 1 || W < 1 || ((long)H * W) % 4) return xq_set_error(XQ_EINVAL, "%s: bad geometry (H * W %% 4)", fn);
     if (B == 0) return XQ_OK;
@@ -380,7 +409,11 @@ extern "C" int xq_image_affine_bf16_backward(const void *g_bf16, int B, int H, i
     long blocks = (total4 + 255) / 256;
     const long cap = (long)num_cus() * 16;
     if (blocks > cap) blocks = cap;
-    hipLaunchKernelGGL(image_affine_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)g_bf16, plane4, scale3_host[0],
-                       scale3_host[1], scale3_host[2], gx, total4);
+    if (gx_is_bf16)
+        hipLaunchKernelGGL((image_affine_bwd_kernel<__hip_bfloat16>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)g_bf16, plane4,
+                           scale3_host[0], scale3_host[1], scale3_host[2], (__hip_bfloat16 *)gx, total4);
+    else
+        hipLaunchKernelGGL((image_affine_bwd_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const __hip_bfloat16 *)g_bf16, plane4,
+                           scale3_host[0], scale3_host[1], scale3_host[2], (float *)gx, total4);
     return xq_check_launch(fn);
 }

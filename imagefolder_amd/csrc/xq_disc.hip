@@ -13,6 +13,7 @@
 // One block owns (group g) x (CH channels), CH = 64, 32 or 16 — the widest that still gives >= 256 blocks (round 4: at C = 384 and 16
 // virtual batches the fixed 64-channel blocks made a 96-block grid on 256 CUs, each walking its 1568 rows three times: 55 - 75 us per
 // call for 40 - 60 MB); its 8*L x CH slab stays in L2 across the passes.
+#include <stdlib.h>
 #include "xq_common.hpp"
 #include "xq_internal.hpp"
 #include "../../include/xq_ops.h"
@@ -31,7 +32,17 @@ __device__ __forceinline__ void block_colsum(float (&acc)[VEC], float *lds /* [R
 #pragma unroll
     for (int j = 0; j < VEC; ++j) lds[rt * CH + ct * VEC + j] = acc[j];
     __syncthreads();
-    if (threadIdx.x < CH) {
+    if (RPP * TPR > 256) {
+        // wide blocks (round 5): halving tree over the row groups, every thread on its own VEC columns — fixed order, log2(RPP) short steps
+        for (int s = RPP / 2; s > 0; s >>= 1) {
+            if (rt < s) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) lds[rt * CH + ct * VEC + j] += lds[(rt + s) * CH + ct * VEC + j];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < CH) out[threadIdx.x] = lds[threadIdx.x];
+    } else if (threadIdx.x < CH) {
         float s = 0.0f;
         for (int r = 0; r < RPP; ++r) s += lds[r * CH + threadIdx.x];
         out[threadIdx.x] = s;
@@ -39,11 +50,11 @@ __device__ __forceinline__ void block_colsum(float (&acc)[VEC], float *lds /* [R
     __syncthreads();
 }
 
-template <typename T, int CH>
-__global__ __launch_bounds__(256) void bnlocal_lrelu_fwd_kernel(const T *__restrict__ y, const float *__restrict__ w, const float *__restrict__ b,
+template <typename T, int CH, int NT = 256>
+__global__ __launch_bounds__(NT) void bnlocal_lrelu_fwd_kernel(const T *__restrict__ y, const float *__restrict__ w, const float *__restrict__ b,
                                                                 const T *__restrict__ skip, int R, int C, float eps, float slope, float ratio,
                                                                 T *__restrict__ out, float *__restrict__ mean_out, float *__restrict__ rstd_out) {
-    constexpr int VEC = 16 / sizeof(T), TPR = CH / VEC, RPP = 256 / TPR;
+    constexpr int VEC = 16 / sizeof(T), TPR = CH / VEC, RPP = NT / TPR;
     __shared__ float red[RPP * CH];
     __shared__ float stat[2][CH];
     const int g = blockIdx.y, c0 = blockIdx.x * CH;
@@ -128,13 +139,13 @@ __global__ __launch_bounds__(256) void bnlocal_lrelu_fwd_kernel(const T *__restr
     (void)v;
 }
 
-template <typename T, int CH>
-__global__ __launch_bounds__(256) void bnlocal_lrelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ y, const float *__restrict__ w,
+template <typename T, int CH, int NT = 256>
+__global__ __launch_bounds__(NT) void bnlocal_lrelu_bwd_kernel(const T *__restrict__ g_out, const T *__restrict__ y, const float *__restrict__ w,
                                                                 const float *__restrict__ b, const float *__restrict__ mean,
                                                                 const float *__restrict__ rstd, int R, int C, float slope, float ratio,
                                                                 int has_skip, T *__restrict__ g_y, T *__restrict__ g_skip,
                                                                 float *__restrict__ gw_part, float *__restrict__ gb_part) {
-    constexpr int VEC = 16 / sizeof(T), TPR = CH / VEC, RPP = 256 / TPR;
+    constexpr int VEC = 16 / sizeof(T), TPR = CH / VEC, RPP = NT / TPR;
     __shared__ float red[RPP * CH];
     __shared__ float stat[2][CH];
     const int g = blockIdx.y, c0 = blockIdx.x * CH;
@@ -267,6 +278,12 @@ static int bn_block_channels(int C, int G) {
     return 16;
 }
 
+// XQ_BN_WIDE=0: the round-4 grid (16-channel blocks of 256 threads) for A/B timing
+static bool bn_wide() {
+    static const int v = getenv("XQ_BN_WIDE") ? atoi(getenv("XQ_BN_WIDE")) : 1;
+    return v != 0;
+}
+
 static int bn_check(const char *fn, int G, int R, int C) {
     if (G < 0 || R < 1 || C < 1 || C % BN_CH != 0)
         return xq_set_error(XQ_EINVAL, "%s: needs rows_per_group >= 1 and C %% 64 == 0 (got %ld, %ld)", fn, (long)R, (long)C);
@@ -282,6 +299,13 @@ extern "C" int xq_bnlocal_lrelu_forward(const void *y, const float *w, const flo
     if (!y || !out || !mean || !rstd) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     hipStream_t s = (hipStream_t)stream;
     const int ch = bn_block_channels(C, G);
+    if (act_bf16 && ch < 64 && bn_wide()) {
+        // round 5: 64-channel blocks of 1024 threads — the same number of waves as the 16-channel grid, but every row access is a full
+        // 128-byte line (16-channel blocks read 32 bytes of each 768-byte row: half of every fetched line was wasted)
+        hipLaunchKernelGGL((bnlocal_lrelu_fwd_kernel<bf16, 64, 1024>), dim3(C / 64, G), dim3(1024), 0, s, (const bf16 *)y, w, b, (const bf16 *)skip,
+                           rows_per_group, C, eps, slope, ratio, (bf16 *)out, mean, rstd);
+        return xq_check_launch(fn);
+    }
 #define BN_FWD(T_, CH_)                                                                                                                          \
     hipLaunchKernelGGL((bnlocal_lrelu_fwd_kernel<T_, CH_>), dim3(C / CH_, G), dim3(256), 0, s, (const T_ *)y, w, b, (const T_ *)skip, rows_per_group, \
                        C, eps, slope, ratio, (T_ *)out, mean, rstd)
@@ -301,6 +325,11 @@ extern "C" int xq_bnlocal_lrelu_backward(const void *g_out, const void *y, const
         return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     hipStream_t s = (hipStream_t)stream;
     const int ch = bn_block_channels(C, G);
+    if (act_bf16 && ch < 64 && bn_wide()) {
+        hipLaunchKernelGGL((bnlocal_lrelu_bwd_kernel<bf16, 64, 1024>), dim3(C / 64, G), dim3(1024), 0, s, (const bf16 *)g_out, (const bf16 *)y, w, b, mean,
+                           rstd, rows_per_group, C, slope, ratio, has_skip, (bf16 *)g_y, (bf16 *)g_skip, gw_part, gb_part);
+        return xq_check_launch(fn);
+    }
 #define BN_BWD(T_, CH_)                                                                                                                          \
     hipLaunchKernelGGL((bnlocal_lrelu_bwd_kernel<T_, CH_>), dim3(C / CH_, G), dim3(256), 0, s, (const T_ *)g_out, (const T_ *)y, w, b, mean, rstd,   \
                        rows_per_group, C, slope, ratio, has_skip, (T_ *)g_y, (T_ *)g_skip, gw_part, gb_part)

@@ -170,10 +170,8 @@ def patch_embed(x, weight, bias, patch, affine=None):
             sc, sh = affine if affine is not None else ((1.0, 1.0, 1.0), (0.0, 0.0, 0.0))
             cols = ops_dense.DinoPrepPatchFn.apply(x, 0, 0, 0, H, patch, tuple(sc), tuple(sh))
             return linear(cols, _weight_2d(weight), bias).view(B, gh * gw, -1)
-    if affine is not None:
-        sc = torch.tensor(affine[0], dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-        sh = torch.tensor(affine[1], dtype=x.dtype, device=x.device).view(1, 3, 1, 1)
-        x = x * sc + sh
+    if affine is not None:      # (callers pass an affine only where the fused kernel takes it; kept as plain channel-wise ops, no host-built tensors)
+        x = torch.stack([x[:, c] * float(affine[0][c]) + float(affine[1][c]) for c in range(Cin)], dim=1)
     cols = x.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gw, Cin * patch * patch)
     return linear(cols, _weight_2d(weight), bias)
 

@@ -1216,17 +1216,20 @@ class DinoPrepPatchFn(torch.autograd.Function):
 
 
 class ImageAffineBf16Fn(torch.autograd.Function):
-    """bf16(scale_c * x + shift_c) of an fp32 image batch (B, 3, H, W) in one pass (csrc/xq_aug.hip image_affine_*): the LPIPS input scaling
-    + autocast's cast in front of conv1_1 (lpips.py:59-64); backward g_x = scale_c * g."""
+    """bf16(scale_c * x + shift_c) of an fp32 or bf16 image batch (B, 3, H, W) in one pass (csrc/xq_aug.hip image_affine_*): the LPIPS input
+    scaling + autocast's cast in front of conv1_1 (lpips.py:59-64); backward g_x = scale_c * g in the image's dtype."""
 
     @staticmethod
     def forward(ctx, x, scale3, shift3):
         B, _, H, W = x.shape
-        xc = x.detach().float().contiguous()
+        xc = x.detach()
+        if xc.dtype not in (torch.float32, torch.bfloat16):
+            xc = xc.float()
+        xc = xc.contiguous()
         out = torch.empty(B, 3, H, W, dtype=torch.bfloat16, device=x.device)
         sc, sh = (ctypes.c_float * 3)(*scale3), (ctypes.c_float * 3)(*shift3)
         with torch.cuda.device(x.device):
-            rc = _lib.lib().xq_image_affine_bf16_forward(ptr(xc), B, H, W, sc, sh, ptr(out), _stream(xc))
+            rc = _lib.lib().xq_image_affine_bf16_forward(ptr(xc), int(xc.dtype == torch.bfloat16), B, H, W, sc, sh, ptr(out), _stream(xc))
         check(rc, "xq_image_affine_bf16_forward")
         ctx.cfg = (B, H, W, tuple(scale3), x.dtype)
         return out
@@ -1235,18 +1238,19 @@ class ImageAffineBf16Fn(torch.autograd.Function):
     def backward(ctx, g):
         B, H, W, scale3, in_dtype = ctx.cfg
         g = g.detach().to(torch.bfloat16).contiguous()
-        gx = torch.empty(B, 3, H, W, dtype=torch.float32, device=g.device)
+        odt = torch.bfloat16 if in_dtype == torch.bfloat16 else torch.float32
+        gx = torch.empty(B, 3, H, W, dtype=odt, device=g.device)
         sc = (ctypes.c_float * 3)(*scale3)
         with torch.cuda.device(g.device):
-            rc = _lib.lib().xq_image_affine_bf16_backward(ptr(g), B, H, W, sc, ptr(gx), _stream(g))
+            rc = _lib.lib().xq_image_affine_bf16_backward(ptr(g), B, H, W, sc, ptr(gx), int(odt == torch.bfloat16), _stream(g))
         check(rc, "xq_image_affine_bf16_backward")
         return gx.to(in_dtype), None, None
 
 
-def image_prep_supported(x):
+def image_prep_supported(x, ok_dtypes=(torch.float32,)):
     """the fused image-side preparation kernels (ImageAffineBf16Fn, DinoPrepPatchFn) serve the bf16-autocast GPU path"""
     from . import nn_ops
-    return (FUSED_IMAGE_PREP and nn_ops.FUSED_BLOCKS and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.dtype == torch.float32
+    return (FUSED_IMAGE_PREP and nn_ops.FUSED_BLOCKS and x.is_cuda and x.dim() == 4 and x.shape[1] == 3 and x.dtype in ok_dtypes
             and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16 and (x.shape[2] * x.shape[3]) % 4 == 0)
 
 

@@ -158,7 +158,8 @@ class LPIPS(nn.Module):
         """`input` is the data (no gradient), `target` the reconstruction — the order VQLoss calls it in (vq_loss.py:169)."""
         if target.is_cuda and not input.requires_grad:
             from . import ops_dense
-            if ops_dense.image_prep_supported(target) and input.dtype == torch.float32:
+            both = (torch.float32, torch.bfloat16)      # (the reconstruction arrives in the autocast dtype, the data in fp32)
+            if ops_dense.image_prep_supported(target, both) and ops_dense.image_prep_supported(input, both):
                 # (x - shift) / scale and autocast's cast in front of conv1_1 as one pass per image batch (ops_dense.ImageAffineBf16Fn)
                 key = (self.shift._version, self.scale._version, self.scale.data_ptr())
                 if getattr(self, "_affine_consts", (None,))[0] != key:

@@ -368,7 +368,10 @@ class VQModel(nn.Module):
         if self.semantic_guide != 'none':
             with torch.no_grad():
                 from . import ops_dense
-                if ops_dense.image_prep_supported(input):
+                pe = getattr(self.semantic_model, "patch_embed", None)
+                pp = pe.patch_size[0] if pe is not None else 0
+                if (ops_dense.image_prep_supported(input) and pp and pp % 8 == 0 and input.shape[2] == input.shape[3]
+                        and input.shape[2] % pp == 0):
                     # normalize(denormalize(x)) = x * (s1 / s2) + (m1 - m2) / s2 per channel: folded into the teacher's patchify kernel
                     # (four element-wise passes over the image batch + the permute-copy + the cast -> one kernel)
                     dn, nm = self.denormalize, self.normalize

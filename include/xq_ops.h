@@ -323,12 +323,12 @@ int xq_dino_prep_patches_forward(const float *x, int B, int H, int W, int S, int
 int xq_dino_prep_patches_backward(const void *gcols_bf16, int B, int H, int W, int S, int P, int mode, int oi, int oj, const float *scale3_host,
                                   const float *shift3_host, float *gx, xq_stream_t stream);
 
-/* out bf16 [B][3][H][W] = scale_c * x + shift_c of an fp32 image batch (scale3 / shift3: HOST pointers): the input scaling layer of LPIPS
+/* out bf16 [B][3][H][W] = scale_c * x + shift_c of an fp32 or bf16 image batch (scale3 / shift3: HOST pointers): the input scaling layer of LPIPS
  * (lpips.py:59-64: (x - shift) / scale) together with autocast's cast in front of the first VGG convolution, one pass; backward
- * gx fp32 = scale_c * g (g bf16). */
-int xq_image_affine_bf16_forward(const float *x, int B, int H, int W, const float *scale3_host, const float *shift3_host, void *out_bf16,
-                                 xq_stream_t stream);
-int xq_image_affine_bf16_backward(const void *g_bf16, int B, int H, int W, const float *scale3_host, float *gx, xq_stream_t stream);
+ * gx (fp32 or bf16: the image's dtype) = scale_c * g (g bf16). */
+int xq_image_affine_bf16_forward(const void *x, int x_is_bf16, int B, int H, int W, const float *scale3_host, const float *shift3_host,
+                                 void *out_bf16, xq_stream_t stream);
+int xq_image_affine_bf16_backward(const void *g_bf16, int B, int H, int W, const float *scale3_host, void *gx, int gx_is_bf16, xq_stream_t stream);
 
 /* out [D] = sum over the nrows rows of partials [nrows][D] (fp32), fixed order: finishes the fc1 bias gradient from the column partials of
  * xq_gemm_bf16_nn_gelu_bwd */

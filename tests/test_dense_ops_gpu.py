@@ -640,6 +640,14 @@ def test_image_affine_cast_and_fused_patchify_equal_the_op_chains(monkeypatch):
     g = torch.randn(y.shape, device="cuda", generator=gen).to(torch.bfloat16)
     (gx,) = torch.autograd.grad(y, x, g)
     assert (gx - g.float() / scale).abs().max().item() <= 1e-6 * (g.float() / scale).abs().max().item()
+    # a bf16 image (the reconstruction under autocast): same values from the rounded input, gradient back in bf16
+    xb = x.detach().to(torch.bfloat16).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = ops_dense.ImageAffineBf16Fn.apply(xb, sc, sh)
+    refb = (xb.detach().float() - shift) / scale
+    assert (yb.float() - refb).abs().max().item() <= 2.0 ** -7 * refb.abs().max().item()
+    (gxb,) = torch.autograd.grad(yb, xb, g)
+    assert gxb.dtype == torch.bfloat16 and (gxb.float() - g.float() / scale).abs().max().item() <= 2.0 ** -7 * (g.float() / scale).abs().max().item()
     # patch embedding: fused patchify (with and without an input affine) against the op chain
     w = torch.randn(64, 3, 8, 8, device="cuda", generator=gen) * 0.05
     b = torch.randn(64, device="cuda", generator=gen) * 0.1
