@@ -47,8 +47,8 @@ def cases():
     def attn_fb():
         o = od.AttentionFn.apply(qkv, H)
         torch.autograd.grad(o, qkv, go)
-    # forward + backward call: the backward rows alone are attn_delta + attn_bwd_*
-    out.append((f"attention bwd B{B} N{Ntok} H{H} (delta + dK/dV + dQ)", ("attn_delta", "attn_bwd"), 2 * (3 * e + e + e + 3 * e) + 8 * B * H * Ntok, attn_fb))
+    # forward + backward call: the backward rows alone are attn_bwd_*
+    out.append((f"attention bwd B{B} N{Ntok} H{H} (dQ with the delta prologue + dK/dV)", ("attn_bwd",), 2 * (3 * e + e + e + 3 * e) + 8 * B * H * Ntok, attn_fb))
     xs = torch.randn(B, Ntok, D, device=dev, requires_grad=True)
     y = torch.randn(B, Ntok, D, device=dev).to(torch.bfloat16).requires_grad_(True)
     gamma = torch.full((D,), 1e-5, device=dev, requires_grad=True)
