@@ -542,11 +542,11 @@ def main():
         # passes, gfx950 read correction applied: tools/pmc_traffic.py); null when that profile does not cover the kernel
         traffic, shape_ratio, traffic_src = {}, {}, None
         try:
-            tf = os.path.join(ROOT, "profiles", "r04_kernel_hbm_traffic.json")       # PMC passes over THIS round's kernels
+            tf = os.path.join(ROOT, "profiles", "r05_kernel_hbm_traffic.json")       # PMC passes over THIS round's kernels
             with open(tf) as fh:
                 traffic = json.load(fh).get("kernels", {})
             traffic_src = os.path.relpath(tf, ROOT)
-            with open(os.path.join(ROOT, "profiles", "r04_kernel_hbm_traffic_shapes.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r05_kernel_hbm_traffic_shapes.json")) as fh:
                 shape_ratio = {c["case"]: round(c["traffic_over_algorithmic"], 3) for c in json.load(fh).get("cases", [])
                                if "traffic_over_algorithmic" in c}
         except (OSError, ValueError, KeyError):
