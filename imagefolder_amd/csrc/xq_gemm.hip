@@ -21,7 +21,6 @@
 //                        MFMAs per K tile, operand tile pointers in scalar registers.
 // Epilogue: accumulators (+ bias) -> bf16 through a wave-private LDS region -> full-row 16-byte stores; TN: fp32 float4 stores
 // into the split's slab, summed by splitk_reduce_kernel (which also folds the < 64-row remainder of R).
-#include <stdlib.h>
 #include "xq_common.hpp"
 #include "xq_internal.hpp"
 #include "xq_gemm_map.hpp"
@@ -74,7 +73,6 @@ struct GemmArgs {
     const char *H;
     float *colpart;
     int gelu_tanh;
-    int sbias;              // persistent schedule: bias through scalar loads (XQ_GEMM_VBIAS=1 keeps the per-lane loads: A/B timing)
     int nt_store;           // non-temporal bf16 output stores (default; XQ_GEMM_PLAIN_STORE turns them off): the 128 KiB a CU
                             // writes per tile do not displace the operand panels in L2 (qkv forward 839 -> 960 TF/s, others unchanged)
     int debug_no_store;     // XQ_GEMM_DEBUG_NO_STORE: timing experiments only (the result is NOT written)
@@ -795,23 +793,6 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             constexpr bool HAS_BIAS = BK == gm::KMAJOR;
             constexpr bool OUT_MASK = AK == gm::KMAJOR_CONV && ACT == ACT_NONE;   // H = out_mask of a convolution's data gradient
             float4 bv[2][4];
-            if (HAS_BIAS && g.bias && g.sbias && ncol0 + 64 <= g.N) {
-                // round 5: the wave's 64 bias values through SCALAR loads (constant address space, wave-uniform pointer): they wait on lgkmcnt.
-                // The per-lane global loads below made hipcc place an s_waitcnt vmcnt(0) in front of their first use — with the next
-                // item's LDS-DMA pieces in flight that drains the whole staging queue once per item (0 - 4 % on the forward products,
-                // measured in round 3 as "NO BIAS" rows).  Lanes 0-31 / 32-63 take columns 8 q + 0..3 / + 4..7: one select per value.
-                typedef const float __attribute__((address_space(4))) cfloat;
-                const unsigned long long pu = (unsigned long long)(g.bias + ncol0);
-                const unsigned plo = __builtin_amdgcn_readfirstlane((unsigned)pu), phi = __builtin_amdgcn_readfirstlane((unsigned)(pu >> 32));
-                cfloat *bp = (cfloat *)(((unsigned long long)phi << 32) | plo);
-#pragma unroll
-                for (int fj = 0; fj < 2; ++fj)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int o = 32 * fj + 8 * q;
-                        bv[fj][q] = make_float4(h ? bp[o + 4] : bp[o + 0], h ? bp[o + 5] : bp[o + 1], h ? bp[o + 6] : bp[o + 2], h ? bp[o + 7] : bp[o + 3]);
-                    }
-            } else {
 #pragma unroll
             for (int fj = 0; fj < 2; ++fj)
 #pragma unroll
@@ -820,7 +801,6 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
                     if (n > g.N - 4) n = g.N - 4;
                     bv[fj][q] = (HAS_BIAS && g.bias) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-            }
             __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ACT_GELU_BWD: this lane's 8 columns over its 16 rows
@@ -1201,12 +1181,6 @@ void bind_trace(GemmArgs &g, int impl) {
     if ((impl & XQ_GEMM_TRACE_SUMS) && g_trace_buf && g_trace_cap >= 16) { g.trace = g_trace_buf; g.trace_cap = g_trace_cap; g.trace_block = g_trace_block; }
 }
 
-// XQ_GEMM_VBIAS=1: per-lane bias loads in the persistent epilogue (the round-4 form) instead of scalar loads — A/B timing
-int scalar_bias() {
-    static const int v = getenv("XQ_GEMM_VBIAS") ? 0 : 1;
-    return v;
-}
-
 int check_mnk(const char *fn, int64_t M, int64_t N, int64_t K) {
     if (M < 0 || N < 0 || K < 0) return xq_set_error(XQ_EINVAL, "%s: negative size", fn);
     if (K < 64 || K % 64 || N % 8 || N < 32)
@@ -1252,7 +1226,6 @@ extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, 
     GemmArgs g{};
     g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.sbias = scalar_bias();
     bind_trace(g, impl);
     impl &= 0xff;
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)y;
@@ -1271,7 +1244,6 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
-    g.sbias = scalar_bias();
     bind_trace(g, impl);
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
@@ -1335,7 +1307,6 @@ extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *b
     if (N < 256 || K < 128) return xq_set_error(XQ_EINVAL, "%s: needs N >= 256 and K >= 128 (N=%ld K=%ld)", fn, (long)N, (long)K);
     GemmArgs g{};
     g.nt_store = 1;
-    g.sbias = scalar_bias();
     g.A = (const char *)x; g.B = (const char *)w; g.bias = bias; g.C = (char *)h; g.C2 = (char *)h_act; g.gelu_tanh = approximate_tanh;
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
@@ -1354,7 +1325,6 @@ extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const vo
     if (N < 256 || K < 128) return xq_set_error(XQ_EINVAL, "%s: needs N >= 256 and K >= 128 (N=%ld K=%ld)", fn, (long)N, (long)K);
     GemmArgs g{};
     g.nt_store = 1;
-    g.sbias = scalar_bias();
     g.A = (const char *)g_y; g.B = (const char *)w; g.C = (char *)g_h; g.H = (const char *)h; g.colpart = colpart; g.gelu_tanh = approximate_tanh;
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
@@ -1379,7 +1349,6 @@ extern "C" int xq_conv3x3_gemm_bf16(const void *x, const void *w_packed, const f
     impl &= 0xff;
     GemmArgs g{};
     g.nt_store = 1;
-    g.sbias = scalar_bias();
     g.A = (const char *)x; g.B = (const char *)w_packed; g.bias = bias; g.C = (char *)y; g.relu = relu;
     g.H = (const char *)out_mask;
     g.M = M; g.N = Cout; g.lda = K; g.ldb = K; g.ldc = Cout;
@@ -1405,7 +1374,6 @@ extern "C" int xq_gemm_bf16_batched(int op, const void *a, const void *b, int ba
     const int BN = pick_bn(N);
     GemmArgs g{};
     g.nt_store = 1;
-    g.sbias = scalar_bias();
     g.A = (const char *)a; g.B = (const char *)b; g.C = (char *)c;
     g.M = M; g.N = N; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
