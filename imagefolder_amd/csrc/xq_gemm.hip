@@ -867,7 +867,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = keep_where_positive(v[e], hv[it][e]);
                     }
-                    if (ok) {
+                    if (ok && (ACT != ACT_GELU_FWD || g.C != nullptr)) {      // (fused GELU forward without a gradient to come: h is not written)
                         u32x4 *p1 = reinterpret_cast<u32x4 *>(C + gr * g.ldc + gc);
                         if (g.nt_store) __builtin_nontemporal_store(o, p1); else *p1 = o;
                     }
@@ -958,7 +958,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
         }
         uint4 pk;
         pk.x = pack_bf16(v[0], v[1]); pk.y = pack_bf16(v[2], v[3]); pk.z = pack_bf16(v[4], v[5]); pk.w = pack_bf16(v[6], v[7]);
-        *reinterpret_cast<uint4 *>(out16 + gr * ldc + gc) = pk;
+        if (out16) *reinterpret_cast<uint4 *>(out16 + gr * ldc + gc) = pk;
         if (out16_act) {      // ACT_GELU_FWD tail tiles: the activation of the bf16-ROUNDED pre-activation, as the whole-tile epilogue does
             const unsigned u[4] = {pk.x, pk.y, pk.z, pk.w};
             unsigned a[4];
@@ -1303,7 +1303,7 @@ extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *b
     const char *fn = "xq_gemm_bf16_nt_gelu";
     if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
-    if (!x || !w || !h || !h_act) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (!x || !w || !h_act) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);      // h may be null: inference, the pre-activation is not kept
     if (N < 256 || K < 128) return xq_set_error(XQ_EINVAL, "%s: needs N >= 256 and K >= 128 (N=%ld K=%ld)", fn, (long)N, (long)K);
     GemmArgs g{};
     g.nt_store = 1;

@@ -438,6 +438,14 @@ class MlpFn(torch.autograd.Function):
     (xq_gemm_bf16_nn_gelu_bwd); weight gradients split-K TN; g_a = g_h W1.  The fc2 bias gradient is delivered by the fused
     residual + LayerNorm backward that produces g_f (same arrangement as LinearFn(bias_grad_external=True))."""
 
+    # grad mode of the CALLER (see LinearFn): a forward no backward follows does not keep — and the kernel does not write — the pre-activation h
+    _caller_grad = True
+
+    @classmethod
+    def apply(cls, *args, **kwargs):
+        MlpFn._caller_grad = torch.is_grad_enabled()
+        return super(MlpFn, cls).apply(*args, **kwargs)
+
     @staticmethod
     def forward(ctx, a, w1, b1, w2, b2, tanh):
         shp = a.shape
@@ -447,15 +455,17 @@ class MlpFn(torch.autograd.Function):
         W1, W2 = _w16(w1), _w16(w2)
         M, D = a2.shape
         Hd = W1.shape[0]
-        h = torch.empty(M, Hd, dtype=torch.bfloat16, device=a2.device)
-        hg = torch.empty_like(h)
+        inference = not MlpFn._caller_grad or not any(ctx.needs_input_grad)
+        hg = torch.empty(M, Hd, dtype=torch.bfloat16, device=a2.device)
+        h = None if inference else torch.empty_like(hg)
         ws, nbytes = _gemm_ws(0, M, Hd, D, a2.device)
         with torch.cuda.device(a2.device):
             rc = _lib.lib().xq_gemm_bf16_nt_gelu(ptr(a2), ptr(W1), ptr(b1.detach().float().contiguous()), M, Hd, D, ptr(h), ptr(hg), int(bool(tanh)),
                                                  ptr(ws), nbytes, _stream(a2))
         check(rc, "xq_gemm_bf16_nt_gelu")
         f = gemm_nt(hg, W2, None if b2 is None else b2.detach().float().contiguous())
-        ctx.save_for_backward(a2, W1, W2, h, hg)
+        if not inference:
+            ctx.save_for_backward(a2, W1, W2, h, hg)
         ctx.meta = (shp, bool(tanh), w1.dtype)
         return f.view(*shp[:-1], W2.shape[0])
 

@@ -500,7 +500,8 @@ int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_t N, int64_
  * unfused Linear -> GELU pair does; approximate_tanh selects F.gelu(approximate='tanh').  N >= 256, K >= 128, K % 64 == 0.
  * workspace: xq_gemm_bf16_workspace_bytes(XQ_GEMM_OP_NT, M, N, K) bytes (the tiles beyond the last full round of CUs are cut along K
  * into fp32 slabs whose sum gets the same bias + activation; without a workspace every tile runs whole: same values up to the fp32
- * summation order, a partial last round). */
+ * summation order, a partial last round).  h may be NULL (round 5): a forward that no backward follows (frozen teacher, the discriminator
+ * update's pass over the frozen DINO-S trunk) does not write the pre-activation — half the output bytes of this store-bound product. */
 int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *h, void *h_act,
                          int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 /* data gradient of fc2 with the GELU derivative in the epilogue: g_h[M][N] = (g_y[M][K] . w[K][N]) * GELU'(h[M][N]) (the product

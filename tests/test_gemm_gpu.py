@@ -293,6 +293,11 @@ def test_fused_mlp_equals_the_unfused_functions(B, N, D, Hd, tanh):
         return [f.detach().float(), a.grad.float(), w1.grad.float(), b1.grad.float(), w2.grad.float()]
     fu, un = run(True), run(False)
     assert torch.equal(fu[0], un[0]), "forward differs"
+    # without a gradient to come the fused forward does not write the pre-activation (h = NULL in xq_gemm_bf16_nt_gelu): same output, whole
+    # tiles and K-split tail tiles alike
+    with torch.no_grad():
+        f_inf = od.MlpFn.apply(a, w1, b1, w2, b2, tanh)
+    assert torch.equal(f_inf.float(), fu[0]), "inference forward (h not written) differs"
     assert torch.equal(fu[1], un[1]), "g_a differs"
     for x, y, name in zip(fu[2:], un[2:], ("g_w1", "g_b1", "g_w2")):
         scale = y.abs().max().item()
