@@ -510,6 +510,10 @@ def main():
                 "op_impl": dict(nn_ops.IMPL, quantizer="hip", latent_perturbation="hip", adamw_ema="hip",
                                 grad_allreduce="rccl" if world > 1 or os.environ.get("XQ_FORCE_DIST") else "not run (single process)"),
                 "loss": args.loss,
+                "parity_of_the_timed_kernels": ("the timed step runs the bf16 kernels (as the reference trains under bf16 autocast): bounded, tensor by tensor, by "
+                                                "1.5x the reference's OWN bf16-autocast error against its fp32 gradients / outputs (tests/test_train_backward_parity.py, "
+                                                "test_model_parity.py); 'indices bit-exact, pixels <= 1e-4' is met by the fp32 path of csrc/xq_f32.hip + the quantizer "
+                                                "kernels (the same quantizer kernels as timed here)"),
                 "hip_graph": graph_note,
                 "hip_graph_eager_ms_per_step": eager_ms,
                 "eager_ms_per_step_without_roofline_events": plain_ms,

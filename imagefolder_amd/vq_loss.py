@@ -390,8 +390,18 @@ class FrozenDINOSmallNoDrop(nn.Module):
             x = nn_ops.linear(cols, nn_ops._weight_2d(self.patch_embed.proj.weight), self.patch_embed.proj.bias).view(cols.shape[0] // n_tok, n_tok, -1)
         else:
             x = nn_ops.patch_embed(x, self.patch_embed.proj.weight, self.patch_embed.proj.bias, self.patch_size)  # conv as GEMM
-        with torch.autocast(device_type=x.device.type, enabled=False):
-            x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x.float()), dim=1) + self.pos_embed
+        from . import ops_dense as _od
+        if x.dim() == 3 and _od.token_assemble_supported(x, x.shape[-1]):
+            # [cls | patches] + position table in one kernel (ops_dense.TokenAssembleFn); the table of the frozen trunk is a constant
+            key = (self.cls_token._version, self.pos_embed._version, self.pos_embed.data_ptr())
+            if getattr(self, "_xq_token_table", (None,))[0] != key:
+                with torch.no_grad(), torch.autocast(device_type=x.device.type, enabled=False):
+                    tbl = torch.cat((self.cls_token, torch.zeros(1, x.shape[1], x.shape[2], device=x.device)), dim=1) + self.pos_embed
+                self._xq_token_table = (key, tbl)
+            x = _od.TokenAssembleFn.apply(x, self._xq_token_table[1], 1, False)
+        else:
+            with torch.autocast(device_type=x.device.type, enabled=False):
+                x = torch.cat((self.cls_token.expand(x.shape[0], -1, -1), x.float()), dim=1) + self.pos_embed
         if x.is_cuda and nn_ops.FUSED_BLOCKS:
             from . import ops_dense
             blocks = list(self.blocks)
