@@ -139,14 +139,14 @@ def _free_port():
     return p
 
 
-def _dp_worker(rank, world, port, out, comm_dtype=None):
+def _dp_worker(rank, world, port, out, comm_dtype=None, max_grad_norm=0.0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from imagefolder_amd.train import TokenizerTrainStep
     m = Tiny()
     ts = TokenizerTrainStep(m, _loss, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9, amp_dtype=None, chunk_bytes=64,
-                            comm_dtype=comm_dtype)
+                            comm_dtype=comm_dtype, max_grad_norm=max_grad_norm)
     assert len(ts.reducer.chunks) > 1  # exercises the chunked path
     hook = []
     ts.disc_step_fn = lambda imgs, rec: hook.append(rec.shape)  # runs between start() and wait()
@@ -173,6 +173,24 @@ def test_data_parallel_two_ranks_equals_single_process_on_the_global_batch(tmp_p
     data = torch.randn(3, world * 4, 5, generator=g)
     for it in range(3):
         ts.step(data[it])
+    for k, v in m.state_dict().items():
+        assert torch.allclose(v, dp[k], atol=1e-6, rtol=1e-5), k
+
+
+def test_data_parallel_gradient_clipping_clips_the_averaged_gradient(tmp_path):
+    """max_grad_norm under data parallelism: the norm is taken of the all-reduced gradient times 1 / world (DDP averages before the trainer's
+    clip_grad_norm_, xqgan_train.py:455-458), so two ranks x 4 samples clip exactly like one process x 8"""
+    world, port, out = 2, _free_port(), str(tmp_path / "dpclip.pt")
+    mp.spawn(_dp_worker, args=(world, port, out, None, 0.02), nprocs=world, join=True)
+    dp = torch.load(out)
+    from imagefolder_amd.train import TokenizerTrainStep
+    m = Tiny()
+    ts = TokenizerTrainStep(m, _loss, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9, amp_dtype=None, max_grad_norm=0.02)
+    g = torch.Generator().manual_seed(100)
+    data = torch.randn(3, world * 4, 5, generator=g)
+    for it in range(3):
+        ts.step(data[it])
+        assert float(ts.opt.last_grad_norm) > 0.02          # the clip is active on every step of this run
     for k, v in m.state_dict().items():
         assert torch.allclose(v, dp[k], atol=1e-6, rtol=1e-5), k
 
