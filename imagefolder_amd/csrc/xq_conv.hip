@@ -401,18 +401,32 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
 // Block = one tap x 128 n x 128 c over a contiguous range of 64-pixel tiles; 2 x 2 waves of 64 x 64; the partial tile is
 // added to dWp with fp32 atomics (dWp zero-initialised by the caller).  The shifted X rows use the forward's halo logic.
 // ---------------------------------------------------------------------------------------------------------------------
+static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ wg_s4 wg_tr4(const short *p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((wg_s4 __attribute__((address_space(3))) *)p);
 }
-static constexpr int WG_PITCH = 136;   // 128 channels + 8: LDS row pitch in bf16 elements (272 bytes)
+// WG_PITCH (template parameter): LDS row pitch in bf16 elements.  A 16-lane group of ds_read_b64_tr_b16 reads 4 rows x 32 bytes: the rows'
+// segments fall into disjoint banks when the pitch is 32 bytes mod 256 (144 elements = 288 bytes); round 2's 136 (272 bytes = 16 mod 256)
+// made neighbouring rows overlap by half — 2-way conflicts on every fragment read.  XQ_WGRAD_PITCH=136 keeps the old pitch for A/B timing.
 #define WG_TFRAG(TRP, ROW0, COL0) __builtin_shufflevector(wg_tr4((TRP) + (ROW0) * WG_PITCH + (COL0)), wg_tr4((TRP) + ((ROW0) + 8) * WG_PITCH + (COL0)), 0, 1, 2, 3, 4, 5, 6, 7)
 
 // Geometry: dY pixel (b, y, x) of an H x Wd map pairs with X pixel ((y * stride + ky - pad) >> up, (x * stride + kx - pad) >> up) of an
 // Hi x Wi map (stride 2 / pad 0: Downsample; up = 1: the conv ran on the nearest-2x upsampled X; default stride 1 / pad 1 / Hi = H).
+// MODE 0: any map size — pixel -> (b, y, x) by two 32-bit divisions per staged row, 8 per thread and K tile: ~280 VALU instructions in the
+//         load block against the tile's 16 MFMAs per wave (the kernel is VALU-bound in this form).
+// MODE 1: H and Wd powers of two: shifts and masks (~150 VALU instructions).
+// MODE 2: additionally Wd >= 16, M % 64 == 0 and both tensors below 4 GiB (every map of the 256 x 256 CNN tokenizer).  The 16 rows a
+//         thread group stages per step (srow = 0..15 at one `I`) lie in ONE image row, so batch index, y, the row's validity and the row base
+//         are wave-uniform (scalar ALU); per lane only x's validity and a 32-bit byte offset remain, and out-of-image taps become buffer
+//         loads past the descriptor's range (they return zero): ~25 VALU instructions per K tile.
+typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
+template <int MODE, int WG_PITCH>
 __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16 *__restrict__ X, const __hip_bfloat16 *__restrict__ dY, long M,
                                                             int H, int Wd, int Cin, int Cout, int tiles_per_split, int nsplit,
-                                                            float *__restrict__ dWp, int Hi, int Wi, int stride, int pad, int up) {
+                                                            float *__restrict__ dWp, int Hi, int Wi, int stride, int pad, int up,
+                                                            unsigned x_bytes, unsigned y_bytes) {
+    constexpr bool POW2 = MODE >= 1;
     __shared__ __attribute__((aligned(16))) short lds[2][2 * 64 * WG_PITCH];   // [buffer][dY tile | X tile], 64 pixels each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
@@ -439,6 +453,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
     // staging: thread -> rows (tid/16) + 16*i (i = 0..3) of the 64-pixel tile, 16-byte chunk tid%16 of the 128 channels
     const int srow = tid >> 4, spart = (tid & 15) * 8;
     const int HWi = H * Wd;
+    const int lw = 31 - __builtin_clz((unsigned)Wd), lhw = 31 - __builtin_clz((unsigned)HWi);     // (POW2 only)
     uint4 ry0, ry1, ry2, ry3, rx0, rx1, rx2, rx3;
     const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
 #define WG_LOAD_ROW(RY, RX, I, TILE)                                                                                   \
@@ -448,15 +463,46 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
         const long mm = okm ? m_ : 0;                                                                                  \
         RY = *reinterpret_cast<const uint4 *>(dY + mm * Cout + n0 + spart);                                            \
         if (!okm) RY = zero4;                                                                                          \
-        const int b_ = (int)mm / HWi;             /* M < 2^31 (checked by the launcher): 32-bit divisions */          \
-        const int rem_ = (int)mm - b_ * HWi;                                                                           \
-        const int y_ = rem_ / Wd, x_ = rem_ - y_ * Wd;                                                                 \
+        int b_, y_, x_;                           /* M < 2^31 (checked by the launcher): 32-bit arithmetic */         \
+        if (POW2) {                                                                                                    \
+            b_ = (int)mm >> lhw; y_ = ((int)mm >> lw) & (H - 1); x_ = (int)mm & (Wd - 1);                              \
+        } else {                                                                                                       \
+            b_ = (int)mm / HWi;                                                                                        \
+            const int rem_ = (int)mm - b_ * HWi;                                                                       \
+            y_ = rem_ / Wd; x_ = rem_ - y_ * Wd;                                                                       \
+        }                                                                                                              \
         const int yy = y_ * stride + dy, xx = x_ * stride + dx;                                                        \
         const bool ok = okm && yy >= 0 && yy < Hl && xx >= 0 && xx < Wl;                                               \
         RX = *reinterpret_cast<const uint4 *>(X + (((long)b_ * HWin + (ok ? (yy >> up) * Wi + (xx >> up) : 0)) * Cin + c0 + spart)); \
         if (!ok) RX = zero4;                                                                                           \
     }
-#define WG_LOAD(TILE) { WG_LOAD_ROW(ry0, rx0, 0, TILE) WG_LOAD_ROW(ry1, rx1, 1, TILE) WG_LOAD_ROW(ry2, rx2, 2, TILE) WG_LOAD_ROW(ry3, rx3, 3, TILE) }
+    // MODE 2 (see above): descriptors over the whole tensors, per-lane constants of the offsets
+    const auto rs_x = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, MODE == 2 ? x_bytes : 0u, 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc((void *)dY, 0, MODE == 2 ? y_bytes : 0u, 0x00020000);
+    const unsigned lane_y = (unsigned)(srow * Cout + spart) * 2u, lane_c = (unsigned)spart * 2u, cin2 = (unsigned)Cin * 2u;
+    const int lane_xs = srow * stride;
+#define WG_LOAD_ROW_FAST(RY, RX, I, TILE)                                                                              \
+    {                                                                                                                  \
+        const int m0_ = (int)(TILE) * 64 + 16 * (I);                  /* wave-uniform: first pixel of this 16-row group */ \
+        const int b_ = m0_ >> lhw, y_ = (m0_ >> lw) & (H - 1), x0_ = m0_ & (Wd - 1);                                   \
+        const int yy = y_ * stride + dy;                                                                               \
+        const bool rowok = (unsigned)yy < (unsigned)Hl;                                                                \
+        const unsigned sbase = ((unsigned)((b_ * Hi + (yy >> up)) * Wi) * (unsigned)Cin + (unsigned)c0) * 2u;          \
+        const int xx = x0_ * stride + dx + lane_xs;                                                                    \
+        unsigned vo = sbase + (unsigned)(xx >> up) * cin2 + lane_c;                                                    \
+        vo = (rowok && (unsigned)xx < (unsigned)Wl) ? vo : 0xffffffffu;                                                \
+        RX = __builtin_bit_cast(uint4, (wg_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_x, vo, 0, 0));               \
+        RY = __builtin_bit_cast(uint4, (wg_u32x4)__builtin_amdgcn_raw_buffer_load_b128(rs_y, ((unsigned)m0_ * (unsigned)Cout + (unsigned)n0) * 2u + lane_y, 0, 0)); \
+    }
+#define WG_LOAD(TILE)                                                                                                  \
+    {                                                                                                                  \
+        if (MODE == 2) {                                                                                               \
+            WG_LOAD_ROW_FAST(ry0, rx0, 0, TILE) WG_LOAD_ROW_FAST(ry1, rx1, 1, TILE)                                    \
+            WG_LOAD_ROW_FAST(ry2, rx2, 2, TILE) WG_LOAD_ROW_FAST(ry3, rx3, 3, TILE)                                    \
+        } else {                                                                                                       \
+            WG_LOAD_ROW(ry0, rx0, 0, TILE) WG_LOAD_ROW(ry1, rx1, 1, TILE) WG_LOAD_ROW(ry2, rx2, 2, TILE) WG_LOAD_ROW(ry3, rx3, 3, TILE) \
+        }                                                                                                              \
+    }
 #define WG_STORE(BUF)                                                                                                  \
     {                                                                                                                  \
         short *Yt = lds[BUF] + srow * WG_PITCH + spart, *Xt = Yt + 64 * WG_PITCH;                                      \
@@ -500,6 +546,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
         __syncthreads();
     }
 #undef WG_LOAD_ROW
+#undef WG_LOAD_ROW_FAST
 #undef WG_LOAD
 #undef WG_STORE
 
@@ -516,6 +563,29 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
                 atomicAdd(dWp + (long)n * K9 + (long)tap * Cin + c, acc[i][j][r]);
             }
         }
+}
+
+// picks the kernel form (MODE, above) from the geometry
+static void launch_conv3x3_wgrad(const void *X, const void *dY, int B, int Hi, int Wi, int Ho, int Wo, int Cin, int Cout, int stride, int pad,
+                                 int up, long T, int tps, int nsplit, float *dWp, hipStream_t s) {
+    const long M = (long)B * Ho * Wo;
+    const long xb = (long)B * Hi * Wi * Cin * 2, yb = M * Cout * 2;
+    const dim3 grid((unsigned)(((T + 7) / 8) * 8));
+    const bool p2 = is_pow2(Ho) && is_pow2(Wo);
+    static const bool old_pitch = getenv("XQ_WGRAD_PITCH") && atoi(getenv("XQ_WGRAD_PITCH")) == 136;
+#define WG_GO(MODE_)                                                                                                                \
+    do {                                                                                                                            \
+        if (old_pitch)                                                                                                              \
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<MODE_, 136>), grid, dim3(256), 0, s, (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, \
+                               Ho, Wo, Cin, Cout, tps, nsplit, dWp, Hi, Wi, stride, pad, up, (unsigned)xb, (unsigned)yb);           \
+        else                                                                                                                        \
+            hipLaunchKernelGGL((conv3x3_wgrad_kernel<MODE_, 144>), grid, dim3(256), 0, s, (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, \
+                               Ho, Wo, Cin, Cout, tps, nsplit, dWp, Hi, Wi, stride, pad, up, (unsigned)xb, (unsigned)yb);           \
+    } while (0)
+    if (p2 && Wo >= 16 && M % 64 == 0 && xb < 0xffffff00L && yb < 0xffffff00L && !getenv("XQ_WGRAD_SLOW_INDEX")) WG_GO(2);
+    else if (p2) WG_GO(1);
+    else WG_GO(0);
+#undef WG_GO
 }
 
 extern "C" int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, int H, int W, int Cin, int Cout, float *dWp,
@@ -535,8 +605,7 @@ extern "C" int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, 
     const long tps = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + tps - 1) / tps;
     const long T = nsplit * base;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(((T + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, H, W, Cin, Cout, (int)tps, (int)nsplit, dWp, H, W, 1, 1, 0);
+    launch_conv3x3_wgrad(X, dY, B, H, W, H, W, Cin, Cout, 1, 1, 0, T, (int)tps, (int)nsplit, dWp, (hipStream_t)stream);
     return xq_check_launch(fn);
 }
 
@@ -558,9 +627,7 @@ extern "C" int xq_conv3x3_wgrad_nhwc_bf16_ex(const void *X, const void *dY, int 
     const long tps = (ntiles + nsplit - 1) / nsplit;
     nsplit = (ntiles + tps - 1) / tps;
     const long T = nsplit * base;
-    hipLaunchKernelGGL(conv3x3_wgrad_kernel, dim3((unsigned)(((T + 7) / 8) * 8)), dim3(256), 0, (hipStream_t)stream,
-                       (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, Ho, Wo, Cin, Cout, (int)tps, (int)nsplit, dWp, Hi, Wi, stride, pad,
-                       upsample2x ? 1 : 0);
+    launch_conv3x3_wgrad(X, dY, B, Hi, Wi, Ho, Wo, Cin, Cout, stride, pad, upsample2x ? 1 : 0, T, (int)tps, (int)nsplit, dWp, (hipStream_t)stream);
     return xq_check_launch(fn);
 }
 

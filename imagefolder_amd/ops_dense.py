@@ -1028,9 +1028,13 @@ def conv3x3_to3_supported(x, weight, stride, padding):
             and weight.shape[1] % 128 == 0 and x.shape[3] % 2 == 0)
 
 
+TO3_WGRAD_GEMM = _os.environ.get("XQ_TO3_WGRAD", "gemm") == "gemm"     # "kernel": conv3x3_to3_wgrad_kernel (rounds 2-4)
+
+
 class Conv3x3ToRgbFn(torch.autograd.Function):
     """y (B, 3, H, W) = conv3x3(x, W) + b for a 3-channel output: forward on conv3x3_to3_kernel, data gradient on conv3x3_from3_mfma_kernel with
-    the rotated weights, weight gradient on conv3x3_to3_wgrad_kernel (per-block partials, summed in a fixed order)."""
+    the rotated weights, weight gradient = im2col27 of the output gradient + the split-K TN GEMM (TO3_WGRAD_GEMM; else conv3x3_to3_wgrad_kernel:
+    per-block partials, summed in a fixed order)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -1056,7 +1060,19 @@ class Conv3x3ToRgbFn(torch.autograd.Function):
                 g_x = _from3(gp, w_kc, None, C).to(ctx.in_dtype)
             else:
                 raise XqError(f"conv_out data gradient: {C} input channels (kernel instantiated for 64 / 128)")
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and TO3_WGRAD_GEMM:
+            # dW[co][tap][c] = sum_q g[co](q - (tap - centre)) X[q][c]: the 27 shifted copies of g are im2col27's columns with the tap
+            # index mirrored (tap' = 8 - tap), so the gradient is ONE product X^T [C][pixels] . cols [pixels][32] on the split-K TN GEMM —
+            # the mirror image of conv_in's weight gradient above.  X streams through once (B = 32, 256 x 256, C = 128: ~0.25 ms against
+            # 1.14 ms of conv3x3_to3_wgrad_kernel's per-thread pixel walk, profiles/r05_cnn_b32_kernel_stats.txt); g is rounded to bf16
+            # in the columns, as the reference's bf16 conv_out receives it.
+            cols = torch.empty(B * H * W, 32, dtype=torch.bfloat16, device=x_cl.device)
+            with torch.cuda.device(x_cl.device):
+                rc = _lib.lib().xq_im2col27(ptr(gp), int(gp.dtype == torch.bfloat16), B, H, W, ptr(cols), _stream(x_cl))
+            check(rc, "xq_im2col27")
+            d32 = gemm_tn(x_cl.permute(0, 2, 3, 1).reshape(B * H * W, C), cols)                 # [C][(8 - tap) * 3 + co]
+            g_w = d32[:, :27].reshape(C, 9, 3).flip(1).reshape(C, 3, 3, 3).permute(3, 0, 1, 2).to(weight.dtype)   # -> [co][ci][ky][kx]
+        elif ctx.needs_input_grad[1]:
             nb = _lib.lib().xq_conv3x3_to3_wgrad_blocks(B, H)
             part = torch.empty(nb, 3, 9, C, dtype=torch.float32, device=x_cl.device)
             with torch.cuda.device(x_cl.device):

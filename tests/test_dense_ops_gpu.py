@@ -433,9 +433,12 @@ def test_maxpool2x2_nhwc_matches_aten():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 12, 12), (1, 256, 128, 7, 9), (3, 128, 256, 16, 8)])
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 128, 128, 12, 12), (1, 256, 128, 7, 9), (3, 128, 256, 16, 8),
+                                            (2, 128, 128, 32, 16), (3, 256, 128, 16, 64), (1, 128, 128, 64, 64), (5, 128, 128, 16, 16)])
 def test_conv3x3_weight_grad_kernel(B, Cin, Cout, H, W):
-    """the transpose-read MFMA weight-gradient kernel vs fp32 autograd on the same bf16-rounded operands"""
+    """the transpose-read MFMA weight-gradient kernel vs fp32 autograd on the same bf16-rounded operands; the three index forms of the
+    kernel (csrc/xq_conv.hip MODE 0: any map, 1: power-of-two maps, 2: power-of-two maps at least 16 wide with scalar row arithmetic and
+    range-checked buffer loads) are all in the list"""
     from imagefolder_amd import ops_dense
     torch.manual_seed(B * 100 + Cin)
     dev = "cuda"
