@@ -4,7 +4,8 @@
 // CNN encoder/decoder (tokenizer/tokenizer_image/xqgan_model.py:625-640 ResnetBlock norm1/norm2, :643-672 AttnBlock.norm,
 // :520-521 / :581-582 norm_out), which under bf16 autocast run as an fp32 group_norm (the input is cast up) followed by
 // fp32 sigmoid and mul kernels on NCHW / strided tensors.  Here: x [B][HW][C] bf16 (channels-last, the layout of the conv
-// kernels), statistics in fp32 (two-pass: mean, then centred sum of squares), y = silu((x - mean) * rstd * w + b) -> bf16.
+// kernels), statistics from ONE pass over x (round 5: per-channel sums of x - K_c and (x - K_c)^2, K_c = the sample's first pixel, folded to mean / rstd in fp64;
+// XQ_GN_TWO_PASS=1: mean, then the centred sum of squares, rounds 2-4), y = silu((x - mean) * rstd * w + b) -> bf16.
 //
 //   gn_reduce_kernel<MODE> : per (sample, pixel slab): per-channel partial sums over the slab's pixels, folded to the
 //                            32 groups -> partial[b][slab][G][2]  (MODE 0: sum x | 1: sum (x - mean)^2 |
@@ -18,6 +19,7 @@
 #include "../../include/xq_ops.h"
 
 #include "xq_vec.hpp"
+#include <cstdlib>
 
 using namespace xq;
 
@@ -33,6 +35,9 @@ __device__ __forceinline__ float gn_silu_grad(float pre) {
 // MODE 0: a = sum x                      (b unused)
 // MODE 1: a = sum (x - mean)^2
 // MODE 2: a = sum d_pre (per channel), b = sum d_pre * xhat (per channel); group partials s1 = sum_c w_c a_c, s2 = sum_c w_c b_c
+// MODE 3 (round 5, the forward's statistics in ONE pass over x): a = sum (x - K_c), b = sum (x - K_c)^2 per channel, shifted by the channel's
+//         value at the sample's first pixel (K_c = x[b][0][c], exact in fp32) so that neither sum carries the mean's magnitude; per-channel
+//         slab sums only (part_c) — gn_finalize_onepass_kernel folds them to mean / rstd in fp64
 template <int MODE>
 __global__ __launch_bounds__(256) void gn_reduce_kernel(const bf16 *__restrict__ x, const bf16 *__restrict__ dy, const float *__restrict__ w,
                                                         const float *__restrict__ bias, const float *__restrict__ mean,
@@ -53,13 +58,14 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const bf16 *__restrict__
         a[j] = 0.0f;
         bq[j] = 0.0f;
         const int c = cidx * 8 + j, g = c / cg;
-        mu[j] = MODE >= 1 ? mean[b * G + g] : 0.0f;
+        mu[j] = (MODE == 1 || MODE == 2) ? mean[b * G + g] : 0.0f;
         rs[j] = MODE == 2 ? rstd[b * G + g] : 1.0f;
         ww[j] = (MODE == 2 && w) ? w[c] : 1.0f;
         bb[j] = (MODE == 2 && bias) ? bias[c] : 0.0f;
     }
     const bf16 *xb = x + ((long)b * HW) * C + cidx * 8;
     const bf16 *db = MODE == 2 ? dy + ((long)b * HW) * C + cidx * 8 : nullptr;
+    if (MODE == 3) gn_load8(xb, mu);      // the shift K_c (pixel 0 of this sample)
     for (int p = p0 + pl; p < p1; p += PL) {
         float v[8];
         gn_load8(xb + (long)p * C, v);
@@ -69,6 +75,9 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const bf16 *__restrict__
         } else if (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float d = v[j] - mu[j]; a[j] = fmaf(d, d, a[j]); }
+        } else if (MODE == 3) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = v[j] - mu[j]; a[j] += d; bq[j] = fmaf(d, d, bq[j]); }
         } else {
             float g8[8];
             gn_load8(db + (long)p * C, g8);
@@ -84,7 +93,7 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const bf16 *__restrict__
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         red[0][threadIdx.x * 8 + j] = a[j];
-        if (MODE == 2) red[1][threadIdx.x * 8 + j] = bq[j];
+        if (MODE >= 2) red[1][threadIdx.x * 8 + j] = bq[j];
     }
     __syncthreads();
     // per-channel sums over the pixel lanes, fixed order
@@ -93,15 +102,16 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(const bf16 *__restrict__
         float sa = 0.0f, sb = 0.0f;
         for (int l = 0; l < PL; ++l) {
             sa += red[0][(l * cv + ci) * 8 + j];
-            if (MODE == 2) sb += red[1][(l * cv + ci) * 8 + j];
+            if (MODE >= 2) sb += red[1][(l * cv + ci) * 8 + j];
         }
         chan[0][c] = sa;
-        if (MODE == 2) {
+        if (MODE >= 2) {
             chan[1][c] = sb;
             part_c[(((long)b * nslab + slab) * 2 + 0) * C + c] = sa;
             part_c[(((long)b * nslab + slab) * 2 + 1) * C + c] = sb;
         }
     }
+    if (MODE == 3) return;      // (block-uniform) no group partials: the finalize kernel folds the per-channel sums
     __syncthreads();
     if (threadIdx.x < G) {
         const int g = threadIdx.x;
@@ -129,6 +139,38 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
     if (what == 0) out0[b * G + g] = s1 / n;
     else if (what == 1) out0[b * G + g] = 1.0f / sqrtf(s1 / n + eps);
     else { out0[b * G + g] = s1 / n; out1[b * G + g] = s2 / n; }
+}
+
+// one-pass statistics (gn_reduce_kernel<3>): S1_c = sum (x - K_c), S2_c = sum (x - K_c)^2 over the sample's HW pixels, fixed-order sums over the
+// slabs; mean = sum_c (S1_c + HW K_c) / n;  sum (x - mean)^2 = sum_c [S2_c - 2 (mean - K_c) S1_c + HW (mean - K_c)^2]   (fp64: B x G threads)
+__global__ __launch_bounds__(64) void gn_finalize_onepass_kernel(const float *__restrict__ part_c, const bf16 *__restrict__ x, int nslab, int HW, int C,
+                                                                 int G, float eps, float *__restrict__ mean, float *__restrict__ rstd) {
+    const int b = blockIdx.x, g = threadIdx.x;
+    if (g >= G) return;
+    const int cg = C / G;
+    const double n = (double)HW * cg;
+    double tot = 0.0;
+    double s1[32], s2[32], kc[32];          // cg <= 32 (checked by the launcher)
+    for (int i = 0; i < cg; ++i) {
+        const int c = g * cg + i;
+        double a = 0.0, q = 0.0;
+        for (int s = 0; s < nslab; ++s) {
+            a += (double)part_c[(((long)b * nslab + s) * 2 + 0) * C + c];
+            q += (double)part_c[(((long)b * nslab + s) * 2 + 1) * C + c];
+        }
+        s1[i] = a; s2[i] = q;
+        kc[i] = (double)__bfloat162float(x[((long)b * HW) * C + c]);
+        tot += a + (double)HW * kc[i];
+    }
+    const double mu = tot / n;
+    double m2 = 0.0;
+    for (int i = 0; i < cg; ++i) {
+        const double d = mu - kc[i];
+        m2 += s2[i] - 2.0 * d * s1[i] + (double)HW * d * d;
+    }
+    if (m2 < 0.0) m2 = 0.0;
+    mean[b * G + g] = (float)mu;
+    rstd[b * G + g] = (float)(1.0 / sqrt(m2 / n + (double)eps));
 }
 
 // element-wise passes: block (slab, sample); a thread keeps its 8 channels for the whole slab (as in gn_reduce_kernel), so the
@@ -247,12 +289,20 @@ extern "C" int xq_groupnorm_silu_forward(const void *x, const float *w, const fl
     const float n = (float)HW * (float)(C / G);
     const bf16 *xp = (const bf16 *)x;
     const int pslot = xq::prof_begin(XQ_PROF_GROUPNORM, (double)B * HW * C * 8.0, s);
-    hipLaunchKernelGGL((gn_reduce_kernel<0>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
-                       workspace, (float *)nullptr);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, workspace, ns, G, n, eps, 0, mean, (float *)nullptr);
-    hipLaunchKernelGGL((gn_reduce_kernel<1>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
-                       workspace, (float *)nullptr);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, workspace, ns, G, n, eps, 1, rstd, (float *)nullptr);
+    static const bool two_pass = getenv("XQ_GN_TWO_PASS") != nullptr;      // rounds 2-4: mean, then the centred sum of squares (two reads of x)
+    if (!two_pass && C / G <= 32) {
+        float *part_c = workspace + (size_t)B * ns * G * 2;
+        hipLaunchKernelGGL((gn_reduce_kernel<3>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
+                           workspace, part_c);
+        hipLaunchKernelGGL(gn_finalize_onepass_kernel, dim3(B), dim3(64), 0, s, (const float *)part_c, xp, ns, HW, C, G, eps, mean, rstd);
+    } else {
+        hipLaunchKernelGGL((gn_reduce_kernel<0>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
+                           workspace, (float *)nullptr);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, workspace, ns, G, n, eps, 0, mean, (float *)nullptr);
+        hipLaunchKernelGGL((gn_reduce_kernel<1>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
+                           workspace, (float *)nullptr);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(64), 0, s, workspace, ns, G, n, eps, 1, rstd, (float *)nullptr);
+    }
     int apx;
     const int ans = gn_apply_slabs(HW, C, &apx);
     hipLaunchKernelGGL(gn_apply_fwd_kernel, dim3(ans, B), dim3(256), 0, s, xp, w, bias, mean, rstd, HW, C, G, silu, apx, (bf16 *)y);
