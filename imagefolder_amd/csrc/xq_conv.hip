@@ -400,6 +400,8 @@ extern "C" int xq_conv3x3_nhwc_bf16(const void *X, const void *Wp, const float *
 // channel, 4 consecutive pixels per read; the same register <-> pixel order on both operands).
 // Block = one tap x 128 n x 128 c over a contiguous range of 64-pixel tiles; 2 x 2 waves of 64 x 64; the partial tile is
 // added to dWp with fp32 atomics (dWp zero-initialised by the caller).  The shifted X rows use the forward's halo logic.
+// Staging goes global -> registers (issued before the tile's MFMAs) -> LDS; NBUF = 2: the store lands in the other buffer, one barrier per K
+// tile; NBUF = 1 (the product form, see the launch plan below): one 37 KiB buffer, a second barrier per K tile, four workgroups per CU.
 // ---------------------------------------------------------------------------------------------------------------------
 static inline bool is_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 typedef short wg_s4 __attribute__((ext_vector_type(4)));
@@ -421,13 +423,13 @@ __device__ __forceinline__ wg_s4 wg_tr4(const short *p) {
 //         are wave-uniform (scalar ALU); per lane only x's validity and a 32-bit byte offset remain, and out-of-image taps become buffer
 //         loads past the descriptor's range (they return zero): ~25 VALU instructions per K tile.
 typedef unsigned wg_u32x4 __attribute__((ext_vector_type(4)));
-template <int MODE, int WG_PITCH>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16 *__restrict__ X, const __hip_bfloat16 *__restrict__ dY, long M,
+template <int MODE, int WG_PITCH, int NBUF = 2, int MINW = 1>
+__global__ __launch_bounds__(256, MINW) void conv3x3_wgrad_kernel(const __hip_bfloat16 *__restrict__ X, const __hip_bfloat16 *__restrict__ dY, long M,
                                                             int H, int Wd, int Cin, int Cout, int tiles_per_split, int nsplit,
                                                             float *__restrict__ dWp, int Hi, int Wi, int stride, int pad, int up,
                                                             unsigned x_bytes, unsigned y_bytes) {
     constexpr bool POW2 = MODE >= 1;
-    __shared__ __attribute__((aligned(16))) short lds[2][2 * 64 * WG_PITCH];   // [buffer][dY tile | X tile], 64 pixels each
+    __shared__ __attribute__((aligned(16))) short lds[NBUF][2 * 64 * WG_PITCH];   // [buffer][dY tile | X tile], 64 pixels each
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
     const int gn = Cout / 128, gc = Cin / 128;
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
     WG_STORE(0)
     __syncthreads();
     for (long t = t_begin; t < t_end; ++t) {
-        const int cur = (int)((t - t_begin) & 1);
+        const int cur = NBUF == 2 ? (int)((t - t_begin) & 1) : 0;
         if (t + 1 < t_end) WG_LOAD(t + 1)
         const short *Yt = lds[cur] + troff + wn * 64, *Xt = lds[cur] + 64 * WG_PITCH + troff + wc * 64;
 #pragma unroll
@@ -542,7 +544,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (t + 1 < t_end) WG_STORE(cur ^ 1)
+        if (NBUF == 1) __syncthreads();      // one buffer: every wave is done reading before the next tile overwrites it
+        if (t + 1 < t_end) WG_STORE(NBUF == 2 ? (cur ^ 1) : 0)
         __syncthreads();
     }
 #undef WG_LOAD_ROW
@@ -565,27 +568,43 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_kernel(const __hip_bfloat16
         }
 }
 
-// picks the kernel form (MODE, above) from the geometry
-static void launch_conv3x3_wgrad(const void *X, const void *dY, int B, int Hi, int Wi, int Ho, int Wo, int Cin, int Cout, int stride, int pad,
-                                 int up, long T, int tps, int nsplit, float *dWp, hipStream_t s) {
+// Launch plan.  The product form for the maps of the CNN tokenizer (MODE 2, one LDS buffer, 128 VGPRs: four workgroups = 16 waves per CU —
+// round 5: with two buffers the 74 KiB of LDS held the kernel at two workgroups per CU, and its one barrier per 16 MFMAs had nothing to hide
+// behind; one buffer costs a second barrier per K tile and wins 15-35 %, profiles/r05_conv_wgrad_ab.txt) runs ~8 workgroups per CU in total, but
+// never fewer than 32 K tiles per workgroup (the 64 atomics per lane of the epilogue); the general forms keep two buffers and ~4 per CU.
+// Environment switches for A/B timing: XQ_WGRAD_TWO_BUFFERS=1 (MODE 2 with two buffers), XQ_WGRAD_PITCH=136 (round-2 LDS pitch, two-buffer forms),
+// XQ_WGRAD_SLOW_INDEX=1 (MODE 1 instead of 2), XQ_WGRAD_BLOCKS_PER_CU=n.
+static int conv3x3_wgrad_launch(const char *fn, const void *X, const void *dY, int B, int Hi, int Wi, int Ho, int Wo, int Cin, int Cout, int stride,
+                                int pad, int up, float *dWp, hipStream_t s) {
+    static const bool old_pitch = getenv("XQ_WGRAD_PITCH") && atoi(getenv("XQ_WGRAD_PITCH")) == 136;
+    static const bool two_buf = getenv("XQ_WGRAD_TWO_BUFFERS") != nullptr || old_pitch;
+    static const bool slow_index = getenv("XQ_WGRAD_SLOW_INDEX") != nullptr;
+    static const long per_cu_env = getenv("XQ_WGRAD_BLOCKS_PER_CU") ? atol(getenv("XQ_WGRAD_BLOCKS_PER_CU")) : 0L;
     const long M = (long)B * Ho * Wo;
     const long xb = (long)B * Hi * Wi * Cin * 2, yb = M * Cout * 2;
-    const dim3 grid((unsigned)(((T + 7) / 8) * 8));
     const bool p2 = is_pow2(Ho) && is_pow2(Wo);
-    static const bool old_pitch = getenv("XQ_WGRAD_PITCH") && atoi(getenv("XQ_WGRAD_PITCH")) == 136;
-#define WG_GO(MODE_)                                                                                                                \
-    do {                                                                                                                            \
-        if (old_pitch)                                                                                                              \
-            hipLaunchKernelGGL((conv3x3_wgrad_kernel<MODE_, 136>), grid, dim3(256), 0, s, (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, \
-                               Ho, Wo, Cin, Cout, tps, nsplit, dWp, Hi, Wi, stride, pad, up, (unsigned)xb, (unsigned)yb);           \
-        else                                                                                                                        \
-            hipLaunchKernelGGL((conv3x3_wgrad_kernel<MODE_, 144>), grid, dim3(256), 0, s, (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, \
-                               Ho, Wo, Cin, Cout, tps, nsplit, dWp, Hi, Wi, stride, pad, up, (unsigned)xb, (unsigned)yb);           \
-    } while (0)
-    if (p2 && Wo >= 16 && M % 64 == 0 && xb < 0xffffff00L && yb < 0xffffff00L && !getenv("XQ_WGRAD_SLOW_INDEX")) WG_GO(2);
-    else if (p2) WG_GO(1);
-    else WG_GO(0);
+    const int mode = (p2 && Wo >= 16 && M % 64 == 0 && xb < 0xffffff00L && yb < 0xffffff00L && !slow_index) ? 2 : (p2 ? 1 : 0);
+    const bool one_buf = mode == 2 && !two_buf;
+    const long ntiles = (M + 63) / 64;
+    const long base = 9L * (Cout / 128) * (Cin / 128);
+    const long per_cu = per_cu_env > 0 ? per_cu_env : (one_buf ? 8L : 4L);
+    long nsplit = (per_cu * num_cus() + base - 1) / base;
+    if (one_buf && nsplit > ntiles / 32) nsplit = ntiles / 32;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > ntiles) nsplit = ntiles;
+    const long tps = (ntiles + nsplit - 1) / nsplit;
+    nsplit = (ntiles + tps - 1) / tps;
+    const long T = nsplit * base;
+    const dim3 grid((unsigned)(((T + 7) / 8) * 8));
+#define WG_GO(...)                                                                                                                        \
+    hipLaunchKernelGGL((conv3x3_wgrad_kernel<__VA_ARGS__>), grid, dim3(256), 0, s, (const __hip_bfloat16 *)X, (const __hip_bfloat16 *)dY, M, Ho, Wo, \
+                       Cin, Cout, (int)tps, (int)nsplit, dWp, Hi, Wi, stride, pad, up, (unsigned)xb, (unsigned)yb)
+    if (one_buf) WG_GO(2, 144, 1, 4);
+    else if (mode == 2) { if (old_pitch) WG_GO(2, 136); else WG_GO(2, 144); }
+    else if (mode == 1) { if (old_pitch) WG_GO(1, 136); else WG_GO(1, 144); }
+    else { if (old_pitch) WG_GO(0, 136); else WG_GO(0, 144); }
 #undef WG_GO
+    return xq_check_launch(fn);
 }
 
 extern "C" int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, int H, int W, int Cin, int Cout, float *dWp,
@@ -595,18 +614,8 @@ extern "C" int xq_conv3x3_wgrad_nhwc_bf16(const void *X, const void *dY, int B, 
     if (!X || !dY || !dWp) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     if (Cin % 128 != 0 || Cout % 128 != 0)
         return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 128 == 0 and Cout %% 128 == 0 (got %ld, %ld)", fn, Cin, Cout);
-    const long M = (long)B * H * W;
-    if (M >= (1L << 31)) return xq_set_error(XQ_EINVAL, "%s: B*H*W must be below 2^31", fn);
-    const long ntiles = (M + 63) / 64;
-    const long base = 9L * (Cout / 128) * (Cin / 128);
-    long nsplit = (4L * num_cus() + base - 1) / base;   // ~4 blocks per CU in total
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > ntiles) nsplit = ntiles;
-    const long tps = (ntiles + nsplit - 1) / nsplit;
-    nsplit = (ntiles + tps - 1) / tps;
-    const long T = nsplit * base;
-    launch_conv3x3_wgrad(X, dY, B, H, W, H, W, Cin, Cout, 1, 1, 0, T, (int)tps, (int)nsplit, dWp, (hipStream_t)stream);
-    return xq_check_launch(fn);
+    if ((long)B * H * W >= (1L << 31)) return xq_set_error(XQ_EINVAL, "%s: B*H*W must be below 2^31", fn);
+    return conv3x3_wgrad_launch(fn, X, dY, B, H, W, H, W, Cin, Cout, 1, 1, 0, dWp, (hipStream_t)stream);
 }
 
 extern "C" int xq_conv3x3_wgrad_nhwc_bf16_ex(const void *X, const void *dY, int B, int Hi, int Wi, int Ho, int Wo, int Cin, int Cout, int stride,
@@ -617,18 +626,8 @@ extern "C" int xq_conv3x3_wgrad_nhwc_bf16_ex(const void *X, const void *dY, int 
     if (Cin % 128 != 0 || Cout % 128 != 0)
         return xq_set_error(XQ_EINVAL, "%s: needs Cin %% 128 == 0 and Cout %% 128 == 0 (got %ld, %ld)", fn, Cin, Cout);
     if ((stride != 1 && stride != 2) || pad < 0 || pad > 1) return xq_set_error(XQ_EINVAL, "%s: stride 1 / 2, pad 0 / 1", fn);
-    const long M = (long)B * Ho * Wo;
-    if (M >= (1L << 31) || (long)B * Hi * Wi >= (1L << 31)) return xq_set_error(XQ_EINVAL, "%s: pixel counts must be below 2^31", fn);
-    const long ntiles = (M + 63) / 64;
-    const long base = 9L * (Cout / 128) * (Cin / 128);
-    long nsplit = (4L * num_cus() + base - 1) / base;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > ntiles) nsplit = ntiles;
-    const long tps = (ntiles + nsplit - 1) / nsplit;
-    nsplit = (ntiles + tps - 1) / tps;
-    const long T = nsplit * base;
-    launch_conv3x3_wgrad(X, dY, B, Hi, Wi, Ho, Wo, Cin, Cout, stride, pad, upsample2x ? 1 : 0, T, (int)tps, (int)nsplit, dWp, (hipStream_t)stream);
-    return xq_check_launch(fn);
+    if ((long)B * Ho * Wo >= (1L << 31) || (long)B * Hi * Wi >= (1L << 31)) return xq_set_error(XQ_EINVAL, "%s: pixel counts must be below 2^31", fn);
+    return conv3x3_wgrad_launch(fn, X, dY, B, Hi, Wi, Ho, Wo, Cin, Cout, stride, pad, upsample2x ? 1 : 0, dWp, (hipStream_t)stream);
 }
 
 // out[b][y][x][c] = sum of the 2 x 2 block of in at (2y, 2x): the backward of nearest-2x upsampling (Upsample, xqgan_model.py:682-686)
