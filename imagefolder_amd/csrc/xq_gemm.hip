@@ -28,6 +28,7 @@
 #include "../../include/xq_ops.h"
 
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 
 
 using namespace xq;
@@ -220,10 +221,24 @@ struct Stager<gm::KMAJOR_CONV, true> {
 };
 
 // fragment of 8 reduction indices for row / column (lane & 31) out of a piece
-template <int KIND, bool IS_A>
+// ASM (K-strided only): the two transpose reads by inline asm.  hipcc puts an s_waitcnt vmcnt(0) in front of the ds_read_b64_tr_b16 INTRINSIC
+// whenever an LDS-DMA may be in flight (it cannot tell the ring slots apart): the whole prefetch queue drains once per K tile.  The asm reads are
+// invisible to that pass; the CALLER must retire them with an explicit s_waitcnt lgkmcnt(0) + sched_barrier in front of the first MFMA that uses
+// them (cdna_hip_programming.md 5.4 rule 18) — the duo schedules do.  The 256 x 256 schedules keep the intrinsic: A/B on the persistent kernel
+// (profiles/r06_gemm_2wg_ab.txt): data gradients +-1..3 %, weight gradients -3..-7 % (both operands transposed: the pinned asm order costs more than
+// the drained queue, whose last pieces were issued a whole phase earlier).
+template <int KIND, bool IS_A, bool ASM = false>
 __device__ __forceinline__ bf16x8 read_frag(const char *piece, int w, int f, int s, int lane) {
     if (KIND != gm::KSTRIDED) {
         return *reinterpret_cast<const bf16x8 *>(piece + gm::frag_off_kmajor<IS_A>(w, f, s, lane));
+    } else if (ASM) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        u32x2_ lo, hi;
+        const unsigned a0 = (unsigned)(size_t)(piece + gm::frag_off_kstrided<IS_A>(w, f, s, 0, lane));
+        const unsigned a1 = (unsigned)(size_t)(piece + gm::frag_off_kstrided<IS_A>(w, f, s, 1, lane));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(a0));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(a1));
+        return __builtin_shufflevector(__builtin_bit_cast(bf16x4, lo), __builtin_bit_cast(bf16x4, hi), 0, 1, 2, 3, 4, 5, 6, 7);
     } else {
         const bf16x4 lo = tr4(piece + gm::frag_off_kstrided<IS_A>(w, f, s, 0, lane));
         const bf16x4 hi = tr4(piece + gm::frag_off_kstrided<IS_A>(w, f, s, 1, lane));
@@ -573,6 +588,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     // phase of every item of the workgroup except each item's first; the traced workgroup writes the six numbers at the end of the kernel.
     // Outputs are bit-identical to the plain kernel (tests/test_gemm_gpu.py).
     unsigned long long q_s = 0, q_a = 0, q_p = 0, q_e = 0;
+    const unsigned long long q_life0 = SUMS ? __builtin_amdgcn_s_memtime() : 0ull, q_real0 = SUMS ? __builtin_amdgcn_s_memrealtime() : 0ull;
     unsigned q_s_prev = 0, q_n = 0, q_phases = 0, q_items = 0, q_load = 0, q_bar1 = 0, q_mfma = 0, q_bar2 = 0;
 #define PR_Q(X)                                                   \
     do {                                                          \
@@ -902,6 +918,8 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             unsigned long long *out = g.trace + (long)wave * g.trace_cap;
             out[0] = 0;
             out[8] = q_phases; out[9] = q_load; out[10] = q_bar1; out[11] = q_mfma; out[12] = q_bar2; out[13] = q_items;
+            out[14] = __builtin_amdgcn_s_memtime() - q_life0;          // shader cycles of this workgroup's life ...
+            out[15] = __builtin_amdgcn_s_memrealtime() - q_real0;      // ... and the 100 MHz reference ticks: their ratio is the clock the chip held
         }
     }
 #undef PR_Q
@@ -920,22 +938,562 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
 #undef PR_ZERO
 }
 
+// =====================================================================================================================
+// duo schedule (round 6): 128 x 256 block tile, TWO workgroups per CU (8 waves of 64 x 64 each: 64 accumulator registers, <= 128
+// VGPRs -> 4 waves per SIMD; 80 KiB of LDS per workgroup).  What the 256 x 256 persistent kernel cannot do (its register file and
+// LDS are both full) the hardware does by itself here: while one workgroup of a CU stores its tile (or waits for its first pieces, or sits at
+// a barrier) the other one's K loop owns the matrix pipe, so the store burst of a short-K item is no longer serial time.
+//   pieces   per K tile: A (128 rows x 64 k, piece-row = tile row), B-left, B-right (128 columns each, as above) = 48 KiB
+//   ring     A(t) in A slot t & 1; B piece y = 2 t + h in B slot y % 3  (2 + 3 slots of 16 KiB = 80 KiB)
+//   phase    (t, h), one barrier each:  wait [own DMA of the pieces read now] - barrier - stage - fragment reads - 8 MFMAs
+//            (t, 0): reads A(t) (kept in registers for both phases) + B-left(t), stages B-left(t + 1)  into the slot of B-right(t - 1)
+//            (t, 1): reads B-right(t),                                            stages B-right(t + 1) into the slot of B-left(t),
+//                                                                                        A(t + 2)       into the slot of A(t)
+//   stream   A0 BL0 BR0 A1 | BL1 | BR1 A2 | BL2 | BR2 A3 | ...  (2 LDS-DMA instructions per piece and wave)
+//   RAW      a piece is read after every wave's own counted vmcnt AND the barrier behind it: at (t, 0) the stream holds A(t) BL(t) BR(t)
+//            A(t + 1) -> vmcnt(4); at (t, 1) BR(t) A(t + 1) BL(t + 1) -> vmcnt(4); the last K tile (nothing staged behind it): vmcnt(2), vmcnt(0)
+//   WAR      a slot is restaged behind the barrier that follows the phase which read it; every wave retires its reads (lgkmcnt(0)) before
+//            its MFMAs, i.e. before it can arrive at that barrier
+// Same MFMA order per accumulator as every other schedule: outputs are bit-identical to gemm_simple_kernel's.
+// =====================================================================================================================
+// bf16 epilogue of one 128 x 256 duo tile: accumulators (+ bias / ReLU) -> bf16, 32 rows x 64 columns at a time through 4 KiB of this wave's own
+// LDS region, full-row 16-byte stores; ACT as in the persistent kernel.  m_lo: first row that belongs to this tile row (the rows [m0, m_lo) of a
+// moved-back edge tile are the tile above's: computed identically, not summed twice into the fc1-bias partials); trow: tile row.
+template <int BK, int ACT>
+__device__ __forceinline__ void duo_epilogue(const f32x16 (&acc)[2][2], const GemmArgs &g, char *region, long m0, long n0, long m_lo, long trow,
+                                             int wr, int wc, int lane) {
+    constexpr int WTN = 64;
+        const int h = lane >> 5;
+    const long ncol0 = n0 + 64 * wc;
+    constexpr bool HAS_BIAS = BK == gm::KMAJOR;
+    float4 bv[2][4];
+#pragma unroll
+    for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            long n = ncol0 + 32 * fj + 8 * q + 4 * h;
+            if (n > g.N - 4) n = g.N - 4;
+            bv[fj][q] = (HAS_BIAS && g.bias) ? *reinterpret_cast<const float4 *>(g.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) {
+        u32x4 hv[4];
+        if (ACT == ACT_GELU_BWD) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                int row, c, off;
+                gm::epi_read_map(it, lane, WTN, &row, &c, &off);
+                long gr = m0 + 64 * wr + 32 * fi + row, gc = ncol0 + 8 * c;
+                if (gr > g.M - 1) gr = g.M - 1;
+                if (gc > g.N - 8) gc = g.N - 8;
+                hv[it] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __hip_bfloat16 *>(g.H) + gr * g.ldc + gc);
+            }
+        }
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint2 pk;
+                float e0 = acc[fi][fj][4 * q + 0], e1 = acc[fi][fj][4 * q + 1], e2 = acc[fi][fj][4 * q + 2], e3 = acc[fi][fj][4 * q + 3];
+                if (HAS_BIAS) {
+                    e0 += bv[fj][q].x; e1 += bv[fj][q].y; e2 += bv[fj][q].z; e3 += bv[fj][q].w;
+                    if (g.relu) { e0 = fmaxf(e0, 0.f); e1 = fmaxf(e1, 0.f); e2 = fmaxf(e2, 0.f); e3 = fmaxf(e3, 0.f); }
+                }
+                pk.x = pack_bf16(e0, e1);
+                pk.y = pack_bf16(e2, e3);
+                *reinterpret_cast<uint2 *>(region + gm::epi_write_off(0, fj, q, lane, WTN)) = pk;
+            }
+        // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            int row, c, off;
+            gm::epi_read_map(it, lane, WTN, &row, &c, &off);
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(region + off);
+            const long gr = m0 + 64 * wr + 32 * fi + row;
+            const long gc = ncol0 + 8 * c;
+            const bool ok = gr < g.M && gc + 8 <= g.N && !g.debug_no_store;
+            u32x4 o = v;
+            if (ACT == ACT_GELU_FWD) {
+                u32x4 a2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = bf16_lo(v[e]), x1 = bf16_hi(v[e]);
+                    a2[e] = g.gelu_tanh ? pack_bf16(gelu_val<true>(x0), gelu_val<true>(x1)) : pack_bf16(gelu_val<false>(x0), gelu_val<false>(x1));
+                }
+                if (ok) {
+                    u32x4 *p2 = reinterpret_cast<u32x4 *>(reinterpret_cast<__hip_bfloat16 *>(g.C2) + gr * g.ldc + gc);
+                    if (g.nt_store) __builtin_nontemporal_store(a2, p2); else *p2 = a2;
+                }
+            } else if (ACT == ACT_GELU_BWD) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d0 = g.gelu_tanh ? gelu_grad<true>(bf16_lo(hv[it][e])) : gelu_grad<false>(bf16_lo(hv[it][e]));
+                    const float d1 = g.gelu_tanh ? gelu_grad<true>(bf16_hi(hv[it][e])) : gelu_grad<false>(bf16_hi(hv[it][e]));
+                    o[e] = pack_bf16(bf16_lo(v[e]) * d0, bf16_hi(v[e]) * d1);
+                    if (gr >= m_lo) { csum[2 * e] += bf16_lo(o[e]); csum[2 * e + 1] += bf16_hi(o[e]); }
+                }
+            }
+            if (ok && (ACT != ACT_GELU_FWD || g.C != nullptr)) {
+                u32x4 *p1 = reinterpret_cast<u32x4 *>(C + gr * g.ldc + gc);
+                if (g.nt_store) __builtin_nontemporal_store(o, p1); else *p1 = o;
+            }
+        }
+    }
+    if (ACT == ACT_GELU_BWD && g.colpart) {
+        // lanes l, l + 8, ..., l + 56 hold the same 8 columns (c = l & 7) for different rows; one colpart row per (tile row, wave row)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = csum[e];
+            t += __shfl_xor(t, 8);
+            t += __shfl_xor(t, 16);
+            t += __shfl_xor(t, 32);
+            csum[e] = t;
+        }
+        const long gc = ncol0 + 8 * (lane & 7);
+        if (lane < 8 && gc + 8 <= g.N) {
+            float *cp = g.colpart + (2 * trow + wr) * g.N + gc;
+            *reinterpret_cast<float4 *>(cp) = make_float4(csum[0], csum[1], csum[2], csum[3]);
+            *reinterpret_cast<float4 *>(cp + 4) = make_float4(csum[4], csum[5], csum[6], csum[7]);
+        }
+    }
+}
+
+// fp32 slab of a K-split duo item: [128][256], this wave's 64 x 64 block
+__device__ __forceinline__ void duo_epilogue_slab(const f32x16 (&acc)[2][2], float *S, int wr, int wc, int lane) {
+    const int h = lane >> 5;
+#pragma unroll
+    for (int fi = 0; fi < 2; ++fi) {
+        const int row = 64 * wr + 32 * fi + (lane & 31);
+#pragma unroll
+        for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<float4 *>(S + row * 256 + 64 * wc + 32 * fj + 8 * q + 4 * h) =
+                    make_float4(acc[fi][fj][4 * q + 0], acc[fi][fj][4 * q + 1], acc[fi][fj][4 * q + 2], acc[fi][fj][4 * q + 3]);
+    }
+}
+
+// tile pointer + wave-uniform deltas in scalar registers, ONE per-lane offset register per operand (xq_gemm_map.hpp)
+template <int KIND, bool IS_A>
+struct DuoStager : gm::DuoStagerAddr<KIND, IS_A> {
+    using gm::DuoStagerAddr<KIND, IS_A>::voff;
+    using gm::DuoStagerAddr<KIND, IS_A>::cur;
+    using gm::DuoStagerAddr<KIND, IS_A>::adv;
+    using gm::DuoStagerAddr<KIND, IS_A>::d_i;
+    using gm::DuoStagerAddr<KIND, IS_A>::d_half;
+    static __device__ __forceinline__ long sgpr64(long v) {
+        const unsigned long long u = (unsigned long long)v;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return (long)(((unsigned long long)hi << 32) | lo);
+    }
+    __device__ __forceinline__ void make_scalar() {
+        cur = (const char *)sgpr64((long)cur);
+        adv = __builtin_amdgcn_readfirstlane(adv); d_i = __builtin_amdgcn_readfirstlane(d_i); d_half = __builtin_amdgcn_readfirstlane(d_half);
+    }
+    // the two LDS-DMA instructions of piece `half` of the K tile under the cursor; the tile pointer goes through an opaque scalar so that
+    // loop strength reduction cannot turn (cursor + per-lane offset) into per-instruction 64-bit VECTOR induction variables (12 VGPRs + spills)
+    __device__ __forceinline__ void issue_cur(int half, char *dst, int wave) const {
+        unsigned long long b = (unsigned long long)(cur + (half ? d_half : 0u));
+        asm volatile("" : "+s"(b));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((gbl_void *)((const char *)(b + (i ? (unsigned long long)d_i : 0ull)) + voff),
+                                             (lds_void *)(dst + (8 * i + wave) * 1024), 16, 0, 0);
+    }
+    __device__ __forceinline__ void issue_one(int half, int i, char *dst, int wave) const {
+        unsigned long long b = (unsigned long long)(cur + (half ? d_half : 0u) + (i ? d_i : 0u));
+        asm volatile("" : "+s"(b));
+        __builtin_amdgcn_global_load_lds((gbl_void *)((const char *)b + voff), (lds_void *)(dst + (8 * i + wave) * 1024), 16, 0, 0);
+    }
+    __device__ __forceinline__ void step() { cur += adv; }
+};
+
+// ---- the K loop of the duo schedules (gemm_duo_kernel, gemm_pduo_kernel): macros over the kernels' local names (smem, acc, af, bf, sa, sb, a_rd,
+//      b_rd, wave, lane, wr, wc, BK, ASM_TR; DU_Q / DU_Q_ACC: the clock stamps of the SUMS twins) ------------------------------------------------
+// Fragment reads are software-pipelined under the MFMAs with NO extra registers: the barrier of a phase certifies the pieces of the NEXT phase, so
+// each fragment register is reloaded right behind the MFMA pair that consumed it and the read latency runs under the rest of the cluster and
+// the barrier wait (tools/duo_timeline.py on the first form — reads in front of the cluster: the counted vmcnt waits ~20 cycles, the data is
+// always there; a phase paid a 255 - 384-cycle read window with the matrix pipe idle for this workgroup).  The LDS-DMA instructions of a phase
+// sit between its MFMA pairs as well: their issue time (~100 cycles each with the TA queue busy) hides in the matrix pipe's 32-cycle slots.
+//   (t, 0)  [vmcnt: B-right(t) landed] [lgkmcnt(0): my reads of A(t), B-left(t) returned] barrier
+//           MFMAs on A(t) x B-left(t); behind pair s: bf[s] <- B-right(t);  stages B-right(t + 1) -> slot of B-left(t), A(t + 2) -> slot of A(t)
+//   (t, 1)  [vmcnt: A(t + 1), B-left(t + 1) landed] [lgkmcnt(0)] barrier
+//           MFMAs on A(t) x B-right(t); behind pair s: bf[s] <- B-left(t + 1), af[.][s] <- A(t + 1);  stages B-left(t + 2) -> slot of B-right(t)
+//   stream  A0 BL0 BR0 A1 BL1 | BR1 A2 | BL2 | BR2 A3 | BL3 | ...   (all five slots are filled before the first MFMA; 2 LDS-DMA instructions per
+//           piece and wave)
+//   RAW     a piece is read after every wave's own counted vmcnt AND the barrier behind it: vmcnt(4) in both phases (behind the pieces a phase
+//           certifies the stream holds two more); tile n - 2: 4, 2; tile n - 1: 0, 0
+//   WAR     a slot is restaged behind the barrier in front of which EVERY wave has seen its reads of that slot return (the lgkmcnt(0))
+// b_rd: slot of the B piece whose fragments are in bf; the next piece sits in DUO_BNEXT(b_rd), piece + 3 is staged into b_rd itself.
+#define DUO_ASLOT(I) (smem + (I) * gm::PIECE_BYTES)
+#define DUO_BSLOT(I) (smem + (2 + (I)) * gm::PIECE_BYTES)
+#define DUO_BNEXT(I) ((I) == 2 ? 0 : (I) + 1)
+#define DUO_PIN(X) asm volatile("" : "+v"(X))
+#define DUO_PAIR(FJ, S_)                                                                                       \
+    do {                                                                                                       \
+        acc[0][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[S_], af[0][S_], acc[0][FJ], 0, 0, 0);          \
+        acc[1][FJ] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[S_], af[1][S_], acc[1][FJ], 0, 0, 0);          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+    } while (0)
+#define DUO_RD_B(S_) bf[S_] = read_frag<BK, false, ASM_TR>(DUO_BSLOT(DUO_BNEXT(b_rd)), wc, 0, S_, lane)
+#define DUO_RD_A(S_)                                                                                           \
+    do {                                                                                                       \
+        af[0][S_] = read_frag<gm::KMAJOR, true>(DUO_ASLOT(a_rd ^ 1), wr, 0, S_, lane);                         \
+        af[1][S_] = read_frag<gm::KMAJOR, true>(DUO_ASLOT(a_rd ^ 1), wr, 1, S_, lane);                         \
+    } while (0)
+#define DUO_SB() __builtin_amdgcn_sched_barrier(0)
+#define DUO_HEAD(V_)                                                          \
+    do {                                                                      \
+        DU_Q(q_a);                                                            \
+        GR_VMCNT(V_);                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+        DU_Q(q_v);                                                            \
+        GR_BARRIER();                                                         \
+        DU_Q(q_b);                                                            \
+    } while (0)
+// one K tile.  ST_BR / ST_A / ST_BL: stage B-right(t + 1), A(t + 2), B-left(t + 2); RDN: tile t + 1 exists (its A, B-left are read in (t, 1))
+#define DUO_TILE(ST_BR, ST_A, ST_BL, RDN, V0, V1)                                                                     \
+    do {                                                                                                              \
+        DUO_HEAD(V0);                                                                                                 \
+        if (ST_BR) sb.issue_one(1, 0, DUO_BSLOT(b_rd), wave);                                                         \
+        DUO_PIN(acc[0][0]); DUO_PIN(acc[1][0]);                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        DUO_PAIR(0, 0);                                                                                               \
+        DUO_RD_B(0); if (ST_BR) { sb.issue_one(1, 1, DUO_BSLOT(b_rd), wave); sb.step(); } DUO_SB();                   \
+        DUO_PAIR(0, 1);                                                                                               \
+        DUO_RD_B(1); if (ST_A) sa.issue_one(0, 0, DUO_ASLOT(a_rd), wave); DUO_SB();                                   \
+        DUO_PAIR(0, 2);                                                                                               \
+        DUO_RD_B(2); if (ST_A) { sa.issue_one(0, 1, DUO_ASLOT(a_rd), wave); sa.step(); } DUO_SB();                    \
+        DUO_PAIR(0, 3);                                                                                               \
+        DUO_RD_B(3); DUO_SB();                                                                                        \
+        DUO_PIN(acc[0][0]); DUO_PIN(acc[1][0]);                                                                       \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+        DU_Q(q_e);                                                                                                    \
+        DU_Q_ACC();                                                                                                   \
+        b_rd = DUO_BNEXT(b_rd);                                                                                       \
+        DUO_HEAD(V1);                                                                                                 \
+        if (ST_BL) sb.issue_one(0, 0, DUO_BSLOT(b_rd), wave);                                                         \
+        DUO_PIN(acc[0][1]); DUO_PIN(acc[1][1]);                                                                       \
+        __builtin_amdgcn_s_setprio(1);                                                                                \
+        DUO_PAIR(1, 0);                                                                                               \
+        if (RDN) { DUO_RD_B(0); DUO_RD_A(0); } if (ST_BL) sb.issue_one(0, 1, DUO_BSLOT(b_rd), wave); DUO_SB();        \
+        DUO_PAIR(1, 1);                                                                                               \
+        if (RDN) { DUO_RD_B(1); DUO_RD_A(1); } DUO_SB();                                                              \
+        DUO_PAIR(1, 2);                                                                                               \
+        if (RDN) { DUO_RD_B(2); DUO_RD_A(2); } DUO_SB();                                                              \
+        DUO_PAIR(1, 3);                                                                                               \
+        if (RDN) { DUO_RD_B(3); DUO_RD_A(3); } DUO_SB();                                                              \
+        DUO_PIN(acc[0][1]); DUO_PIN(acc[1][1]);                                                                       \
+        __builtin_amdgcn_s_setprio(0);                                                                                \
+        DU_Q(q_e);                                                                                                    \
+        DU_Q_ACC();                                                                                                   \
+        b_rd = DUO_BNEXT(b_rd);                                                                                       \
+        a_rd ^= 1;                                                                                                    \
+    } while (0)
+
+// one workgroup per tile (the form the schedule was developed and timed in; tools/duo_timeline.py reads its clock stamps)
+template <int BK, int ACT, bool SUMS = false>
+__global__ __attribute__((amdgpu_flat_work_group_size(GT, GT), amdgpu_waves_per_eu(4, 4))) void gemm_duo_kernel(const GemmArgs g) {
+    // SUMS (diagnostics, XQ_GEMM_TRACE_SUMS + xq_gemm_trace_bind; tools/duo_timeline.py): shader-clock reads at the workgroup's start, K-loop
+    // start / end and end, the CU it ran on, the 100 MHz reference ticks of its life, and per-phase segment sums (wait = counted vmcnt, bar =
+    // barrier, mfma = the MFMA cluster with the phase's fragment reads and LDS-DMA instructions in it) of every wave — [workgroup][8 waves][16]
+    // uint64.  Outputs are bit-identical to the plain kernel.
+    unsigned long long q_t0 = 0, q_t1 = 0, q_t2 = 0, q_a = 0, q_v = 0, q_b = 0, q_e = 0;
+    unsigned q_wait = 0, q_bar = 0, q_mfma = 0, q_ph = 0;
+#define DU_Q(X)                                                   \
+    do {                                                          \
+        if (SUMS) {                                               \
+            __builtin_amdgcn_sched_barrier(0);                    \
+            X = __builtin_amdgcn_s_memtime();                     \
+            __builtin_amdgcn_sched_barrier(0);                    \
+        }                                                         \
+    } while (0)
+#define DU_Q_ACC()                                                \
+    do {                                                          \
+        if (SUMS) {                                               \
+            q_wait += (unsigned)q_v - (unsigned)q_a;              \
+            q_bar += (unsigned)q_b - (unsigned)q_v;               \
+            q_mfma += (unsigned)q_e - (unsigned)q_b;              \
+            ++q_ph;                                               \
+        }                                                         \
+    } while (0)
+    DU_Q(q_t0);
+    const unsigned long long q_real0 = SUMS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // A slots 0, 1 | B slots 0, 1, 2; the epilogue restages through the first 32 KiB
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const long total = (long)g.tiles_m * g.tiles_n;
+    const long pos = gm::xcd_order(blockIdx.x, total);
+    const long trow = pos / g.tiles_n;
+    long m0 = trow * gm::BM_DUO, n0 = (pos - trow * g.tiles_n) * 256;
+    // ragged edges: the last tile row / column moves back inside the matrix (the overlap is computed twice, identically)
+    const long m_lo = m0;                 // rows below m_lo belong to the previous tile row (ACT_GELU_BWD: not summed twice)
+    if (m0 > g.M - gm::BM_DUO) m0 = g.M - gm::BM_DUO;
+    if (n0 > g.N - 256) n0 = g.N - 256;
+    const int KT = __builtin_amdgcn_readfirstlane(g.kt_full);
+
+    DuoStager<gm::KMAJOR, true> sa;
+    DuoStager<BK, false> sb;
+    sa.init(g.A, g.lda, m0, 0, wave, lane);
+    sb.init(g.B, g.ldb, n0, 0, wave, lane);
+    sa.make_scalar();
+    sb.make_scalar();
+    constexpr bool ASM_TR = BK == gm::KSTRIDED;      // K-strided fragments by inline asm (read_frag)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    int a_rd = 0, b_rd = 0;      // slot of the A piece / the B piece whose fragments are in registers (scalar)
+    bf16x8 af[2][4], bf[4];
+    DU_Q(q_t1);
+    sa.issue_cur(0, DUO_ASLOT(0), wave);
+    sa.step();
+    sb.issue_cur(0, DUO_BSLOT(0), wave);
+    sb.issue_cur(1, DUO_BSLOT(1), wave);
+    sb.step();
+    if (KT > 1) {
+        sa.issue_cur(0, DUO_ASLOT(1), wave);
+        sa.step();
+        sb.issue_cur(0, DUO_BSLOT(2), wave);
+        GR_VMCNT(6);
+    } else {
+        GR_VMCNT(2);
+    }
+    GR_BARRIER();
+#pragma unroll
+    for (int s_ = 0; s_ < 4; ++s_) {
+        bf[s_] = read_frag<BK, false, ASM_TR>(DUO_BSLOT(0), wc, 0, s_, lane);
+        af[0][s_] = read_frag<gm::KMAJOR, true>(DUO_ASLOT(0), wr, 0, s_, lane);
+        af[1][s_] = read_frag<gm::KMAJOR, true>(DUO_ASLOT(0), wr, 1, s_, lane);
+    }
+    if (KT > 1) {
+        for (int t = 0; t < KT - 2; ++t) DUO_TILE(1, 1, 1, 1, 4, 4);
+        DUO_TILE(1, 0, 0, 1, 4, 2);
+    }
+    DUO_TILE(0, 0, 0, 0, 0, 0);
+    GR_BARRIER();      // (the head barrier of the last phase already freed the ring; this one keeps the epilogues of a workgroup together)
+    DU_Q(q_t2);
+    duo_epilogue<BK, ACT>(acc, g, smem + wave * 4096, m0, n0, m_lo, trow, wr, wc, lane);
+    if (SUMS) {
+        if (g.trace != nullptr && (long)blockIdx.x * 128 + 128 <= (long)g.trace_cap * 8 && lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's stores have been acknowledged
+            unsigned long long q_t3 = __builtin_amdgcn_s_memtime();
+            unsigned long long *out = g.trace + (long)blockIdx.x * 128 + wave * 16;
+            out[0] = q_t0; out[1] = q_t1; out[2] = q_t2; out[3] = q_t3;
+            out[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+            out[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+            out[6] = q_ph; out[7] = q_wait; out[8] = q_bar; out[9] = 0; out[10] = q_mfma; out[11] = (unsigned long long)pos;
+            out[12] = __builtin_amdgcn_s_getreg((31 << 11) | 6);      // HW_REG_LDS_ALLOC: which half of the CU's LDS this workgroup got
+            out[13] = __builtin_amdgcn_s_memrealtime() - q_real0;      // 100 MHz reference ticks over (t0, t3): shader clock = (t3 - t0) / ticks * 100 MHz
+        }
+    }
+#undef DU_Q_ACC
+#undef DU_Q
+}
+
+// =====================================================================================================================
+// persistent duo schedule (round 6): the duo kernel's pipelined K loop (fragment reads under the MFMAs) inside a per-workgroup item loop — grid =
+// 2 workgroups per CU, each walks the item list with stride grid (whole 128 x 256 tiles, then the tail tiles beyond the last full round cut along
+// K into fp32 slabs, as the 256 x 256 persistent kernel does).  What tools/duo_timeline.py measured on the one-workgroup-per-tile form: a workgroup
+// spends 43 % of its life outside the phases of its K loop — launch + tile arithmetic (1.3 k cycles), the first pieces' way from HBM (~8 k), the
+// epilogue INCLUDING the wait for its stores' acknowledgement (5 - 10 k) — against 27 k cycles of phases at K = 768.  Here the next item's
+// pieces are requested the moment the epilogue's last store is issued, nothing waits for acknowledgements, and no workgroup is relaunched.
+//   item boundary   [K loop] [epilogue: 32 KiB of the A slots] barrier [A0 BL0 BR0 A1 BL1 of the next item] vmcnt(6) barrier [fragment reads] ...
+//                   (the stores are OLDER than the pieces: they never enter a counted wait's arithmetic, they only make it stricter)
+// =====================================================================================================================
+template <int BK, int ACT, bool SUMS = false>
+__global__ __attribute__((amdgpu_flat_work_group_size(GT, GT), amdgpu_waves_per_eu(4, 4))) void gemm_pduo_kernel(const GemmArgs g0) {
+    // The kernel runs at the SGPR limit (two 64-bit tile cursors with their deltas, slot arithmetic, loop state), and a spilled scalar is a scratch
+    // load with s_waitcnt vmcnt(0) at the item boundary — a wait for the previous tile's store acknowledgements, the very thing this schedule
+    // removes.  So the launch arguments are NOT kept in registers across the K loop: every item re-reads what it needs from the kernarg segment
+    // (scalar loads through an opaque copy of the segment pointer, which the optimiser can neither hoist nor merge with earlier reads).
+    typedef const __attribute__((address_space(4))) unsigned long long *KArgs;
+    const KArgs kp = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+    struct ArgWords { unsigned long long w[sizeof(GemmArgs) / 8]; };
+    static_assert(sizeof(GemmArgs) % 8 == 0 && sizeof(ArgWords) == sizeof(GemmArgs), "GemmArgs is copied word by word from the kernarg segment");
+#define PD_ARGS(NAME)                                                                                  \
+    KArgs NAME##_p = kp;                                                                               \
+    asm volatile("" : "+s"(NAME##_p));                                                                 \
+    ArgWords NAME##_w;                                                                                 \
+    _Pragma("unroll") for (unsigned i_ = 0; i_ < sizeof(GemmArgs) / 8; ++i_) NAME##_w.w[i_] = NAME##_p[i_]; \
+    const GemmArgs NAME = __builtin_bit_cast(GemmArgs, NAME##_w);
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // A slots 0, 1 | B slots 0, 1, 2
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const unsigned G = gridDim.x;
+    unsigned items;
+    unsigned cp = (unsigned)gm::xcd_order(blockIdx.x, G);
+    gm::DuoItem cit;
+    {
+        PD_ARGS(g);
+        items = (unsigned)(g.main_items + (long)g.tail_tiles * g.tail_splits);
+        if (cp >= items) return;
+        gm::decode_item_duo(g, cp, cit);
+    }
+    // SUMS (diagnostics, tools/duo_timeline.py --persistent): [workgroup][8 waves][16] uint64 — life of the workgroup in shader cycles and 100 MHz
+    // reference ticks, items, phases, per-phase segment sums (vmcnt wait, barrier, MFMA cluster), cycles inside K loops / epilogues / boundaries
+    const unsigned long long q_t0 = SUMS ? __builtin_amdgcn_s_memtime() : 0ull, q_real0 = SUMS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+    unsigned long long q_a = 0, q_v = 0, q_b = 0, q_e = 0, q_x = 0, q_y = 0;
+    unsigned q_wait = 0, q_bar = 0, q_mfma = 0, q_ph = 0, q_items = 0, q_loop = 0, q_epi = 0, q_fill = 0;
+#define DU_Q(X)                                                   \
+    do {                                                          \
+        if (SUMS) {                                               \
+            __builtin_amdgcn_sched_barrier(0);                    \
+            X = __builtin_amdgcn_s_memtime();                     \
+            __builtin_amdgcn_sched_barrier(0);                    \
+        }                                                         \
+    } while (0)
+#define DU_Q_ACC()                                                \
+    do {                                                          \
+        if (SUMS) {                                               \
+            q_wait += (unsigned)q_v - (unsigned)q_a;              \
+            q_bar += (unsigned)q_b - (unsigned)q_v;               \
+            q_mfma += (unsigned)q_e - (unsigned)q_b;              \
+            ++q_ph;                                               \
+        }                                                         \
+    } while (0)
+
+    DuoStager<gm::KMAJOR, true> sa;
+    DuoStager<BK, false> sb;
+    constexpr bool ASM_TR = BK == gm::KSTRIDED;
+
+    f32x16 acc[2][2];
+#define PD_ZERO()                                                    \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_)                 \
+    _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_)                 \
+    _Pragma("unroll") for (int r_ = 0; r_ < 16; ++r_) acc[i_][j_][r_] = 0.0f;
+    PD_ZERO()
+
+    int a_rd = 0, b_rd = 0;      // slot of the A piece / B piece whose fragments are in registers (scalar)
+    bf16x8 af[2][4], bf[4];
+
+    for (;;) {
+        // ---- the item's first pieces: A0 BL0 BR0 (A1 BL1); every slot is free (the barrier below / the kernel start) ----
+        DU_Q(q_x);
+        const int KT = __builtin_amdgcn_readfirstlane(cit.KT);
+        {
+            int lane_s = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // = lane (not a live register across the K loop)
+            asm volatile("" : "+v"(lane_s));
+            PD_ARGS(g);
+            sa.init(g.A, g.lda, cit.m0, cit.k0, wave, lane_s);
+            sb.init(g.B, g.ldb, cit.n0, cit.k0, wave, lane_s);
+        }
+        sa.make_scalar();
+        sb.make_scalar();
+        sa.issue_cur(0, DUO_ASLOT(a_rd), wave);
+        sa.step();
+        sb.issue_cur(0, DUO_BSLOT(b_rd), wave);
+        sb.issue_cur(1, DUO_BSLOT(DUO_BNEXT(b_rd)), wave);
+        sb.step();
+        if (KT > 1) {
+            sa.issue_cur(0, DUO_ASLOT(a_rd ^ 1), wave);
+            sa.step();
+            sb.issue_cur(0, DUO_BSLOT(DUO_BNEXT(DUO_BNEXT(b_rd))), wave);
+            GR_VMCNT(6);
+        } else {
+            GR_VMCNT(2);
+        }
+        GR_BARRIER();
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+            bf[s_] = read_frag<BK, false, ASM_TR>(DUO_BSLOT(b_rd), wc, 0, s_, lane);
+            af[0][s_] = read_frag<gm::KMAJOR, true>(DUO_ASLOT(a_rd), wr, 0, s_, lane);
+            af[1][s_] = read_frag<gm::KMAJOR, true>(DUO_ASLOT(a_rd), wr, 1, s_, lane);
+        }
+        DU_Q(q_y);
+        if (SUMS) q_fill += (unsigned)q_y - (unsigned)q_x;
+        if (KT > 1) {
+            for (int t = 0; t < KT - 2; ++t) DUO_TILE(1, 1, 1, 1, 4, 4);
+            DUO_TILE(1, 0, 0, 1, 4, 2);
+        }
+        DUO_TILE(0, 0, 0, 0, 0, 0);
+        DU_Q(q_x);
+        if (SUMS) q_loop += (unsigned)q_x - (unsigned)q_y;
+        // ---- epilogue (behind the head barrier of the last phase every fragment has been read: the ring is free) ----
+        {
+            // the lane id goes through an opaque register once per item: everything the epilogue derives from it (LDS offsets, row / column of
+            // every store) is then recomputed here instead of being hoisted out of the item loop — 30 registers that do not exist: they were
+            // spilled, and every reload (a scratch load) waited with vmcnt(0) for the previous stores' acknowledgement
+            int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // = lane, from the hardware
+            asm volatile("" : "+v"(lane_e));
+            PD_ARGS(g);
+            if (cit.slab) duo_epilogue_slab(acc, g.slabs + (size_t)cit.slab_idx * (gm::BM_DUO * 256), wr, wc, lane_e);
+            else duo_epilogue<BK, ACT>(acc, g, smem + wave * 4096, cit.m0, cit.n0, cit.m_lo, cit.trow, wr, wc, lane_e);
+        }
+        DU_Q(q_y);
+        if (SUMS) { q_epi += (unsigned)q_y - (unsigned)q_x; ++q_items; }
+        cp += G;
+        if (cp >= items) break;
+        {
+            PD_ARGS(g);
+            gm::decode_item_duo(g, cp, cit);
+        }
+        PD_ZERO()
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // this wave's epilogue reads of its LDS region have returned
+        GR_BARRIER();                                            // ... every wave's: the A slots may be restaged
+    }
+    if (SUMS) {
+        PD_ARGS(g);
+        if (g.trace != nullptr && (long)blockIdx.x * 128 + 128 <= (long)g.trace_cap * 8 && lane == 0) {
+            unsigned long long *out = g.trace + (long)blockIdx.x * 128 + wave * 16;
+            out[0] = q_t0; out[1] = 0; out[2] = 0; out[3] = __builtin_amdgcn_s_memtime();
+            out[4] = __builtin_amdgcn_s_getreg((31 << 11) | 4);       // HW_REG_HW_ID
+            out[5] = __builtin_amdgcn_s_getreg((31 << 11) | 20);      // HW_REG_XCC_ID
+            out[6] = q_ph; out[7] = q_wait; out[8] = q_bar; out[9] = q_items; out[10] = q_mfma; out[11] = q_loop;
+            out[12] = q_epi; out[13] = __builtin_amdgcn_s_memrealtime() - q_real0; out[14] = q_fill;
+        }
+    }
+#undef PD_ZERO
+#undef PD_ARGS
+#undef DU_Q_ACC
+#undef DU_Q
+}
+
+#undef DUO_TILE
+#undef DUO_HEAD
+#undef DUO_SB
+#undef DUO_RD_A
+#undef DUO_RD_B
+#undef DUO_PAIR
+#undef DUO_PIN
+#undef DUO_BNEXT
+#undef DUO_BSLOT
+#undef DUO_ASLOT
+
 // slabs [item = tail tile * nsplit + split][256][256] fp32 -> output: the sum over the splits of every tail tile,
 //   bf16 (+ bias) into C (NT / NN tail tiles), or fp32 into out (TN; + the < 64 remainder rows of the reduction, folded in here)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_n,
                                                           long M, long N, long ldc, const float *__restrict__ bias,
                                                           __hip_bfloat16 *__restrict__ out16, float *__restrict__ out32,
                                                           const __hip_bfloat16 *__restrict__ G, const __hip_bfloat16 *__restrict__ X,
-                                                          long r_begin, long r_end, __hip_bfloat16 *__restrict__ out16_act, int gelu_tanh) {
+                                                          long r_begin, long r_end, __hip_bfloat16 *__restrict__ out16_act, int gelu_tanh,
+                                                          int tile_rows, int move_back) {
+    // tile_rows = 256 (persistent schedule; grid.y = 32) or 128 (persistent duo schedule; grid.y = 16, edge tiles moved back inside the matrix)
     const long t = blockIdx.x;
     const long tile = first_tile + t;
-    const long m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+    long m0 = (tile / tiles_n) * tile_rows, n0 = (tile % tiles_n) * 256;
+    if (move_back) {
+        if (m0 > M - tile_rows) m0 = M - tile_rows;
+        if (n0 > N - 256) n0 = N - 256;
+    }
     const int rl = blockIdx.y * 8 + (threadIdx.x >> 5), cl = (threadIdx.x & 31) * 8;
     const long gr = m0 + rl, gc = n0 + cl;
     if (gr >= M || gc + 8 > N) return;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int k = 0; k < nsplit; ++k) {
-        const float *sp = slabs + ((size_t)(t * nsplit + k) * 256 + rl) * 256 + cl;
+        const float *sp = slabs + ((size_t)(t * nsplit + k) * tile_rows + rl) * 256 + cl;
         const float4 a = *reinterpret_cast<const float4 *>(sp), b = *reinterpret_cast<const float4 *>(sp + 4);
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
         v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
@@ -978,21 +1536,31 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 // grid (tail tiles, 2 halves), 1024 threads: thread = (row lane 0..31, 8-column group 0..31), 4 rows each; fixed-order LDS reduction.
 __global__ __launch_bounds__(1024) void slab_reduce_gelu_bwd_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_n,
                                                                     long M, long N, long ldc, const __hip_bfloat16 *__restrict__ H,
-                                                                    __hip_bfloat16 *__restrict__ out16, float *__restrict__ colpart, int gelu_tanh) {
+                                                                    __hip_bfloat16 *__restrict__ out16, float *__restrict__ colpart, int gelu_tanh,
+                                                                    int tile_rows, int move_back) {
+    // tile_rows = 256: colpart row (m0 / 128) + half, 128 rows per half;  tile_rows = 128 (persistent duo schedule): colpart row 2 * tile row +
+    // half, 64 rows per half, edge tiles moved back inside the matrix (their rows above the tile row's own first row are not summed again)
     __shared__ float red[32][257];
     const long t = blockIdx.x;
     const long tile = first_tile + t;
-    const long m0 = (tile / tiles_n) * 256, n0 = (tile % tiles_n) * 256;
+    const long trow = tile / tiles_n;
+    long m0 = trow * tile_rows, n0 = (tile % tiles_n) * 256;
+    const long m_lo = m0;
+    if (move_back) {
+        if (m0 > M - tile_rows) m0 = M - tile_rows;
+        if (n0 > N - 256) n0 = N - 256;
+    }
+    const int half_rows = tile_rows / 2;
     const int half = blockIdx.y, rl0 = threadIdx.x >> 5, cl = (threadIdx.x & 31) * 8;
     const long gc = n0 + cl;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < 4; ++i) {
-        const int rl = 128 * half + 32 * i + rl0;
+    for (int i = 0; i < half_rows / 32; ++i) {
+        const int rl = half_rows * half + 32 * i + rl0;
         const long gr = m0 + rl;
         if (gr >= M || gc + 8 > N) continue;
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int k = 0; k < nsplit; ++k) {
-            const float *sp = slabs + ((size_t)(t * nsplit + k) * 256 + rl) * 256 + cl;
+            const float *sp = slabs + ((size_t)(t * nsplit + k) * tile_rows + rl) * 256 + cl;
             const float4 a = *reinterpret_cast<const float4 *>(sp), b = *reinterpret_cast<const float4 *>(sp + 4);
             v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
             v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
@@ -1006,8 +1574,10 @@ __global__ __launch_bounds__(1024) void slab_reduce_gelu_bwd_kernel(const float 
             const act_f2 h2 = {bf16_lo(hu[e]), bf16_hi(hu[e])};
             const act_f2 d2 = act_f2{bf16_lo(vr), bf16_hi(vr)} * (gelu_tanh ? gelu_grad2<true>(h2) : gelu_grad2<false>(h2));
             o[e] = pack_bf16(d2.x, d2.y);
-            cs[2 * e] += bf16_lo(o[e]);
-            cs[2 * e + 1] += bf16_hi(o[e]);
+            if (gr >= m_lo) {
+                cs[2 * e] += bf16_lo(o[e]);
+                cs[2 * e + 1] += bf16_hi(o[e]);
+            }
         }
         *reinterpret_cast<uint4 *>(out16 + gr * ldc + gc) = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -1019,7 +1589,7 @@ __global__ __launch_bounds__(1024) void slab_reduce_gelu_bwd_kernel(const float 
         if (c < N) {
             float tsum = 0.f;
             for (int r = 0; r < 32; ++r) tsum += red[r][threadIdx.x];
-            colpart[((m0 / 128) + half) * N + c] = tsum;
+            colpart[(tile_rows == 256 ? (m0 / 128) + half : 2 * trow + half) * N + c] = tsum;
         }
     }
 }
@@ -1100,6 +1670,20 @@ PPlan plan_persistent(long tiles, int kt_full, bool weight_grad) {
     return p;
 }
 
+// persistent duo schedule: 2 workgroups per CU; the tiles beyond the last full round of 2 x CUs are cut along K (fp32 slabs [item][128][256])
+PPlan plan_duo(long tiles, int kt_full) {
+    PPlan p{tiles, 0, 1, 0};
+    const long G = 2L * num_cus();
+    const long rem = tiles % G;
+    if (tiles > G && rem > 0 && rem <= G / 4 && kt_full >= 4) {
+        long S = G / rem;
+        if (S > kt_full / 2) S = kt_full / 2;
+        if (S >= 2) { p.main_items = tiles - rem; p.tail_tiles = (int)rem; p.tail_splits = (int)S; }
+    }
+    p.slab_bytes = (size_t)p.tail_tiles * p.tail_splits * (gm::BM_DUO * 256) * sizeof(float);
+    return p;
+}
+
 // the persistent kernel, or (XQ_GEMM_TRACE_SUMS with a bound trace buffer; plain NT / NN / TN only) its clock-summing twin
 template <int AK, int BK, int ACT>
 int launch_pring(const GemmArgs &g, long grid, int lds, hipStream_t s) {
@@ -1146,12 +1730,66 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         if (EPI == EPI_BF16 && pl.tail_tiles) {
             if (ACT == ACT_GELU_BWD)
                 hipLaunchKernelGGL(slab_reduce_gelu_bwd_kernel, dim3((unsigned)pl.tail_tiles, 2), dim3(1024), 0, s, (const float *)ws, pl.tail_splits,
-                                   pl.main_items, g.tiles_n, g.M, g.N, g.ldc, (const __hip_bfloat16 *)g.H, (__hip_bfloat16 *)g.C, g.colpart, g.gelu_tanh);
+                                   pl.main_items, g.tiles_n, g.M, g.N, g.ldc, (const __hip_bfloat16 *)g.H, (__hip_bfloat16 *)g.C, g.colpart, g.gelu_tanh, 256, 0);
             else
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
                                    pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
                                    (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L,
-                                   ACT == ACT_GELU_FWD ? (__hip_bfloat16 *)g.C2 : (__hip_bfloat16 *)nullptr, g.gelu_tanh);
+                                   ACT == ACT_GELU_FWD ? (__hip_bfloat16 *)g.C2 : (__hip_bfloat16 *)nullptr, g.gelu_tanh, 256, 0);
+        }
+    } else if (impl == XQ_GEMM_PDUO) {
+        if constexpr (AK == gm::KMAJOR && EPI == EPI_BF16) {
+            if (BN != 256 || g.M < gm::BM_DUO || g.N < 256)
+                return xq_set_error(XQ_EINVAL, "%s: the duo schedules need M >= 128 and N >= 256 (M=%ld N=%ld)", fn, g.M, g.N);
+            g.tiles_m = (int)((g.M + gm::BM_DUO - 1) / gm::BM_DUO);
+            const long dtiles = (long)g.tiles_m * g.tiles_n;
+            PPlan pl = plan_duo(dtiles, g.kt_full);
+            if (pl.slab_bytes > ws_bytes || (pl.slab_bytes && !ws)) pl = PPlan{dtiles, 0, 1, 0};      // no workspace: every tile whole
+            g.main_items = pl.main_items;
+            g.tail_tiles = pl.tail_tiles;
+            g.tail_splits = pl.tail_splits;
+            g.slabs = (float *)ws;
+            const long items = pl.main_items + (long)pl.tail_tiles * pl.tail_splits;
+            if (items > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: too many work items", fn);
+            const long grid = items < 2L * num_cus() ? items : 2L * num_cus();
+            const int lds = 5 * gm::PIECE_BYTES;
+            if (ACT == ACT_NONE && g.trace) {
+                if (set_lds<gemm_pduo_kernel<BK, ACT_NONE, true>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+                hipLaunchKernelGGL((gemm_pduo_kernel<BK, ACT_NONE, true>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+            } else {
+                if (set_lds<gemm_pduo_kernel<BK, ACT>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+                hipLaunchKernelGGL((gemm_pduo_kernel<BK, ACT>), dim3((unsigned)grid), dim3(GT), lds, s, g);
+            }
+            if (pl.tail_tiles) {
+                if (ACT == ACT_GELU_BWD)
+                    hipLaunchKernelGGL(slab_reduce_gelu_bwd_kernel, dim3((unsigned)pl.tail_tiles, 2), dim3(1024), 0, s, (const float *)ws, pl.tail_splits,
+                                       pl.main_items, g.tiles_n, g.M, g.N, g.ldc, (const __hip_bfloat16 *)g.H, (__hip_bfloat16 *)g.C, g.colpart, g.gelu_tanh,
+                                       gm::BM_DUO, 1);
+                else
+                    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, gm::BM_DUO / 8), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
+                                       pl.main_items, g.tiles_n, g.M, g.N, g.ldc, g.bias, (__hip_bfloat16 *)g.C, (float *)nullptr,
+                                       (const __hip_bfloat16 *)nullptr, (const __hip_bfloat16 *)nullptr, 0L, 0L,
+                                       ACT == ACT_GELU_FWD ? (__hip_bfloat16 *)g.C2 : (__hip_bfloat16 *)nullptr, g.gelu_tanh, gm::BM_DUO, 1);
+            }
+        } else {
+            return xq_set_error(XQ_EINVAL, "%s: the duo schedules serve the K-major A operand with the bf16 epilogue only", fn);
+        }
+    } else if (impl == XQ_GEMM_DUO) {
+        if constexpr (AK == gm::KMAJOR && EPI == EPI_BF16) {
+            if (BN != 256 || g.M < gm::BM_DUO || g.N < 256)
+                return xq_set_error(XQ_EINVAL, "%s: the duo schedule needs M >= 128 and N >= 256 (M=%ld N=%ld)", fn, g.M, g.N);
+            g.tiles_m = (int)((g.M + gm::BM_DUO - 1) / gm::BM_DUO);
+            const long total = (long)g.tiles_m * g.tiles_n;
+            const int lds = 5 * gm::PIECE_BYTES;
+            if (ACT == ACT_NONE && g.trace) {
+                if (set_lds<gemm_duo_kernel<BK, ACT_NONE, true>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+                hipLaunchKernelGGL((gemm_duo_kernel<BK, ACT_NONE, true>), dim3((unsigned)total), dim3(GT), lds, s, g);
+            } else {
+                if (set_lds<gemm_duo_kernel<BK, ACT>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+                hipLaunchKernelGGL((gemm_duo_kernel<BK, ACT>), dim3((unsigned)total), dim3(GT), lds, s, g);
+            }
+        } else {
+            return xq_set_error(XQ_EINVAL, "%s: the duo schedule serves the K-major A operand with the bf16 epilogue only", fn);
         }
     } else {
         if (ACT != ACT_NONE) return xq_set_error(XQ_EINVAL, "%s: the fused activation needs the persistent schedule", fn);
@@ -1213,7 +1851,9 @@ extern "C" size_t xq_gemm_bf16_workspace_bytes(int op, int64_t M, int64_t N, int
         const size_t flat = (size_t)tn_splits(kt, tilesbn) * M * N * sizeof(float);
         return compact > flat ? compact : flat;
     }
-    return plan_persistent(tiles256, kt, false).slab_bytes;
+    const size_t a = plan_persistent(tiles256, kt, false).slab_bytes;
+    const size_t b = (M >= gm::BM_DUO && N >= 256) ? plan_duo(((M + gm::BM_DUO - 1) / gm::BM_DUO) * ((N + 255) / 256), kt).slab_bytes : 0;
+    return a > b ? a : b;
 }
 
 extern "C" int xq_gemm_bf16_nt(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *y,
@@ -1244,6 +1884,7 @@ extern "C" int xq_gemm_bf16_nn(const void *g_y, const void *w, int64_t M, int64_
     const int BN = pick_bn(N, impl);
     GemmArgs g{};
     g.nt_store = (impl & XQ_GEMM_PLAIN_STORE) ? 0 : 1;
+    g.debug_no_store = (impl & XQ_GEMM_DEBUG_NO_STORE) ? 1 : 0;
     bind_trace(g, impl);
     impl &= 0xff;
     g.A = (const char *)g_y; g.B = (const char *)w; g.bias = nullptr; g.C = (char *)g_x;
@@ -1288,7 +1929,7 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     if (compact) {
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)tiles, 32), dim3(256), 0, s, (const float *)ws, splits, 0L, g.tiles_n, (long)P,
                            (long)Q, (long)Q, (const float *)nullptr, (__hip_bfloat16 *)nullptr, g_w, (const __hip_bfloat16 *)g_y,
-                           (const __hip_bfloat16 *)x, done, (long)R, (__hip_bfloat16 *)nullptr, 0);
+                           (const __hip_bfloat16 *)x, done, (long)R, (__hip_bfloat16 *)nullptr, 0, 256, 0);
     } else {
         const long quads = (P * Q) / 4;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, (const float *)ws, splits, (long)P,
@@ -1297,7 +1938,29 @@ extern "C" int xq_gemm_bf16_tn(const void *g_y, const void *x, int64_t R, int64_
     return xq_check_launch(fn);
 }
 
-// ---- fused MLP GEMMs (persistent schedule only: N >= 256, K >= 128) -----------------------------------------------------
+// ---- fused MLP GEMMs (persistent / duo schedules: N >= 256, K >= 128) ----------------------------------------------------
+namespace {
+int g_fused_impl = -1;      // -1: not yet read from XQ_GEMM_FUSED_SCHEDULE
+int fused_impl() {
+    if (g_fused_impl < 0) {
+        const char *e = getenv("XQ_GEMM_FUSED_SCHEDULE");
+        g_fused_impl = e ? (int)strtol(e, nullptr, 0) : XQ_GEMM_AUTO;
+    }
+    return g_fused_impl;
+}
+// schedule of a fused product: AUTO = the persistent 256 x 256 schedule; DUO / PDUO where the shape admits them
+int pick_fused(int64_t M, int64_t N) {
+    const int want = fused_impl();
+    if ((want == XQ_GEMM_DUO || want == XQ_GEMM_PDUO) && M >= gm::BM_DUO && N >= 256) return want;
+    return XQ_GEMM_PERSISTENT;
+}
+}  // namespace
+extern "C" int xq_gemm_fused_schedule(int impl) {
+    const int prev = fused_impl();
+    g_fused_impl = impl < 0 ? XQ_GEMM_AUTO : impl;
+    return prev;
+}
+
 extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_t M, int64_t N, int64_t K, void *h, void *h_act,
                                     int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
     const char *fn = "xq_gemm_bf16_nt_gelu";
@@ -1311,10 +1974,11 @@ extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *b
     g.M = M; g.N = N; g.lda = K; g.ldb = K; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
     g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
-    return launch_gemm<gm::KMAJOR, gm::KMAJOR, EPI_BF16, ACT_GELU_FWD>(g, 256, XQ_GEMM_PERSISTENT, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
+    return launch_gemm<gm::KMAJOR, gm::KMAJOR, EPI_BF16, ACT_GELU_FWD>(g, 256, pick_fused(M, N), ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }
 
-extern "C" size_t xq_gemm_colpart_rows(int64_t M) { return M > 0 ? (size_t)(2 * ((M + 255) / 256)) : 0; }
+// one partial row per 128-row block (256-row schedule: 2 per tile) or per 64-row wave tile (duo schedules: 2 per 128-row tile) — the larger count
+extern "C" size_t xq_gemm_colpart_rows(int64_t M) { return M > 0 ? (size_t)(2 * ((M + 127) / 128)) : 0; }
 
 extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h,
                                         float *colpart, int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
@@ -1329,7 +1993,14 @@ extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const vo
     g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
     g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
-    return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16, ACT_GELU_BWD>(g, 256, XQ_GEMM_PERSISTENT, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
+    const int impl = pick_fused(M, N);
+    if (impl == XQ_GEMM_PERSISTENT && colpart) {
+        // the 256-row schedule fills the first 2 * ceil(M / 256) partial rows; the rest of the xq_gemm_colpart_rows(M) rows count as zero
+        const size_t used = (size_t)(2 * ((M + 255) / 256)), all = xq_gemm_colpart_rows(M);
+        if (all > used && hipMemsetAsync(colpart + used * N, 0, (all - used) * N * sizeof(float), (hipStream_t)stream) != hipSuccess)
+            return xq_set_error(XQ_ELAUNCH, "%s: hipMemsetAsync failed", fn);
+    }
+    return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16, ACT_GELU_BWD>(g, 256, impl, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }
 
 // ---- 3x3 convolution as an implicit GEMM on the tile engine (NHWC bf16; Cin % 64 == 0, Cout % 8 == 0, Cout >= 64) -------------

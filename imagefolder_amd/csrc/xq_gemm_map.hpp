@@ -169,6 +169,96 @@ struct StagerAddr {
     GM_HD void step() { cur += adv; }
 };
 
+// ---- 128-row tiles (gemm_duo_kernel: 128 x 256 block tile, two workgroups per CU) ----------------------------------------------------
+// Block tile 128 x 256 x 64, 8 waves as 2 x 4, wave (wr, wc) owns rows [64 wr, +64) and columns [64 wc, +64).  Pieces per K tile: A (piece-row R
+// = tile row R: frag_off_kmajor<true>(wr, f, s, lane) with R = 64 wr + 32 f + lane % 32 reads it unchanged), B-left, B-right (b_rc at WTN = 64,
+// read by frag_off_kmajor<false> / frag_off_kstrided<false> as above).  The LDS images are the ones above; what differs is WHICH wave instruction
+// fills which KiB: instruction (wave, i) writes piece bytes [(8 i + wave) * 1024, +1024), so that the source addresses of a lane's two (A) /
+// four (B: 2 halves x 2) instructions differ by wave-uniform constants — one 32-bit per-lane offset register per operand, everything else is
+// scalar arithmetic on the tile pointer (the 128-VGPR budget of two workgroups per CU has no room for six offset registers):
+//     K-major    piece-row R = 64 i + 8 wave + lane / 8, 16-byte chunk lane % 8 <- source chunk (lane % 8) ^ ((R >> 1) & 7)
+//                i -> +64 rows (A) / +128 columns (B), half -> +32 columns        ((R >> 1) & 7 does not depend on i)
+//     K-strided  k row kr = 32 i + 4 wave + lane / 16, chunk lane % 16 <- source chunk (lane % 16) ^ (4 (kr & 3))
+//                i -> +32 k rows, half -> +32 columns                              (kr & 3 does not depend on i)
+// Ragged edges are handled by moving the last tile row / column BACK inside the matrix (m0 = M - 128, n0 = N - 256): the overlap is
+// computed twice with identical values (same operands, same order), no lane is ever clamped.
+constexpr int BM_DUO = 128;
+GM_HD int duo_stage_dst(int wave, int i, int lane) { return (8 * i + wave) * 1024 + lane * 16; }
+template <int KIND, bool IS_A>
+GM_HD StageSrc duo_stage_src(int half, int wave, int i, int lane) {
+    StageSrc s;
+    if (KIND == KMAJOR) {
+        const int R = 64 * i + 8 * wave + (lane >> 3);
+        s.k = 8 * ((lane & 7) ^ ((R >> 1) & 7));
+        s.rc = IS_A ? R : b_rc(half, R, 64);
+    } else {
+        const int kr = 32 * i + 4 * wave + (lane >> 4);
+        const int c = (lane & 15) ^ (4 * (kr & 3));
+        s.k = kr;
+        s.rc = (c >> 2) * 64 + half * 32 + 8 * (c & 3);
+    }
+    return s;
+}
+// byte offset of the lane's chunk for (half 0, i 0) relative to the tile pointer, and the wave-uniform deltas
+template <int KIND, bool IS_A>
+struct DuoStagerAddr {
+    unsigned voff;          // per lane
+    unsigned d_i, d_half;   // bytes: instruction i = 1, half = 1 (B only)   (32-bit: 128 rows of a matrix row < 2^31 bytes, checked by the launcher)
+    const char *cur;        // tile pointer of the K tile being staged (wave-uniform)
+    unsigned adv;           // bytes per K tile
+    GM_HD void init(const char *mat, long ld, long rc0, long k0, int wave, int lane) {
+        const StageSrc s = duo_stage_src<KIND, IS_A>(0, wave, 0, lane);
+        if (KIND == KMAJOR) {
+            cur = mat + (rc0 * ld + k0) * 2;
+            adv = BKT * 2;
+            voff = (unsigned)(((long)s.rc * ld + s.k) * 2);
+            d_i = (unsigned)((IS_A ? 64 : 128) * ld * 2);
+            d_half = (unsigned)(32 * ld * 2);
+        } else {
+            cur = mat + (k0 * ld + rc0) * 2;
+            adv = (unsigned)((long)BKT * ld * 2);
+            voff = (unsigned)(((long)s.k * ld + s.rc) * 2);
+            d_i = (unsigned)(32 * ld * 2);
+            d_half = 64;
+        }
+    }
+    GM_HD const char *src(int half, int i) const { return cur + (half ? d_half : 0) + (i ? d_i : 0) + voff; }
+};
+
+// ---- work items of the persistent duo schedule (gemm_pduo_kernel; 128 x 256 tiles, two workgroups per CU, grid = 2 x CUs) ------------
+// Same list as decode_item's (whole tiles, then the tail tiles cut along K, tile-major), on 128-row tiles, with the moved-back edge tiles.
+// G: main_items, tail_tiles, tail_splits, tiles_n, kt_full, M, N.  32-bit arithmetic (the launcher checks tiles * splits < 2^31).
+struct DuoItem {
+    int m0, n0, k0;      // output row / column of the tile (moved back inside the matrix at the ragged edges), first reduction index (all < 2^31)
+    int m_lo;            // first row that belongs to THIS tile row (rows [m0, m_lo) are the overlap with the tile row above)
+    int KT;              // K tiles of the item
+    int slab;            // 0: bf16 epilogue into C; 1: fp32 slab [slab_idx][128][256]
+    int slab_idx;
+    int trow;            // tile row (index of the fc1-bias column partials: 2 trow + wave row)
+};
+template <class G>
+GM_HD void decode_item_duo(const G &g, unsigned p, DuoItem &it) {
+    unsigned tile, split, nsplit;
+    if ((long)p < g.main_items) { tile = p; split = 0; nsplit = 1; it.slab = 0; it.slab_idx = 0; }
+    else {
+        const unsigned q = p - (unsigned)g.main_items;
+        nsplit = (unsigned)g.tail_splits;
+        const unsigned tl = q / nsplit;
+        split = q - tl * nsplit;
+        tile = (unsigned)g.main_items + tl;
+        it.slab = 1;
+        it.slab_idx = (int)q;
+    }
+    const unsigned trow = tile / (unsigned)g.tiles_n, tcol = tile - trow * (unsigned)g.tiles_n;
+    it.trow = (int)trow;
+    it.m_lo = (int)trow * BM_DUO;
+    it.m0 = it.m_lo > (int)g.M - BM_DUO ? (int)g.M - BM_DUO : it.m_lo;
+    it.n0 = (int)tcol * 256 > (int)g.N - 256 ? (int)g.N - 256 : (int)tcol * 256;
+    const unsigned base = (unsigned)g.kt_full / nsplit, rem = (unsigned)g.kt_full % nsplit;
+    it.k0 = (int)((split * base + (split < rem ? split : rem)) * BKT);
+    it.KT = (int)(base + (split < rem ? 1 : 0));
+}
+
 // ---- work items of the persistent schedule (gemm_pring_kernel) ----------------------------------------------------------------------
 // Position p of the item list: p < main_items is the whole output tile p (bf16 epilogue); the tail_tiles tiles behind them are cut into
 // tail_splits K ranges each, one item per range (fp32 slab [tile][split]), executed tile-major or split-major.  G = any struct with the

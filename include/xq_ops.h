@@ -468,6 +468,10 @@ int xq_groupnorm_silu_f32(const float *x, const float *w, const float *bias, int
 #define XQ_GEMM_RING 2       /* 8-slot LDS-DMA ring, counted vmcnt, staggered wave rows; one workgroup per tile              */
 #define XQ_GEMM_PERSISTENT 3 /* the ring kept streaming across a per-CU list of work items; tail tiles / weight gradients
                                 cut along K into fp32 slabs (256-column tiles, >= 2 K tiles per item)                       */
+#define XQ_GEMM_DUO 4        /* round 6: 128 x 256 tiles, two workgroups per CU (4 waves per SIMD), 5-slot LDS-DMA ring, one workgroup per
+                                tile: one workgroup's store burst / prologue runs under the other's K loop (NT / NN, N >= 256)            */
+#define XQ_GEMM_PDUO 5       /* round 6: the duo schedule kept streaming across a per-workgroup list of work items (grid = 2 workgroups per CU),
+                                fragment reads software-pipelined under the MFMAs, tail tiles cut along K into fp32 slabs                       */
 #define XQ_GEMM_WIDE_TILES 0x100 /* OR-ed into impl: 256-column tiles even when N is not a multiple of 256 (ragged last tile) */
 #define XQ_GEMM_DEBUG_NO_STORE 0x200 /* OR-ed into impl (NT, persistent schedule): skip the output stores — timing experiments, result unusable */
 #define XQ_GEMM_TILE_MAJOR 0x400 /* OR-ed into impl (TN, persistent schedule): execute the K-split items tile-major instead of split-major (A/B timing) */
@@ -506,9 +510,13 @@ int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_
                          int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 /* data gradient of fc2 with the GELU derivative in the epilogue: g_h[M][N] = (g_y[M][K] . w[K][N]) * GELU'(h[M][N]) (the product
  * rounded to bf16 before the multiplication, as the unfused pair does); colpart (nullable) fp32 [xq_gemm_colpart_rows(M)][N]
- * receives the column sums of g_h per 128-row block: their sum over the rows is the fc1 bias gradient.  workspace:
+ * receives partial column sums of g_h (per 128-row block or per 64-row wave tile, unused rows zero): their sum over the rows is the fc1 bias gradient.  workspace:
  * xq_gemm_bf16_workspace_bytes(XQ_GEMM_OP_NN, M, N, K) bytes, used as in xq_gemm_bf16_nt_gelu. */
 size_t xq_gemm_colpart_rows(int64_t M);
+/* schedule of the two fused MLP products (XQ_GEMM_AUTO / _PERSISTENT / _DUO / _PDUO; default: environment XQ_GEMM_FUSED_SCHEDULE, else AUTO);
+ * returns the previous value.  Tests and benchmarks; every schedule writes the same h / h_act / g_h bits (K-split tail tiles: up to the fp32
+ * summation order) and colpart rows whose column sums agree to the summation order. */
+int xq_gemm_fused_schedule(int impl);
 int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h, float *colpart,
                              int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 /* 3x3 convolution on the GEMM tile engine (implicit GEMM: the A operand is gathered from the NHWC image tap by tap by the

@@ -163,6 +163,95 @@ static void run(int BN, unsigned seed) {
     std::printf("AK=%d BK=%d BN=%d: %s; bank-conflict cycles: b128 %ld, tr %ld\n", AK, BK, BN, g_fail ? "FAIL" : "ok", g_conf_b128, g_conf_tr);
 }
 
+// ---- duo schedule (128 x 256 tiles): the staging goes through gm::DuoStagerAddr's own address arithmetic (tile pointer + wave-uniform
+// deltas + ONE per-lane offset) on a real matrix in memory, ragged edges by moving the last tile back inside the matrix; then fragment reads,
+// MFMA lane layout and the accumulator -> (row, column) map of the epilogue (epi_write_off / epi_read_map at WTN = 64, two 32-row passes)
+template <int BK>
+static void run_duo(long M, long N, long K, long trow, long tcol, unsigned seed) {
+    const long lda = K, ldb = (BK == KMAJOR) ? K : N;
+    std::vector<int16_t> A((size_t)M * K), B((size_t)N * K);
+    srand(seed);
+    for (auto &x : A) x = (int16_t)(rand() % 7 - 3);
+    for (auto &x : B) x = (int16_t)(rand() % 5 - 2);
+    auto bat = [&](long n, long k) { return BK == KMAJOR ? B[(size_t)n * K + k] : B[(size_t)k * N + n]; };
+    long m0 = trow * BM_DUO, n0 = tcol * 256;
+    if (m0 > M - BM_DUO) m0 = M - BM_DUO;
+    if (n0 > N - 256) n0 = N - 256;
+    std::vector<int> acc((size_t)8 * 2 * 2 * 64 * 16, 0);
+    const int fail0 = g_fail;
+    for (long kt = 0; kt < K / 64; ++kt) {
+        Piece pa, pb[2];
+        std::vector<int> wa(PIECE_BYTES / 16, 0), wb0(PIECE_BYTES / 16, 0), wb1(PIECE_BYTES / 16, 0);
+        for (int wave = 0; wave < 8; ++wave)
+            for (int lane = 0; lane < 64; ++lane) {
+                DuoStagerAddr<KMAJOR, true> sa;
+                DuoStagerAddr<BK, false> sb;
+                sa.init((const char *)A.data(), lda, m0, 0, wave, lane);
+                sb.init((const char *)B.data(), ldb, n0, 0, wave, lane);
+                for (long t = 0; t < kt; ++t) { sa.cur += sa.adv; sb.cur += sb.adv; }
+                for (int i = 0; i < 2; ++i) {
+                    const int dst = duo_stage_dst(wave, i, lane);
+                    std::memcpy(&pa.e[dst / 2], sa.src(0, i), 16);
+                    wa[dst / 16]++;
+                    for (int h = 0; h < 2; ++h) {
+                        std::memcpy(&pb[h].e[dst / 2], sb.src(h, i), 16);
+                        (h ? wb1 : wb0)[dst / 16]++;
+                    }
+                    // the map the addresses implement
+                    const StageSrc s = duo_stage_src<KMAJOR, true>(0, wave, i, lane);
+                    if (sa.src(0, i) != (const char *)&A[(size_t)(m0 + s.rc) * K + kt * 64 + s.k]) { if (g_fail++ < 5) std::printf("duo A address != map\n"); }
+                }
+            }
+        for (size_t c = 0; c < wa.size(); ++c)
+            if (wa[c] != 1 || wb0[c] != 1 || wb1[c] != 1) { g_fail++; std::printf("duo stage: chunk written %d/%d/%d times\n", wa[c], wb0[c], wb1[c]); break; }
+        for (int wave = 0; wave < 8; ++wave) {
+            const int wr = wave >> 2, wc = wave & 3;
+            for (int s = 0; s < 4; ++s)
+                for (int fi = 0; fi < 2; ++fi)
+                    for (int fj = 0; fj < 2; ++fj) {
+                        int16_t af[64][8], bf[64][8];
+                        read_frag<KMAJOR, true>(pa, wr, fi, s, af);
+                        read_frag<BK, false>(pb[fj], wc, 0, s, bf);
+                        for (int lane = 0; lane < 64; ++lane)
+                            for (int r = 0; r < 16; ++r) {
+                                const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), j = lane & 31;
+                                int sum = 0;
+                                for (int k = 0; k < 16; ++k) sum += (int)bf[i + 32 * (k / 8)][k % 8] * (int)af[j + 32 * (k / 8)][k % 8];
+                                acc[((((size_t)wave * 2 + fi) * 2 + fj) * 64 + lane) * 16 + r] += sum;
+                            }
+                    }
+        }
+    }
+    // epilogue: 32 rows x 64 columns per pass through 4 KiB
+    std::vector<long> C((size_t)BM_DUO * 256, 0x7fffffff);
+    for (int wave = 0; wave < 8; ++wave) {
+        const int wr = wave >> 2, wc = wave & 3;
+        for (int fi = 0; fi < 2; ++fi) {
+            std::vector<int> region(2048, 0x7fffffff);      // 4 KiB as 16-bit slots holding ints
+            for (int fj = 0; fj < 2; ++fj)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int q = 0; q < 4; ++q) {
+                        const int off = epi_write_off(0, fj, q, lane, 64);
+                        for (int e = 0; e < 4; ++e) region[off / 2 + e] = acc[((((size_t)wave * 2 + fi) * 2 + fj) * 64 + lane) * 16 + 4 * q + e];
+                    }
+            for (int it = 0; it < 4; ++it)
+                for (int lane = 0; lane < 64; ++lane) {
+                    int row, c, off;
+                    epi_read_map(it, lane, 64, &row, &c, &off);
+                    for (int e = 0; e < 8; ++e) C[(size_t)(64 * wr + 32 * fi + row) * 256 + 64 * wc + 8 * c + e] = region[off / 2 + e];
+                }
+        }
+    }
+    for (int m = 0; m < BM_DUO; ++m)
+        for (int n = 0; n < 256; ++n) {
+            long want = 0;
+            for (long k = 0; k < K; ++k) want += (long)A[(size_t)(m0 + m) * K + k] * (long)bat(n0 + n, k);
+            if (C[(size_t)m * 256 + n] != want && g_fail < 10) { g_fail++; std::printf("duo C[%d][%d] = %ld, want %ld (BK %d)\n", m, n, C[(size_t)m * 256 + n], want, BK); }
+        }
+    std::printf("duo BK=%d M=%ld N=%ld K=%ld tile (%ld, %ld): %s; bank-conflict cycles: b128 %ld, tr %ld\n", BK, M, N, K, trow, tcol, g_fail == fail0 ? "duo-ok" : "FAIL",
+                g_conf_b128, g_conf_tr);
+}
+
 // ---- work items of the persistent schedule --------------------------------------------------------------------------------------------
 // Replays every workgroup's item list (positions cp, cp + G, ... with cp = xcd_order(block, G)) for the plans csrc/xq_gemm.hip makes
 // (plan_persistent is restated here: whole tiles for the full rounds of CUs, the remainder cut along K; weight gradient: every tile cut),
@@ -347,6 +436,11 @@ int main() {
         run<KMAJOR, KSTRIDED>(BN, 2);
         run<KSTRIDED, KSTRIDED>(BN, 3);
     }
+    // duo schedule: interior tile, ragged last tile row (M = 300: rows 172..299), ragged last tile column (N = 384: columns 128..383)
+    run_duo<KMAJOR>(256, 512, 128, 1, 1, 4);
+    run_duo<KSTRIDED>(256, 512, 128, 0, 1, 5);
+    run_duo<KMAJOR>(300, 384, 192, 2, 1, 6);
+    run_duo<KSTRIDED>(300, 384, 192, 2, 1, 7);
     // tile order is a bijection for awkward totals
     for (long total : {1L, 7L, 8L, 9L, 771L, 2313L, 3084L, 252L}) {
         std::vector<int> seen(total, 0);

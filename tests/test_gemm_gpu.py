@@ -10,7 +10,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SIMPLE, RING, PERSISTENT = 1, 2, 3      # include/xq_ops.h XQ_GEMM_*
+SIMPLE, RING, PERSISTENT, DUO, PDUO = 1, 2, 3, 4, 5      # include/xq_ops.h XQ_GEMM_*
 
 
 def _ops():
@@ -175,6 +175,120 @@ def test_persistent_schedule_race_screen(op, M, N, K):
     else:
         scale = base.float().abs().max().item()
         assert (outs[0].float() - base.float()).abs().max().item() <= 2.0 ** -7 * scale
+
+
+# ---- round 6: the duo schedule (128 x 256 tiles, two workgroups per CU) ----------------------------------------------------------------
+# ragged M (moved-back last tile row), ragged N (moved-back last tile column: 384 = 128 + 256, 1152), one K tile (K = 64), the bench shapes
+DUO_SHAPES = [(128, 256, 64), (256, 256, 128), (300, 256, 128), (513, 768, 768), (2052, 2304, 768), (2052, 768, 3072), (2056, 3072, 768),
+              (788, 384, 384), (788, 1152, 384), (788, 384, 1536), (22300, 768, 768), (51400, 768, 128), (131, 264, 192)]
+
+
+def _duo_has_tail(M, N, K):
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    tiles, G = -(-M // 128) * -(-N // 256), 2 * cus
+    rem = tiles % G
+    return tiles > G and 0 < rem <= G // 4 and K // 64 >= 4
+
+
+@pytest.mark.parametrize("op", ["nt", "nn"])
+@pytest.mark.parametrize("M,N,K", DUO_SHAPES)
+def test_gemm_duo_equals_simple_bit_for_bit(M, N, K, op):
+    """Same MFMA order per accumulator as the barrier-per-tile schedule -> identical bits (incl. the rows / columns that the moved-back
+    last tiles compute twice), and inside the fp32-reference bound."""
+    od = _ops()
+    if op == "nt":
+        a, b = _rand((M, K), 21), _rand((N, K), 22, 0.05)
+        bias = torch.randn(N, device="cuda")
+        run = lambda: od.gemm_nt(a, b, bias)
+        ref, absprod = a.float() @ b.float().t() + bias, a.float().abs() @ b.float().abs().t() + bias.abs()
+    else:
+        a, b = _rand((M, K), 23), _rand((K, N), 24, 0.05)
+        run = lambda: od.gemm_nn(a, b)
+        ref, absprod = a.float() @ b.float(), a.float().abs() @ b.float().abs()
+    try:
+        od.GEMM_SCHEDULE = SIMPLE
+        base = run()
+        od.GEMM_SCHEDULE = DUO
+        outs = [run() for _ in range(6)]
+    finally:
+        od.GEMM_SCHEDULE = 0
+    torch.cuda.synchronize()
+    _check_bf16(outs[0], ref, absprod)
+    for i, o in enumerate(outs):
+        assert torch.equal(o, base), f"launch {i}: {(o != base).sum().item()} entries differ from the simple schedule"
+
+
+@pytest.mark.parametrize("sched", [DUO, PDUO])
+@pytest.mark.parametrize("op", ["nt", "nn"])
+@pytest.mark.parametrize("M,N,K", [(65664, 2304, 768), (65664, 768, 3072), (65664, 3072, 768), (65664, 768, 768), (25216, 1536, 384)])
+def test_duo_schedule_race_screen(op, M, N, K, sched):
+    """24 back-to-back launches on the bench shapes (two workgroups per CU, counted vmcnt across barriers, fragment reads in flight across the
+    barriers; persistent form: the item boundary): bit-identical to each other and to the ring schedule's whole tiles."""
+    od = _ops()
+    if op == "nn":
+        a, b = _rand((M, K), 7), _rand((K, N), 8, 0.05)
+        run = lambda: od.gemm_nn(a, b)
+    else:
+        a, b = _rand((M, K), 7), _rand((N, K), 8, 0.05)
+        bias = torch.randn(N, device="cuda")
+        run = lambda: od.gemm_nt(a, b, bias)
+    try:
+        od.GEMM_SCHEDULE = RING
+        base = run()
+        od.GEMM_SCHEDULE = sched
+        outs = [run() for _ in range(24)]
+    finally:
+        od.GEMM_SCHEDULE = 0
+    torch.cuda.synchronize()
+    if sched == PDUO and _duo_has_tail(M, N, K):      # K-split tail tiles: fp32 summation order differs from whole tiles
+        for i, o in enumerate(outs):
+            assert torch.equal(o, outs[0]), f"launch {i} differs from launch 0"
+        scale = base.float().abs().max().item()
+        assert (outs[0].float() - base.float()).abs().max().item() <= 2.0 ** -7 * scale
+        return
+    for i, o in enumerate(outs):
+        assert torch.equal(o, base), f"launch {i}: {(o != base).sum().item()} entries differ from the ring schedule"
+
+
+@pytest.mark.parametrize("op", ["nt", "nn"])
+@pytest.mark.parametrize("M,N,K", DUO_SHAPES + [(65664, 2304, 768), (65664, 768, 3072), (65664, 3072, 768), (65664, 768, 768), (25216, 1536, 384), (65792, 768, 768),
+                                               (66000, 768, 256)])
+def test_gemm_persistent_duo(M, N, K, op):
+    """XQ_GEMM_PDUO: the duo K loop inside a per-workgroup item loop (2 workgroups per CU).  Whole tiles are bit-identical to the simple schedule; where
+    the tiles beyond the last full round are cut along K (fp32 slabs + slab_reduce_kernel on 128-row tiles) the result differs by the fp32
+    summation order only; 12 back-to-back launches are bit-identical to each other (race screen of the item boundary)."""
+    od = _ops()
+    if op == "nt":
+        a, b = _rand((M, K), 31), _rand((N, K), 32, 0.05)
+        bias = torch.randn(N, device="cuda")
+        run = lambda: od.gemm_nt(a, b, bias)
+        ref, absprod = a.float() @ b.float().t() + bias, a.float().abs() @ b.float().abs().t() + bias.abs()
+    else:
+        a, b = _rand((M, K), 33), _rand((K, N), 34, 0.05)
+        run = lambda: od.gemm_nn(a, b)
+        ref, absprod = a.float() @ b.float(), a.float().abs() @ b.float().abs()
+    try:
+        od.GEMM_SCHEDULE = SIMPLE
+        base = run()
+        od.GEMM_SCHEDULE = PDUO
+        outs = [run() for _ in range(12)]
+    finally:
+        od.GEMM_SCHEDULE = 0
+    torch.cuda.synchronize()
+    _check_bf16(outs[0], ref, absprod)
+    for i, o in enumerate(outs):
+        assert torch.equal(o, outs[0]), f"launch {i} differs from launch 0 in {(o != outs[0]).sum().item()} entries"
+    if _duo_has_tail(M, N, K):
+        scale = base.float().abs().max().item()
+        assert (outs[0].float() - base.float()).abs().max().item() <= 2.0 ** -7 * scale
+        # the whole tiles (everything in front of the tail tiles' first row) are bit-identical
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        tiles_n = -(-N // 256)
+        main = (-(-M // 128) * tiles_n) // (2 * cus) * (2 * cus)
+        rows = (main // tiles_n) * 128
+        assert torch.equal(outs[0][:rows], base[:rows])
+    else:
+        assert torch.equal(outs[0], base), f"{(outs[0] != base).sum().item()} entries differ from the simple schedule"
 
 
 @pytest.mark.parametrize("op", ["nt", "nn", "tn"])

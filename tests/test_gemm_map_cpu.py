@@ -23,4 +23,5 @@ def test_gemm_maps_and_item_lists_replay_on_the_cpu(tmp_path):
     assert out.returncode == 0 and out.stdout.strip().endswith("ALL OK"), out.stdout[-2000:]
     assert out.stdout.count(": ok;") == 6 and "item lists:" in out.stdout
     assert "bank-conflict cycles: b128 0, tr 0" in out.stdout
+    assert out.stdout.count("duo-ok; bank-conflict cycles: b128 0, tr 0") == 4      # round 6: 128 x 256 tiles, uniform-delta staging, ragged edges moved back
     assert out.stdout.count("addresses compared, ok") == 10      # staging address streams: scalar cursor == base + kt * adv

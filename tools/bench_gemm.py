@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--layers", nargs="*", default=None, help="subset of qkv proj fc1 fc2")
     ap.add_argument("--no-library", action="store_true", help="skip the hipBLASLt rows (counter-collection runs)")
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--rounds", type=int, default=1, help="> 1: interleaved rounds over all cases of a layer, median (and best) per case (cdna_hip_programming.md 5.4 rule 24)")
     a = ap.parse_args()
     lines = []
 
@@ -58,7 +59,7 @@ def main():
                     ("gx   library mm", lambda: torch.mm(g, w)),
                     ("gW   library bmm S=16 + sum", (lambda: od._weight_grad(g, x, torch.float32))),
                 ]
-                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)"}.get(int(x, 0), x)) for x in a.scheds]:
+                for sched, tag in [(int(x, 0), {1: "simple", 2: "ring", 3: "persistent", 4: "duo", 5: "persistent duo", 0x103: "persistent wide", 0x102: "ring wide", 0x203: "persistent NO-STORE (debug)", 0x803: "persistent plain stores", 0x403: "persistent tile-major items (old order)"}.get(int(x, 0), x)) for x in a.scheds]:
                     def mk(f, sched=sched):
                         def run():
                             od.GEMM_SCHEDULE = sched
@@ -71,8 +72,9 @@ def main():
                         (f"fwd  hip nt {tag}", mk(lambda: od.gemm_nt(x, w, bias))),
                         (f"fwd  hip nt NO BIAS {tag}", mk(lambda: od.gemm_nt(x, w, None))),
                         (f"gx   hip nn {tag}", mk(lambda: od.gemm_nn(g, w))),
-                        (f"gW   hip tn {tag}", mk(lambda: od.gemm_tn(g, x))),
                     ]
+                    if (sched & 0xff) not in (4, 5):      # the duo schedule serves NT / NN only
+                        cases.append((f"gW   hip tn {tag}", mk(lambda: od.gemm_tn(g, x))))
                 if a.only:
                     key = {"nt": "fwd", "nn": "gx", "tn": "gW"}[a.only]
                     cases = [c for c in cases if c[0].startswith(key)]
@@ -82,6 +84,19 @@ def main():
                     except Exception:  # noqa: BLE001
                         pass
                 torch.cuda.synchronize()
+                if a.rounds > 1:
+                    import statistics
+                    ts = {label: [] for label, _ in cases}
+                    for _ in range(a.rounds):
+                        for label, fn in cases:
+                            try:
+                                ts[label].append(timeit(fn, iters=a.iters, warm=1))
+                            except Exception as e:  # noqa: BLE001
+                                ts[label].append(float("nan"))
+                    for label, _ in cases:
+                        med, mn = statistics.median(ts[label]), min(ts[label])
+                        emit(f"D{D} M{M} {name:5s} N{N:5d} K{K:5d} {label:44s} median {med:8.3f} ms {fl / med / 1e9:8.1f} TF/s   best {fl / mn / 1e9:8.1f} TF/s")
+                    continue
                 for label, fn in cases:
                     try:
                         ms = timeit(fn, iters=a.iters)

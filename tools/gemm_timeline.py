@@ -56,6 +56,8 @@ def sums_case(fn, fl, ref, a, emit):
         n = max(1, int(tr[w, 8]))
         load, bar1, mfma, bar2 = (tr[w, 9 + i] / n for i in range(4))
         emit(f"    wave {w} ({w >> 2}, {w & 3})     {int(tr[w, 8]):8d}{int(tr[w, 13]):7d}{load:9.0f}{bar1:9.0f}{mfma:9.0f}{bar2:9.0f}{load + bar1 + mfma + bar2:9.0f}")
+    if tr[0, 15] > 0:
+        emit(f"    shader clock over the traced workgroup's life (s_memtime / s_memrealtime): {tr[0, 14] / tr[0, 15] * 100.0:6.0f} MHz")
     n = max(1, int(tr[0, 8]))
     per_tile = 2.0 * sum(tr[0, 9 + i] for i in range(4)) / n
     emit(f"    K tile period {per_tile:7.0f} cycles  ->  MFMA-pipe utilisation {2048 / per_tile:5.2f}")
