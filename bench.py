@@ -274,6 +274,51 @@ def _first_collective_with_watchdog(dev, rank, world, groups, seconds):
     done.set()
 
 
+# ---- PMC traffic per roofline entry --------------------------------------------------------------------------------------------------
+# Every roofline entry carries the library's profiling kind (include/xq_ops.h XQ_PROF_*; 0 = the code search); TRAFFIC_KEYS maps a kind to
+# the rows of profiles/rNN_kernel_hbm_traffic.json (tools/pmc_traffic.py: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 read
+# correction) whose bytes are this entry's kernels', and to the prefix of its rows in rNN_kernel_hbm_traffic_shapes.json.  An entry whose kernels
+# the profile does not cover keeps "traffic": null (round 5 attached the code search's 15 MB to every HBM-bound entry).
+TRAFFIC_KEYS = {0: (["assign"], "assign"), 1: (["conv3x3"], "conv3x3"), 2: (["attn_fwd"], "attention fwd"),
+                3: (["attn_bwd_dkdv", "attn_bwd_dq"], "attention bwd"), 4: (["gemm"], "gemm"), 5: (["res_ln_fwd"], "res_ln fwd"),
+                6: (["res_ln_bwd"], "res_ln bwd"), 7: (["adamw_ema"], "adamw_ema"), 8: (["gn"], "groupnorm"), 9: (["vq_elem"], "vq element-wise"),
+                10: (["conv3x3_from3"], "conv3x3_from3")}
+
+
+def load_traffic_profiles():
+    """(kernels, per-shape ratios, source path) of the newest committed PMC traffic profile; empty when there is none"""
+    for rnd in ("r06", "r05"):
+        tf = os.path.join(ROOT, "profiles", f"{rnd}_kernel_hbm_traffic.json")
+        try:
+            with open(tf) as fh:
+                traffic = json.load(fh).get("kernels", {})
+        except (OSError, ValueError):
+            continue
+        shape_ratio = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", f"{rnd}_kernel_hbm_traffic_shapes.json")) as fh:
+                shape_ratio = {c["case"]: round(c["traffic_over_algorithmic"], 3) for c in json.load(fh).get("cases", [])
+                               if "traffic_over_algorithmic" in c}
+        except (OSError, ValueError, KeyError):
+            pass
+        return traffic, shape_ratio, os.path.relpath(tf, ROOT)
+    return {}, {}, None
+
+
+def attach_traffic(entries, traffic, shape_ratio, traffic_src):
+    """entry["traffic"] = PMC bytes per launch of the entry's OWN kernels (null without a row for every one of them)"""
+    for e in entries:
+        keys, prefix = TRAFFIC_KEYS.get(e.get("prof_kind"), ([], None))
+        if not keys or not all(k in traffic for k in keys):
+            e["traffic"] = None
+            continue
+        e["traffic"] = sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)
+        e["traffic_source"] = f"{traffic_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, average bytes per launch; per-shape rows in the file)"
+        e["traffic_note"] = ("fabric-side bytes: requests the eight L2s sent to the Infinity Fabric (they include Infinity-Cache hits) — an "
+                             "UPPER bound on HBM bytes, MI355X_MICROARCH.md §HBM; collected on a committed profile of this workload, not in this run")
+        e["traffic_over_algorithmic_by_shape"] = {k: v for k, v in shape_ratio.items() if k.startswith(prefix)}
+
+
 def main():
     args = parse()
     # XQ_FORCE_RESPAWN=1: take the self-spawn path at --gpus 1 too (tests/test_train_arena_gpu.py drives it on the 1-GPU box)
@@ -455,7 +500,7 @@ def main():
         k_ms, k_n, k_work = ctypes.c_double(0.0), ctypes.c_int(0), ctypes.c_double(0.0)
         lib.xq_prof_collect_kind(kind, ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_work))
         if k_n.value:
-            kinds[name] = (k_ms.value, k_n.value, k_work.value)
+            kinds[name] = (k_ms.value, k_n.value, k_work.value, kind)
     # HBM-bound hand-written kernels (round 5): algorithmic BYTES per launch recorded by the library next to the same HIP-event pairs
     hbm_kinds = {}
     for kind, name, per in ((5, "res_ln_fwd_kernel (residual + LayerScale + DropPath + LayerNorm rows)", "12 B/elem at bf16 activations: x 4 + y 2 read, x_new 4 + LN output 2 written"),
@@ -467,7 +512,7 @@ def main():
         k_ms, k_n, k_work = ctypes.c_double(0.0), ctypes.c_int(0), ctypes.c_double(0.0)
         lib.xq_prof_collect_kind(kind, ctypes.byref(k_ms), ctypes.byref(k_n), ctypes.byref(k_work))
         if k_n.value:
-            hbm_kinds[name] = (k_ms.value, k_n.value, k_work.value, per)
+            hbm_kinds[name] = (k_ms.value, k_n.value, k_work.value, per, kind)
     lib.xq_prof_collect(ctypes.byref(ms_tot), ctypes.byref(n_launch))
     lib.xq_prof_enable(0)
 
@@ -531,42 +576,24 @@ def main():
         entries = [{"bound": "mfma", "kernel": f"assign_kernel<C={CFG['C']}> (v_mfma_f32_32x32x2_f32, quantizer code search)",
                     "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None, "flops_per_launch": flops,
-                    "avg_launch_ms": k_ms, "launches": n_launch.value, "ms_per_step": ms_tot.value / prof_steps}]
-        for name, (t_ms, n, work) in kinds.items():
+                    "avg_launch_ms": k_ms, "launches": n_launch.value, "ms_per_step": ms_tot.value / prof_steps, "prof_kind": 0}]
+        for name, (t_ms, n, work, kind) in kinds.items():
             ach = work / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
             entries.append({"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s",
                             "frac": ach / PEAK_BF16_MFMA_TFLOPS, "traffic": None, "flops_per_launch": work / n,
-                            "avg_launch_ms": t_ms / n, "launches": n, "ms_per_step": t_ms / prof_steps})
-        for name, (t_ms, n, work, per) in hbm_kinds.items():
+                            "avg_launch_ms": t_ms / n, "launches": n, "ms_per_step": t_ms / prof_steps, "prof_kind": kind})
+        for name, (t_ms, n, work, per, kind) in hbm_kinds.items():
             ach = work / (t_ms * 1e-3) / 1e9 if t_ms > 0 else 0.0
             entries.append({"bound": "hbm", "kernel": name, "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
                             "traffic": None, "bytes_per_launch": work / n, "algorithmic_bytes": per, "avg_launch_ms": t_ms / n, "launches": n,
-                            "ms_per_step": t_ms / prof_steps})
+                            "ms_per_step": t_ms / prof_steps, "prof_kind": kind})
         # HBM bytes per launch from the committed rocprofv3 PMC passes of this same command (FETCH_SIZE / WRITE_SIZE, separate
         # passes, gfx950 read correction applied: tools/pmc_traffic.py); null when that profile does not cover the kernel
-        traffic, shape_ratio, traffic_src = {}, {}, None
-        try:
-            tf = os.path.join(ROOT, "profiles", "r05_kernel_hbm_traffic.json")       # PMC passes over THIS round's kernels
-            with open(tf) as fh:
-                traffic = json.load(fh).get("kernels", {})
-            traffic_src = os.path.relpath(tf, ROOT)
-            with open(os.path.join(ROOT, "profiles", "r05_kernel_hbm_traffic_shapes.json")) as fh:
-                shape_ratio = {c["case"]: round(c["traffic_over_algorithmic"], 3) for c in json.load(fh).get("cases", [])
-                               if "traffic_over_algorithmic" in c}
-        except (OSError, ValueError, KeyError):
-            shape_ratio = {}
+        traffic, shape_ratio, traffic_src = load_traffic_profiles()
         if full and CFG["name"] == "VQ-8192" and B == 128:   # the profile was taken on this workload
-            for e in entries:
-                keys = (["conv3x3"] if e["kernel"].startswith("conv3x3") else ["attn_fwd"] if e["kernel"].startswith("attn_fwd")
-                        else ["attn_bwd_dkdv", "attn_bwd_dq"] if e["kernel"].startswith("attn_bwd_dq")
-                        else ["gemm"] if e["kernel"].startswith("gemm") else ["assign"])
-                if all(k in traffic for k in keys):
-                    e["traffic"] = sum(traffic[k]["hbm_bytes_per_launch"] for k in keys)
-                    e["traffic_source"] = traffic_src + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, average bytes per launch; per-shape rows in the file)"
-                    e["traffic_note"] = ("fabric-side bytes: requests the eight L2s sent to the Infinity Fabric (they include Infinity-Cache hits) — an "
-                                         "UPPER bound on HBM bytes, MI355X_MICROARCH.md §HBM; collected on this round's kernels")
-                    pre = "gemm" if keys == ["gemm"] else "attention" if keys[0].startswith("attn") else "conv3x3" if keys == ["conv3x3"] else "assign"
-                    e["traffic_over_algorithmic_by_shape"] = {k: v for k, v in shape_ratio.items() if k.startswith(pre)}
+            attach_traffic(entries, traffic, shape_ratio, traffic_src)
+        for e in entries:
+            e.pop("prof_kind", None)
         entries.sort(key=lambda e: -e["ms_per_step"])
         out["roofline"] = dict(entries[0], note="kernel family with the most GPU time in the timed region (every MFMA kernel of "
                                                 "the step is hand-written and instrumented: HIP events on its launch stream); "

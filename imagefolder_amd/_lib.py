@@ -10,6 +10,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libxq_ops.so")
+ABI_VERSION = 3      # include/xq_ops.h XQ_ABI_VERSION
 
 c_f32p = ctypes.POINTER(ctypes.c_float)
 c_i64p = ctypes.POINTER(ctypes.c_int64)
@@ -164,6 +165,9 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        if l.xq_abi_version() != ABI_VERSION:
+            raise XqError(f"{LIB_PATH} has C-ABI version {l.xq_abi_version()}, this package expects {ABI_VERSION} (include/xq_ops.h XQ_ABI_VERSION): "
+                          "stale build — rebuild with `python -c 'import __graft_entry__ as g; g.build()'`")
         _lib = l
     return _lib
 

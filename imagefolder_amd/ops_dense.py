@@ -255,6 +255,7 @@ def _weight_grad(g2, x2, wdtype):
 # configuration of the reference).  GEMM_IMPL is not a user switch: there is no environment variable behind it; the A/B harness
 # tools/library_backend.py (hipBLASLt timings, the flop-counting pass of bench.py) flips it programmatically and restores it.
 import os as _os
+import threading as _threading
 GEMM_IMPL = "hip"
 GEMM_SCHEDULE = int(_os.environ.get("XQ_GEMM_SCHEDULE", "0"), 0)   # include/xq_ops.h XQ_GEMM_*: 0 auto; schedule / A-B bits for tools + tests
 
@@ -309,11 +310,11 @@ class LinearFn(torch.autograd.Function):
 
     # grad mode of the CALLER (inside forward() autograd has switched it off; and it reports needs_input_grad for a parameter under
     # no_grad too): what tells fp32 inference — the exact-fp32 kernel, nothing saved — from an fp32 training step
-    _caller_grad = True
+    _tls = _threading.local()       # per thread (round 5 kept it on the class: a forward under no_grad on another thread flipped a training forward)
 
     @classmethod
     def apply(cls, *args, **kwargs):
-        LinearFn._caller_grad = torch.is_grad_enabled()
+        LinearFn._tls.caller_grad = torch.is_grad_enabled()
         return super(LinearFn, cls).apply(*args, **kwargs)
 
     @staticmethod
@@ -353,7 +354,7 @@ class LinearFn(torch.autograd.Function):
             b = None if bias is None else bias.detach()
             from . import ops_f32
             # (inference is "the caller runs without gradient mode OR nothing wants one")
-            if x2.is_cuda and x2.dtype == torch.float32 and (not LinearFn._caller_grad or not any(ctx.needs_input_grad)) \
+            if x2.is_cuda and x2.dtype == torch.float32 and (not getattr(LinearFn._tls, "caller_grad", True) or not any(ctx.needs_input_grad)) \
                     and not torch.is_autocast_enabled("cuda") and x2.numel():
                 # fp32 inference (the reference-parity path): exact fp32 MFMA product, no library call
                 nn_ops.IMPL["linear_fp32_inference"] = "hip (xq_conv2d_f32_nhwc as a 1x1 convolution: fp32 MFMA)"
@@ -439,11 +440,11 @@ class MlpFn(torch.autograd.Function):
     residual + LayerNorm backward that produces g_f (same arrangement as LinearFn(bias_grad_external=True))."""
 
     # grad mode of the CALLER (see LinearFn): a forward no backward follows does not keep — and the kernel does not write — the pre-activation h
-    _caller_grad = True
+    _tls = _threading.local()
 
     @classmethod
     def apply(cls, *args, **kwargs):
-        MlpFn._caller_grad = torch.is_grad_enabled()
+        MlpFn._tls.caller_grad = torch.is_grad_enabled()
         return super(MlpFn, cls).apply(*args, **kwargs)
 
     @staticmethod
@@ -455,7 +456,7 @@ class MlpFn(torch.autograd.Function):
         W1, W2 = _w16(w1), _w16(w2)
         M, D = a2.shape
         Hd = W1.shape[0]
-        inference = not MlpFn._caller_grad or not any(ctx.needs_input_grad)
+        inference = not getattr(MlpFn._tls, "caller_grad", True) or not any(ctx.needs_input_grad)
         hg = torch.empty(M, Hd, dtype=torch.bfloat16, device=a2.device)
         h = None if inference else torch.empty_like(hg)
         ws, nbytes = _gemm_ws(0, M, Hd, D, a2.device)

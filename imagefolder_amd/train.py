@@ -255,7 +255,9 @@ class GradAllReducer:
                 self._launch(ci)
         self._pos = len(self._order)
         if not self._learned and was_armed:
-            self._adopt_learned_order()
+            self._adopt_pending = True      # exchanged at the END of wait(): a blocking broadcast here would stall the host behind every gradient
+                                            # collective just enqueued (the learning step would lose all overlap, and a rank that raised between
+                                            # its all-reduces and the broadcast would leave the others hanging in it)
 
     def wait(self):
         if not self._works:
@@ -273,6 +275,9 @@ class GradAllReducer:
             self._pending_ev.append((e0, e1))
         self._works = []
         self._launched = [False] * len(self.chunks)
+        if getattr(self, "_adopt_pending", False):
+            self._adopt_pending = False
+            self._adopt_learned_order()      # (every rank reaches this point: the step's collectives have completed on all of them)
 
     def collect_exposed_ms(self):
         """durations of the wait()s whose events have completed (never blocks: an event pair still in flight stays pending and is picked
@@ -637,8 +642,8 @@ class DiscriminatorStep:
         return {"optimizer_disc": self.opt.state_dict(), "global_step": self.global_step,
                 "fade_blur_schedule": self.fade_blur_schedule}
 
-    def load_state_dict(self, sd):
-        self.opt.load_state_dict(sd["optimizer_disc"])
+    def load_state_dict(self, sd, allow_partial: bool = False):
+        self.opt.load_state_dict(sd["optimizer_disc"], allow_partial=allow_partial)
         self.global_step = int(sd["global_step"])
         self.fade_blur_schedule = sd.get("fade_blur_schedule", 0)
 

@@ -24,7 +24,8 @@
 extern "C" {
 #endif
 
-#define XQ_ABI_VERSION 1
+#define XQ_ABI_VERSION 3      /* 2: round 5's entry points (xq_adamw_ema_step_ex, xq_grad_norm_clip, xq_sn_batched_*, xq_token_assemble_*, ...);
+                                  3: round 6 (xq_gemm_fused_schedule, XQ_GEMM_DUO / _PDUO, xq_gemm_colpart_rows = 2 * ceil(M / 128)) */
 
 #define XQ_OK 0
 #define XQ_EINVAL (-1)   /* bad shape / null pointer / unsupported size */

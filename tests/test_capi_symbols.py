@@ -29,7 +29,7 @@ def test_python_binding_covers_header():
     from imagefolder_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()
     l = _lib.lib()
-    assert l.xq_abi_version() == 1
+    assert l.xq_abi_version() == 3
     assert l.xq_assign_workspace_bytes(1024, 64, 4096) > 4096 * 64 * 4
 
 
