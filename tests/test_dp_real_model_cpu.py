@@ -341,3 +341,76 @@ def test_chunks_completing_in_a_rank_dependent_order_still_reduce_in_one_order(t
     for k, v in m.state_dict().items():
         for r in rs:
             assert torch.allclose(v, r["sd"][k], atol=1e-6, rtol=1e-5), k
+
+
+class _Skippy(_Branchy):
+    """_Branchy whose branch 1 is left out of the graph when `skip` is set: its parameters receive NO gradient in that step (a frozen /
+    data-dependent branch), so no hook ever completes their chunks on that rank"""
+    skip = False
+
+    def forward(self, x, epoch, alpha, beta, delta):
+        outs = {i: self.br[i](x) for i in self.order if not (self.skip and i == 1)}
+        return (outs[0] + (2.0 * outs[1] if 1 in outs else 0.0) - outs[2],)
+
+
+def _skippy_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from imagefolder_amd.train import TokenizerTrainStep
+    m = _Skippy()
+    ts = TokenizerTrainStep(m, _loss_b, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9, amp_dtype=None, chunk_bytes=256)
+    r = ts.reducer
+    seen = []
+    launch = r._launch
+    r._launch = lambda ci: (seen.append(ci), launch(ci))[1]
+    g = torch.Generator().manual_seed(78)
+    data = torch.randn(5, world * 4, 6, generator=g)
+    per_step, grads = [], []
+    for it in range(5):
+        seen.clear()
+        # step 0 is the learning pass; in steps 1 and 3 rank 1 ALONE builds no graph through branch 1, in step 2 rank 0 alone, step 4 both build all
+        m.skip = (it in (1, 3) and rank == 1) or (it == 2 and rank == 0)
+        ts.step(data[it, rank * 4:(rank + 1) * 4])
+        per_step.append(list(seen))
+    torch.save({"sd": {k: v.clone() for k, v in m.state_dict().items()}, "launches": per_step, "order": list(r._order), "chunks": len(r.chunks)}, out + f".{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_a_rank_without_a_gradient_for_some_chunks_still_issues_their_collectives_in_the_fixed_order(tmp_path):
+    """Round 6 (multi-GPU kept warm without hardware): a branch that receives no gradient on ONE rank only.  Its chunks are completed by no hook
+    there, so they leave in start() — and every rank must still issue EVERY chunk's all-reduce, in the same sequence, or the job hangs / sums the
+    wrong chunks.  The result equals a single process whose step sees the same per-sample graphs (the skipping rank's samples contribute zero
+    to branch 1)."""
+    world, port, out = 2, _free_port(), str(tmp_path / "sk")
+    mp.spawn(_skippy_worker, args=(world, port, out), nprocs=world, join=True)      # a hang here = a collective one rank never issued
+    rs = [torch.load(out + f".{r}") for r in range(world)]
+    assert rs[0]["chunks"] >= 6
+    for step_a, step_b in zip(rs[0]["launches"], rs[1]["launches"]):
+        assert step_a == step_b, "ranks issued their collectives in different orders"
+        assert sorted(step_a) == list(range(rs[0]["chunks"])), "a chunk's collective was not issued"
+    for k, v in rs[0]["sd"].items():
+        assert torch.equal(v, rs[1]["sd"][k]), f"ranks diverged: {k}"
+    # single process: the same five steps on the global batch, branch 1 masked per sample the way the ranks skipped it
+    from imagefolder_amd.train import TokenizerTrainStep
+
+    class _Masked(_Branchy):
+        mask = None
+
+        def forward(self, x, epoch, alpha, beta, delta):
+            outs = {i: self.br[i](x) for i in self.order}
+            return (outs[0] + 2.0 * outs[1] * self.mask - outs[2],)
+    m = _Masked()
+    ts = TokenizerTrainStep(m, _loss_b, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.0, ema_decay=0.9, amp_dtype=None)
+    data = torch.randn(5, world * 4, 6, generator=torch.Generator().manual_seed(78))
+    for it in range(5):
+        mask = torch.ones(world * 4, 1)
+        if it in (1, 3):
+            mask[4:] = 0.0
+        if it == 2:
+            mask[:4] = 0.0
+        m.mask = mask
+        ts.step(data[it])
+    for k, v in m.state_dict().items():
+        assert torch.allclose(v, rs[0]["sd"][k], atol=1e-6, rtol=1e-5), k
