@@ -32,6 +32,9 @@ __device__ __forceinline__ void erf_half_tail2(act_f2 x, act_f2 ax, act_f2 &half
 }
 
 template <bool TANH> __device__ __forceinline__ act_f2 gelu_val2(act_f2 x) {
+#ifdef XQ_ACT_DEBUG_CHEAP      // timing experiment only (profiles/r06_gelu_epilogue_cost.txt): what the fused epilogues cost WITHOUT the activation arithmetic
+    return x * act_splat(0.5f);
+#endif
     if (TANH) {   // F.gelu(approximate='tanh'): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u)
         const act_f2 w = act_fma((x * x) * act_splat(0.044715f), x, x);
         const act_f2 s = act_rcp(act_splat(1.0f) + act_exp2(w * act_splat(-2.8853900817779268f * 0.7978845608028654f)));
@@ -46,6 +49,9 @@ template <bool TANH> __device__ __forceinline__ act_f2 gelu_val2(act_f2 x) {
 }
 
 template <bool TANH> __device__ __forceinline__ act_f2 gelu_grad2(act_f2 x) {
+#ifdef XQ_ACT_DEBUG_CHEAP
+    return act_splat(0.5f) + x * act_splat(0.125f);
+#endif
     if (TANH) {
         const act_f2 x2 = x * x;
         const act_f2 w = act_fma(x2 * act_splat(0.044715f), x, x);
