@@ -579,6 +579,32 @@ using gm::next_item_walk;
 __device__ __forceinline__ float bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
 
+// ---- GELU / GELU' of the fused MLP epilogues by table (round 6) -------------------------------------------------------------------------
+// The activation acts on bf16 values: it is a function of 16 bits.  profiles/r06_gelu_epilogue_cost.txt: the erf arithmetic (one rcp, one exp2,
+// ~10 packed-fp32 operations per value, A&S 7.1.26) costs 0.06 - 0.10 ms per fused launch with the matrix pipe idle — 25 k cycles per 256 x 256
+// tile and SIMD.  Each workgroup of a fused kernel therefore evaluates csrc/xq_act.hpp's OWN functions once per input value at kernel start (under
+// the first pieces' way from HBM) into LDS — forward: bf16 gelu(x) for |x| in [2^-20, 16), both signs, 12 KiB; backward: fp32 gelu'(x) for |x| in
+// [2^-12, 16), 16 KiB — and the epilogue reads the result: bit-identical by construction.  Values outside the table (|x| >= 16, tiny or zero: 1 in
+// ~5000 at the backward's range) are caught per wave instruction batch by a ballot and that batch is redone by the formula.
+constexpr unsigned GT_LO_F = 107u << 7, GT_N_F = 24u * 128u;      // forward table: biased exponents 107 .. 130
+constexpr unsigned GT_LO_B = 115u << 7, GT_N_B = 16u * 128u;      // backward table: biased exponents 115 .. 130
+constexpr int GT_TABLE_OFF = 16384;                               // behind the 8 x 2 KiB staging regions of the fused kernels
+__device__ __forceinline__ unsigned gelu_tab_pair(unsigned w, const char *tab, unsigned &bad) {
+    const unsigned lo = w & 0xffffu, hi = w >> 16;
+    unsigned il = (lo & 0x7fffu) - GT_LO_F, ih = (hi & 0x7fffu) - GT_LO_F;
+    bad |= (unsigned)(il >= GT_N_F) | (unsigned)(ih >= GT_N_F);
+    il = (il < GT_N_F ? il : GT_N_F - 1) + (lo >> 15) * GT_N_F;
+    ih = (ih < GT_N_F ? ih : GT_N_F - 1) + (hi >> 15) * GT_N_F;
+    const unsigned rl = *reinterpret_cast<const unsigned short *>(tab + 2 * il), rh = *reinterpret_cast<const unsigned short *>(tab + 2 * ih);
+    return rl | (rh << 16);
+}
+__device__ __forceinline__ float gelu_tab_grad(unsigned u, const char *tab, unsigned &bad) {
+    unsigned i = (u & 0x7fffu) - GT_LO_B;
+    bad |= (unsigned)(i >= GT_N_B);
+    i = (i < GT_N_B ? i : GT_N_B - 1) + (u >> 15) * GT_N_B;
+    return *reinterpret_cast<const float *>(tab + 4 * i);
+}
+
 template <int AK, int BK, int ACT, bool SUMS = false>
 __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     constexpr int WTN = 64;
@@ -644,7 +670,9 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     // tile into this wave's own epilogue staging area), so that the counted vmcnt of the phases stays exact to the end
     // of the stream and one tile body serves every K tile
     int s_dummy = 0;
-    char *const region = smem + 8 * gm::PIECE_BYTES + wave * 4096;
+    constexpr bool TABLE = ACT != ACT_NONE;      // fused GELU kernels: 2 KiB of staging per wave + the activation table (see gelu_tab_pair)
+    char *const region = smem + 8 * gm::PIECE_BYTES + wave * (TABLE ? 2048 : 4096);
+    const char *const act_tab = smem + 8 * gm::PIECE_BYTES + GT_TABLE_OFF;
 
     f32x16 acc[4][2];
 #define PR_ZERO()                                                    \
@@ -776,6 +804,25 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
     PR_ADVANCE();
     PR_STAGE(0);
     PR_STAGE(1);
+    if (TABLE) {      // the activation table, built by xq_act.hpp's own functions while the first pieces are on their way
+        char *tab = smem + 8 * gm::PIECE_BYTES + GT_TABLE_OFF;
+        if (ACT == ACT_GELU_FWD) {
+            for (unsigned i = tid; i < 2 * GT_N_F; i += GT) {
+                const unsigned sg = i >= GT_N_F ? 1u : 0u, u = (sg << 15) | (GT_LO_F + (i - sg * GT_N_F));
+                const float x = __uint_as_float(u << 16);
+                const float y = g.gelu_tanh ? gelu_val<true>(x) : gelu_val<false>(x);
+                reinterpret_cast<unsigned short *>(tab)[i] = (unsigned short)(pack_bf16(y, y) & 0xffffu);
+            }
+        } else {
+            for (unsigned i = tid; i < 2 * GT_N_B; i += GT) {
+                const unsigned sg = i >= GT_N_B ? 1u : 0u, u = (sg << 15) | (GT_LO_B + (i - sg * GT_N_B));
+                const float x = __uint_as_float(u << 16);
+                reinterpret_cast<float *>(tab)[i] = g.gelu_tanh ? gelu_grad<true>(x) : gelu_grad<false>(x);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // my table entries are written before I signal the barrier below
+    }
     GR_VMCNT(6);
     GR_BARRIER();
 
@@ -820,6 +867,100 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             __hip_bfloat16 *C = reinterpret_cast<__hip_bfloat16 *>(g.C);
             typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
             float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // ACT_GELU_BWD: this lane's 8 columns over its 16 rows
+            if constexpr (TABLE) {
+                // fused GELU products: 16 rows x 64 columns per round trip through this wave's 2 KiB (the half of the lanes whose fragment row lies in
+                // the 16 writes, all 64 read), the activation from the table
+                // backward: the pre-activations of the NEXT 32-row block are requested before this block's stores are issued (two register sets).
+                // Fetched at the head of each pass (round 5) every pass began with a wait for its own loads, which — vmcnt retires in order —
+                // is also a wait for the previous pass's STORES to be acknowledged: a serial memory round trip per pass.  (All 16 loads of the item
+                // up front: 64 registers more than the kernel has — measured, 272 bytes of scratch, 0.505 -> 0.572 ms.)
+                u32x4 hvbuf[2][2][2];
+#define PR_LOAD_H(FI_)                                                                                                                    \
+    _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                                                                                      \
+    _Pragma("unroll") for (int it_ = 0; it_ < 2; ++it_) {                                                                                 \
+        int row_, c_, off_;                                                                                                               \
+        gm::epi_read_map(it_, lane, WTN, &row_, &c_, &off_);                                                                              \
+        long gr_ = cit.m0 + 128 * wr + 32 * (FI_) + 16 * u_ + row_, gc_ = ncol0 + 8 * c_;                                                 \
+        if (gr_ > g.M - 1) gr_ = g.M - 1;                                                                                                 \
+        if (gc_ > g.N - 8) gc_ = g.N - 8;                                                                                                 \
+        hvbuf[(FI_) & 1][u_][it_] = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __hip_bfloat16 *>(g.H) + gr_ * g.ldc + gc_);  \
+    }
+                if (ACT == ACT_GELU_BWD) { PR_LOAD_H(0) }
+#pragma unroll
+                for (int fi = 0; fi < 4; ++fi)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (ACT == ACT_GELU_BWD && u == 0 && fi + 1 < 4) { PR_LOAD_H(fi + 1) }
+                        const u32x4 (&hv)[2] = hvbuf[fi & 1][u];
+                        if (((lane >> 4) & 1) == u) {
+#pragma unroll
+                            for (int fj = 0; fj < 2; ++fj)
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    uint2 pk;
+                                    float e0 = acc[fi][fj][4 * q + 0], e1 = acc[fi][fj][4 * q + 1], e2 = acc[fi][fj][4 * q + 2], e3 = acc[fi][fj][4 * q + 3];
+                                    if (HAS_BIAS) { e0 += bv[fj][q].x; e1 += bv[fj][q].y; e2 += bv[fj][q].z; e3 += bv[fj][q].w; }
+                                    pk.x = pack_bf16(e0, e1);
+                                    pk.y = pack_bf16(e2, e3);
+                                    // rows 0 .. 15 of the region: lane (l & 15) + 32 (l >> 5) of the writing half plays lane (l & 31) of the 32-row map
+                                    *reinterpret_cast<uint2 *>(region + gm::epi_write_off(0, fj, q, lane & 47, WTN)) = pk;
+                                }
+                        }
+                        // same wave wrote and reads: LDS operations of one wave complete in order
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) {
+                            int row, c, off;
+                            gm::epi_read_map(it, lane, WTN, &row, &c, &off);
+                            const u32x4 v = *reinterpret_cast<const u32x4 *>(region + off);
+                            const long gr = cit.m0 + 128 * wr + 32 * fi + 16 * u + row;
+                            const long gc = ncol0 + 8 * c;
+                            const bool ok = gr < g.M && gc + 8 <= g.N;
+                            u32x4 o = v;
+                            unsigned bad = 0;
+                            if (ACT == ACT_GELU_FWD) {
+                                // the activation acts on the bf16-ROUNDED pre-activation, as the unfused pair (Linear -> GELU) does
+                                u32x4 a2;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) a2[e] = gelu_tab_pair(v[e], act_tab, bad);
+                                if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        const float x0 = bf16_lo(v[e]), x1 = bf16_hi(v[e]);
+                                        a2[e] = g.gelu_tanh ? pack_bf16(gelu_val<true>(x0), gelu_val<true>(x1)) : pack_bf16(gelu_val<false>(x0), gelu_val<false>(x1));
+                                    }
+                                }
+                                if (ok) {
+                                    u32x4 *p2 = reinterpret_cast<u32x4 *>(reinterpret_cast<__hip_bfloat16 *>(g.C2) + gr * g.ldc + gc);
+                                    if (g.nt_store) __builtin_nontemporal_store(a2, p2); else *p2 = a2;
+                                }
+                            } else {
+                                float d[8];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    d[2 * e] = gelu_tab_grad(hv[it][e] & 0xffffu, act_tab, bad);
+                                    d[2 * e + 1] = gelu_tab_grad(hv[it][e] >> 16, act_tab, bad);
+                                }
+                                if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) {
+                                        d[2 * e] = g.gelu_tanh ? gelu_grad<true>(bf16_lo(hv[it][e])) : gelu_grad<false>(bf16_lo(hv[it][e]));
+                                        d[2 * e + 1] = g.gelu_tanh ? gelu_grad<true>(bf16_hi(hv[it][e])) : gelu_grad<false>(bf16_hi(hv[it][e]));
+                                    }
+                                }
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    o[e] = pack_bf16(bf16_lo(v[e]) * d[2 * e], bf16_hi(v[e]) * d[2 * e + 1]);
+                                    if (gr < g.M) { csum[2 * e] += bf16_lo(o[e]); csum[2 * e + 1] += bf16_hi(o[e]); }
+                                }
+                            }
+                            if (ok && (ACT != ACT_GELU_FWD || g.C != nullptr)) {      // (fused GELU forward without a gradient to come: h is not written)
+                                u32x4 *p1 = reinterpret_cast<u32x4 *>(C + gr * g.ldc + gc);
+                                if (g.nt_store) __builtin_nontemporal_store(o, p1); else *p1 = o;
+                            }
+                        }
+                    }
+#undef PR_LOAD_H
+            } else
 #pragma unroll
             for (int fi = 0; fi < 4; ++fi) {
                 u32x4 hv[4];
