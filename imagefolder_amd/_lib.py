@@ -130,8 +130,11 @@ SIGNATURES = {
     "xq_gemm_bf16_nn": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_size_t, ctypes.c_int, vp]),
     "xq_gemm_bf16_nt_gelu": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp]),
     "xq_gemm_colpart_rows": (ctypes.c_size_t, [ctypes.c_int64]),
+    "xq_gemm_colpart_rows_written": (ctypes.c_size_t, [ctypes.c_int64, ctypes.c_int64]),
     "xq_gemm_fused_schedule": (ctypes.c_int, [ctypes.c_int]),
     "xq_gemm_bf16_nn_gelu_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp]),
+    "xq_gemm_bf16_nt_gelu_bwd": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_int, vp, ctypes.c_size_t, vp]),
+    "xq_transpose_bf16_batched": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int64, vp]),
     "xq_conv3x3_gemm_bf16": (ctypes.c_int, [vp, vp, vp] + [ctypes.c_int] * 12 + [vp, vp, ctypes.c_int, vp]),
     "xq_gemm_bf16_batched": (ctypes.c_int, [ctypes.c_int, vp, vp, ctypes.c_int] + [ctypes.c_int64] * 6 + [vp, vp]),
     "xq_gemm_bf16_tn": (ctypes.c_int, [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, vp, vp, ctypes.c_size_t, ctypes.c_int, vp]),

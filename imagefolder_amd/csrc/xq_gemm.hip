@@ -853,7 +853,7 @@ __global__ __launch_bounds__(GT) void gemm_pring_kernel(const GemmArgs g) {
             const long ncol0 = cit.n0 + 64 * wc;
             // bias and ReLU exist for the K-major B operand only (Linear forward, convolutions): the data gradients have neither, and
             // their epilogues keep the 32 registers
-            constexpr bool HAS_BIAS = BK == gm::KMAJOR;
+            constexpr bool HAS_BIAS = BK == gm::KMAJOR && ACT != ACT_GELU_BWD;
             constexpr bool OUT_MASK = AK == gm::KMAJOR_CONV && ACT == ACT_NONE;   // H = out_mask of a convolution's data gradient
             float4 bv[2][4];
 #pragma unroll
@@ -1106,7 +1106,7 @@ __device__ __forceinline__ void duo_epilogue(const f32x16 (&acc)[2][2], const Ge
     constexpr int WTN = 64;
         const int h = lane >> 5;
     const long ncol0 = n0 + 64 * wc;
-    constexpr bool HAS_BIAS = BK == gm::KMAJOR;
+    constexpr bool HAS_BIAS = BK == gm::KMAJOR && ACT != ACT_GELU_BWD;
     float4 bv[2][4];
 #pragma unroll
     for (int fj = 0; fj < 2; ++fj)
@@ -2118,12 +2118,20 @@ extern "C" int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *b
     return launch_gemm<gm::KMAJOR, gm::KMAJOR, EPI_BF16, ACT_GELU_FWD>(g, 256, pick_fused(M, N), ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
 }
 
-// one partial row per 128-row block (256-row schedule: 2 per tile) or per 64-row wave tile (duo schedules: 2 per 128-row tile) — the larger count
+// Partial rows of the GELU' products.  xq_gemm_colpart_rows(M): what a caller ALLOCATES — enough for every schedule (one row per 128-row block
+// of the 256-row schedule = 2 per tile; one per 64-row wave tile of the duo schedules = 2 per 128-row tile).  xq_gemm_colpart_rows_written(M, N):
+// the leading rows the schedule now in force for that shape writes — what the caller sums (xq_colsum_partials); the rest stays untouched.
 extern "C" size_t xq_gemm_colpart_rows(int64_t M) { return M > 0 ? (size_t)(2 * ((M + 127) / 128)) : 0; }
+extern "C" size_t xq_gemm_colpart_rows_written(int64_t M, int64_t N) {
+    if (M <= 0) return 0;
+    return pick_fused(M, N) == XQ_GEMM_PERSISTENT ? (size_t)(2 * ((M + 255) / 256)) : (size_t)(2 * ((M + 127) / 128));
+}
 
-extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h,
-                                        float *colpart, int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
-    const char *fn = "xq_gemm_bf16_nn_gelu_bwd";
+namespace {
+// g_h = (g_y W2) * GELU'(h) with W2 as stored ([K][N], BK = KSTRIDED: transpose reads) or its transposed copy ([N][K], BK = KMAJOR)
+template <int BK>
+int gelu_bwd_product(const char *fn, const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h, float *colpart,
+                     int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
     if (int rc = check_mnk(fn, M, N, K)) return rc;
     if (M == 0 || N == 0) return XQ_OK;
     if (!g_y || !w || !h || !g_h) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
@@ -2131,17 +2139,21 @@ extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const vo
     GemmArgs g{};
     g.nt_store = 1;
     g.A = (const char *)g_y; g.B = (const char *)w; g.C = (char *)g_h; g.H = (const char *)h; g.colpart = colpart; g.gelu_tanh = approximate_tanh;
-    g.M = M; g.N = N; g.lda = K; g.ldb = N; g.ldc = N;
+    g.M = M; g.N = N; g.lda = K; g.ldb = BK == gm::KMAJOR ? K : N; g.ldc = N;
     g.ktiles = g.kt_full = (int)(K / 64); g.kt_rem = 0; g.splits = 1;
     g.tiles_m = (int)((M + 255) / 256); g.tiles_n = (int)((N + 255) / 256);
-    const int impl = pick_fused(M, N);
-    if (impl == XQ_GEMM_PERSISTENT && colpart) {
-        // the 256-row schedule fills the first 2 * ceil(M / 256) partial rows; the rest of the xq_gemm_colpart_rows(M) rows count as zero
-        const size_t used = (size_t)(2 * ((M + 255) / 256)), all = xq_gemm_colpart_rows(M);
-        if (all > used && hipMemsetAsync(colpart + used * N, 0, (all - used) * N * sizeof(float), (hipStream_t)stream) != hipSuccess)
-            return xq_set_error(XQ_ELAUNCH, "%s: hipMemsetAsync failed", fn);
-    }
-    return launch_gemm<gm::KMAJOR, gm::KSTRIDED, EPI_BF16, ACT_GELU_BWD>(g, 256, impl, ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
+    return launch_gemm<gm::KMAJOR, BK, EPI_BF16, ACT_GELU_BWD>(g, 256, pick_fused(M, N), ws, ws_bytes, (hipStream_t)stream, fn, 2.0 * M * N * K);
+}
+}  // namespace
+
+extern "C" int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h,
+                                        float *colpart, int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
+    return gelu_bwd_product<gm::KSTRIDED>("xq_gemm_bf16_nn_gelu_bwd", g_y, w, h, M, N, K, g_h, colpart, approximate_tanh, ws, ws_bytes, stream);
+}
+
+extern "C" int xq_gemm_bf16_nt_gelu_bwd(const void *g_y, const void *w_t, const void *h, int64_t M, int64_t N, int64_t K, void *g_h,
+                                        float *colpart, int approximate_tanh, void *ws, size_t ws_bytes, xq_stream_t stream) {
+    return gelu_bwd_product<gm::KMAJOR>("xq_gemm_bf16_nt_gelu_bwd", g_y, w_t, h, M, N, K, g_h, colpart, approximate_tanh, ws, ws_bytes, stream);
 }
 
 // ---- 3x3 convolution as an implicit GEMM on the tile engine (NHWC bf16; Cin % 64 == 0, Cout % 8 == 0, Cout >= 64) -------------

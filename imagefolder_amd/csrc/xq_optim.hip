@@ -209,3 +209,56 @@ extern "C" int xq_adamw_ema_step_ex(float *p, float *g, float *m, float *v, floa
     return adamw_launch("xq_adamw_ema_step_ex", p, g, m, v, ema, p_bf16, n, lr, beta1, beta2, eps, weight_decay, step, coeffs, ema_decay,
                         grad_scale, zero_grad, stream, clip2);
 }
+
+// ---- transposed bf16 shadows of the Linear weights ------------------------------------------------------------------------------
+// The data gradient of a Linear, g_x = g_y W, runs 7-10 % faster as an NT product on W^T ([in][out]: both operands K-major, staged by LDS-DMA
+// and read with plain ds_read_b64) than as an NN product on W as stored (transpose reads) — profiles/r06_nn_vs_nt_transposed_weight.txt.
+// One launch after the optimizer step rewrites every registered weight's transposed copy: `table` (device, int64 [n][5]) = {source offset,
+// destination offset (elements from src / dst), rows, cols, first tile}, rows and cols multiples of 64, tiles numbered row-major inside a
+// matrix.  HBM-bound, 4 B per element.
+__global__ __launch_bounds__(256) void transpose_shadow_kernel(const unsigned short *__restrict__ src, unsigned short *__restrict__ dst,
+                                                               const long *__restrict__ table, int n) {
+    __shared__ unsigned short tile[64 * 66];        // pitch 33 words: the 8 rows a lane gathers and the 8 lanes of a column group hit distinct banks
+    const long t = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                               // last matrix whose first tile <= t
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[5 * mid + 4] <= t) lo = mid; else hi = mid - 1;
+    }
+    const long *e = table + 5 * lo;
+    const long rows = e[2], cols = e[3];
+    const long tl = t - e[4], tcols = cols >> 6;
+    const long r0 = (tl / tcols) << 6, c0 = (tl % tcols) << 6;
+    const unsigned short *s = src + e[0] + r0 * cols + c0;
+    unsigned short *d = dst + e[1] + c0 * rows + r0;
+    const int lane8 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = grp + 32 * p;
+        const uint4 v = *reinterpret_cast<const uint4 *>(s + (long)r * cols + 8 * lane8);
+        unsigned *w = reinterpret_cast<unsigned *>(tile + r * 66 + 8 * lane8);
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int c = grp + 32 * p;                 // source column = destination row
+        unsigned o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = (unsigned)tile[(8 * lane8 + 2 * j) * 66 + c] | ((unsigned)tile[(8 * lane8 + 2 * j + 1) * 66 + c] << 16);
+        *reinterpret_cast<uint4 *>(d + (long)c * rows + 8 * lane8) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+extern "C" int xq_transpose_bf16_batched(const void *src, void *dst, const int64_t *table, int n_mats, int64_t tiles, xq_stream_t stream) {
+    const char *fn = "xq_transpose_bf16_batched";
+    if (n_mats < 0 || tiles < 0) return xq_set_error(XQ_EINVAL, "%s: negative count", fn);
+    if (n_mats == 0 || tiles == 0) return XQ_OK;
+    if (!src || !dst || !table) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
+    if (tiles > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: %ld tiles exceed the grid", fn, (long)tiles);
+    static_assert(sizeof(long) == sizeof(int64_t), "table entries are read as long");
+    hipLaunchKernelGGL(transpose_shadow_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const unsigned short *)src,
+                       (unsigned short *)dst, (const long *)table, n_mats);
+    return xq_check_launch("transpose_shadow_kernel");
+}

@@ -213,6 +213,9 @@ def _w16(weight):
             # (load_state_dict, manual init): re-cast this tensor and invalidate what is derived from it
             with torch.no_grad():
                 w16.copy_(weight.detach())
+                wt = getattr(weight, "_xq_w16t", None)
+                if wt is not None:
+                    wt.copy_(w16.t())
             weight._xq_w16_version = weight._version
             arena = getattr(weight, "_xq_arena", None)
             if arena is not None:
@@ -227,6 +230,26 @@ def _w16(weight):
     return weight.detach().to(torch.bfloat16)
 
 
+def _w16t(weight):
+    """[in][out] bf16 copy of a Linear weight for its data gradient (g_x = g_y W as an NT product: gemm_nt(g_y, W^T)), or None: the copy the
+    optimizer step keeps next to the shadow for trainable parameters (train.FlatArena.p16t), a cached transpose for frozen ones (the DINO
+    backbone of the discriminator, whose input gradient reaches the generator)."""
+    if not DGRAD_NT or weight.dim() != 2:
+        return None
+    W = _w16(weight)           # (refreshes a stale shadow and its transposed copy)
+    wt = getattr(weight, "_xq_w16t", None)
+    if wt is not None:
+        return wt
+    if not weight.requires_grad and getattr(weight, "_xq_w16", None) is None:
+        cache = getattr(weight, "_xq_w16t_frozen", None)
+        if cache is None or cache[0] != weight._version or cache[1].device != weight.device:
+            cache = (weight._version, W.t().contiguous())
+            weight._xq_w16t_frozen = cache
+        return cache[1]
+    return None
+
+
+DGRAD_NT = __import__("os").environ.get("XQ_DGRAD_NT", "1") == "1"     # round 6: data gradients as NT products on transposed weight copies
 FUSED_IMAGE_PREP = __import__("os").environ.get("XQ_FUSED_IMAGE_PREP", "1") == "1"      # round 5: affine + cast / + patchify of input images in one kernel
 FUSED_TOKEN_ASSEMBLY = __import__("os").environ.get("XQ_FUSED_TOKENS", "1") == "1"      # round 5: TokenAssembleFn in front of the block stacks
 _SPLIT_K = 16  # slices of the token axis for the weight-gradient GEMM
@@ -325,6 +348,7 @@ class LinearFn(torch.autograd.Function):
         hip = f32 = False
         pad_k = pad_n = 0
         n_out = weight.shape[0]
+        Wt = None
         if x2.dtype == torch.bfloat16:
             W = _w16(weight)
             hip = GEMM_IMPL == "hip" and x2.is_cuda and x2.shape[0] > 0
@@ -338,6 +362,8 @@ class LinearFn(torch.autograd.Function):
                     x2 = F.pad(x2, (0, pad_k)) if pad_k else x2
                 if not W.is_contiguous():
                     W = W.contiguous()
+                elif not (pad_k or pad_n) and ctx.needs_input_grad[0] and W.shape[0] % 64 == 0 and W.shape[1] % 64 == 0:
+                    Wt = _w16t(weight)      # the data gradient's operand: W^T, K-major (None: NN product on W)
                 if not x2.is_contiguous():
                     x2 = x2.contiguous()
                 b32 = None if bias is None else bias.detach().float().contiguous()
@@ -368,14 +394,14 @@ class LinearFn(torch.autograd.Function):
                 nn_ops.IMPL["linear_fp32_training"] = "hip (xq_conv2d_f32_nhwc fwd / dgrad, xq_gemm_f32_tn wgrad — fp32 MFMA)"
         if not hip and not f32:
             y = torch.addmm(b, x2, W.t()) if b is not None else torch.mm(x2, W.t())
-        ctx.save_for_backward(x2, W)
+        ctx.save_for_backward(x2, W, Wt)
         ctx.meta = (shp, weight.dtype, bias is not None and not bias_grad_external, bias is not None, hip, pad_k, pad_n, tuple(weight.shape))
         ctx.f32 = f32
         return y.reshape(*shp[:-1], n_out)
 
     @staticmethod
     def backward(ctx, g):
-        x2, W = ctx.saved_tensors
+        x2, W, Wt = ctx.saved_tensors
         shp, wdtype, want_bias, has_bias, hip, pad_k, pad_n, wshape = ctx.meta
         g2 = g.reshape(-1, g.shape[-1])
         if not g2.is_contiguous():
@@ -388,7 +414,7 @@ class LinearFn(torch.autograd.Function):
             from . import ops_f32
         if ctx.needs_input_grad[0]:
             if hip:
-                g_x = gemm_nn(gp, W)
+                g_x = gemm_nt(gp, Wt, None) if Wt is not None else gemm_nn(gp, W)
                 g_x = (g_x[:, :wshape[1]] if pad_k else g_x).reshape(shp)
             elif f32:
                 g_x = ops_f32._rows_times(g2, W.t().contiguous(), None).view(shp)
@@ -466,25 +492,30 @@ class MlpFn(torch.autograd.Function):
         check(rc, "xq_gemm_bf16_nt_gelu")
         f = gemm_nt(hg, W2, None if b2 is None else b2.detach().float().contiguous())
         if not inference:
-            ctx.save_for_backward(a2, W1, W2, h, hg)
+            W1t = _w16t(w1) if ctx.needs_input_grad[0] else None
+            ctx.save_for_backward(a2, W1, W2, h, hg, W1t, _w16t(w2))
         ctx.meta = (shp, bool(tanh), w1.dtype)
         return f.view(*shp[:-1], W2.shape[0])
 
     @staticmethod
     def backward(ctx, g):
-        a2, W1, W2, h, hg = ctx.saved_tensors
+        a2, W1, W2, h, hg, W1t, W2t = ctx.saved_tensors
         shp, tanh, wdtype = ctx.meta
         g2 = g.reshape(-1, g.shape[-1]).to(torch.bfloat16)
         if not g2.is_contiguous():
             g2 = g2.contiguous()
         M, Hd = h.shape
         g_h = torch.empty_like(h)
-        rows = _lib.lib().xq_gemm_colpart_rows(M)
+        rows = _lib.lib().xq_gemm_colpart_rows_written(M, Hd)      # the rows the schedule in force fills (<= xq_gemm_colpart_rows(M))
         colpart = torch.empty(rows, Hd, dtype=torch.float32, device=h.device)
-        ws, nbytes = _gemm_ws(1, M, Hd, W2.shape[0], h.device)
+        ws, nbytes = _gemm_ws(0 if W2t is not None else 1, M, Hd, W2.shape[0], h.device)
         with torch.cuda.device(h.device):
-            rc = _lib.lib().xq_gemm_bf16_nn_gelu_bwd(ptr(g2), ptr(W2), ptr(h), M, Hd, W2.shape[0], ptr(g_h), ptr(colpart), int(tanh), ptr(ws), nbytes,
-                                                     _stream(h))
+            if W2t is not None:     # the same product on W2^T [hidden][D]: both operands K-major
+                rc = _lib.lib().xq_gemm_bf16_nt_gelu_bwd(ptr(g2), ptr(W2t), ptr(h), M, Hd, W2.shape[0], ptr(g_h), ptr(colpart), int(tanh), ptr(ws),
+                                                         nbytes, _stream(h))
+            else:
+                rc = _lib.lib().xq_gemm_bf16_nn_gelu_bwd(ptr(g2), ptr(W2), ptr(h), M, Hd, W2.shape[0], ptr(g_h), ptr(colpart), int(tanh), ptr(ws),
+                                                         nbytes, _stream(h))
         check(rc, "xq_gemm_bf16_nn_gelu_bwd")
         g_w2 = gemm_tn(g2, hg).to(wdtype) if ctx.needs_input_grad[3] else None
         g_b1 = None
@@ -493,7 +524,9 @@ class MlpFn(torch.autograd.Function):
             with torch.cuda.device(h.device):
                 check(_lib.lib().xq_colsum_partials(ptr(colpart), rows, Hd, ptr(g_b1), _stream(h)), "xq_colsum_partials")
         g_w1 = gemm_tn(g_h, a2).to(wdtype) if ctx.needs_input_grad[1] else None
-        g_a = gemm_nn(g_h, W1).view(shp) if ctx.needs_input_grad[0] else None
+        g_a = None
+        if ctx.needs_input_grad[0]:
+            g_a = (gemm_nt(g_h, W1t, None) if W1t is not None else gemm_nn(g_h, W1)).view(shp)
         return g_a, g_w1, g_b1, g_w2, None, None
 
 

@@ -25,6 +25,9 @@ from . import _lib
 from ._lib import check, ptr
 from ._lib import marker as _marker
 
+# round 6: [in][out] bf16 copies of the Linear weights for the data gradients (FlatArena._init_transposed_shadows); 0 = the NN products on W as stored
+TRANSPOSED_SHADOWS = os.environ.get("XQ_DGRAD_NT", "1") == "1"
+
 
 def get_random_ratio(randomness_anneal_start, randomness_anneal_end, end_ratio, cur_step):
     """xqgan_train.py:62-68 (perturbation schedule)"""
@@ -67,6 +70,7 @@ class FlatArena:
                 self.p16.copy_(self.p)
                 for p, o in zip(self.params, self.offsets):
                     p._xq_w16 = self.p16[o:o + p.numel()].view(p.shape)
+        self._init_transposed_shadows()
         self.step_count = 0
         # `epoch` counts the updates that reach the masters through raw pointers (the optimizer kernel, resync): those never
         # bump torch's per-tensor version counter, so every cache derived from a parameter (packed conv weights, ...) keys
@@ -78,6 +82,38 @@ class FlatArena:
             p._xq_arena = self
             p._xq_w16_version = p._version
 
+    def _init_transposed_shadows(self):
+        """[in][out] bf16 copies of the Linear-shaped weights (2-D, both widths multiples of 64), next to the [out][in] shadow: the data
+        gradients g_x = g_y W read them as the K-major operand of an NT product, 7-10 % faster than the transpose reads of the NN product
+        on W as stored (profiles/r06_nn_vs_nt_transposed_weight.txt; ops_dense._w16t).  One xq_transpose_bf16_batched launch after every
+        optimizer step keeps them current (refresh_transposed_shadows)."""
+        self.p16t, self._t_table, self._t_count, self._t_tiles = None, None, 0, 0
+        if self.p16 is None or not TRANSPOSED_SHADOWS:
+            return
+        rows, dst, tiles = [], 0, 0
+        for p, o in zip(self.params, self.offsets):
+            if p.dim() == 2 and p.shape[0] % 64 == 0 and p.shape[1] % 64 == 0:
+                rows.append((o, dst, p.shape[0], p.shape[1], tiles, p))
+                dst += p.numel()
+                tiles += (p.shape[0] // 64) * (p.shape[1] // 64)
+        if not rows:
+            return
+        self.p16t = torch.empty(dst, dtype=torch.bfloat16, device=self.p16.device)
+        self._t_table = torch.tensor([r[:5] for r in rows], dtype=torch.int64).to(self.p16.device)
+        self._t_count, self._t_tiles = len(rows), tiles
+        for o, d, r, c, _, p in rows:
+            p._xq_w16t = self.p16t[d:d + r * c].view(c, r)
+        self.refresh_transposed_shadows()
+
+    def refresh_transposed_shadows(self):
+        """p16t = the transposes of the bf16 shadow's Linear weights — after anything that rewrote the shadow (one launch, ~4 B per element)"""
+        if self.p16t is None:
+            return
+        with torch.cuda.device(self.p16.device):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(self.p16.device).cuda_stream)
+            rc = _lib.lib().xq_transpose_bf16_batched(ptr(self.p16), ptr(self.p16t), ptr(self._t_table), self._t_count, self._t_tiles, stream)
+        check(rc, "xq_transpose_bf16_batched")
+
     @torch.no_grad()
     def resync(self, ema: bool = False):
         """Call after the masters were overwritten (checkpoint load, weight surgery): refreshes the bf16 shadow, invalidates
@@ -85,6 +121,7 @@ class FlatArena:
         (xqgan_train.py:384) — re-seeds the EMA copy from the masters."""
         if self.p16 is not None:
             self.p16.copy_(self.p)
+            self.refresh_transposed_shadows()
         if ema and self.ema is not None:
             self.ema.copy_(self.p)
         self.epoch += 1
@@ -425,6 +462,7 @@ class ArenaOptimizer:
                                                          ctypes.c_float(self.weight_decay), 0, ptr(self._coeffs), ptr(clip),
                                                          ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
                     check(rc, "xq_adamw_ema_step_ex")
+                    a.refresh_transposed_shadows()
                     return
                 rc = _lib.lib().xq_adamw_ema_step_ex(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
                                                      ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
@@ -432,6 +470,7 @@ class ArenaOptimizer:
                                                      ctypes.c_float(self.weight_decay), a.step_count, None, ptr(clip),
                                                      ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
             check(rc, "xq_adamw_ema_step_ex")
+            a.refresh_transposed_shadows()
         else:
             self._step_host()
 

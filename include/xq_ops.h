@@ -25,7 +25,8 @@ extern "C" {
 #endif
 
 #define XQ_ABI_VERSION 3      /* 2: round 5's entry points (xq_adamw_ema_step_ex, xq_grad_norm_clip, xq_sn_batched_*, xq_token_assemble_*, ...);
-                                  3: round 6 (xq_gemm_fused_schedule, XQ_GEMM_DUO / _PDUO, xq_gemm_colpart_rows = 2 * ceil(M / 128)) */
+                                  3: round 6 (xq_gemm_fused_schedule, XQ_GEMM_DUO / _PDUO, xq_gemm_colpart_rows = 2 * ceil(M / 128) + _rows_written,
+                                     xq_gemm_bf16_nt_gelu_bwd, xq_transpose_bf16_batched) */
 
 #define XQ_OK 0
 #define XQ_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -179,6 +180,12 @@ int xq_grad_norm_clip(const float *g, int64_t n, float grad_scale, float max_nor
 int xq_adamw_ema_step_ex(float *p, float *g, float *m, float *v, float *ema, void *p_bf16, int64_t n, float lr, float beta1, float beta2,
                          float eps, float weight_decay, int64_t step, const float *coeffs, const float *clip2, float ema_decay,
                          float grad_scale, int zero_grad, xq_stream_t stream);
+/* Transposed bf16 copies of many matrices in one launch (round 6): the [in][out] shadows of the Linear weights that the data gradients read as
+ * the K-major operand of an NT product (xq_gemm_bf16_nt on w_t; xq_gemm_bf16_nt_gelu_bwd) instead of transpose-reading W [out][in]
+ * (xq_gemm_bf16_nn) — the reference computes the same g_x = g_y W inside autograd's mm backward (torch.nn.Linear; vision_transformer.py:295-339).
+ * table: DEVICE int64 [n_mats][5] = {source offset, destination offset (bf16 elements from src / dst), rows, cols, first tile}; rows and cols
+ * multiples of 64; a matrix owns (rows / 64) * (cols / 64) consecutive tiles starting at its first tile, `tiles` = their total. */
+int xq_transpose_bf16_batched(const void *src, void *dst, const int64_t *table, int n_mats, int64_t tiles, xq_stream_t stream);
 
 /* ---- fused row kernels of the ViT blocks (dino_enc/vision_transformer.py:280-339; timm Mlp) ------------------------
  * Activations are [rows][D] row-major; act_bf16 selects their dtype (1 = bf16, 0 = fp32); the residual stream,
@@ -511,14 +518,20 @@ int xq_gemm_bf16_nt_gelu(const void *x, const void *w, const float *bias, int64_
                          int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 /* data gradient of fc2 with the GELU derivative in the epilogue: g_h[M][N] = (g_y[M][K] . w[K][N]) * GELU'(h[M][N]) (the product
  * rounded to bf16 before the multiplication, as the unfused pair does); colpart (nullable) fp32 [xq_gemm_colpart_rows(M)][N]
- * receives partial column sums of g_h (per 128-row block or per 64-row wave tile, unused rows zero): their sum over the rows is the fc1 bias gradient.  workspace:
- * xq_gemm_bf16_workspace_bytes(XQ_GEMM_OP_NN, M, N, K) bytes, used as in xq_gemm_bf16_nt_gelu. */
+ * receives partial column sums of g_h (per 128-row block or per 64-row wave tile) in its first xq_gemm_colpart_rows_written(M, N) rows — the
+ * count depends on the schedule in force for the shape; the remaining rows are left untouched: their sum over the written rows is the fc1 bias
+ * gradient.  workspace: xq_gemm_bf16_workspace_bytes(XQ_GEMM_OP_NN, M, N, K) bytes, used as in xq_gemm_bf16_nt_gelu.
+ * xq_gemm_bf16_nt_gelu_bwd: the same product on the TRANSPOSED weight w_t [N][K] (= W2^T, e.g. the shadow xq_transpose_bf16_batched maintains):
+ * both operands K-major, no transpose reads; bit-identical g_h and colpart. */
 size_t xq_gemm_colpart_rows(int64_t M);
+size_t xq_gemm_colpart_rows_written(int64_t M, int64_t N);
 /* schedule of the two fused MLP products (XQ_GEMM_AUTO / _PERSISTENT / _DUO / _PDUO; default: environment XQ_GEMM_FUSED_SCHEDULE, else AUTO);
  * returns the previous value.  Tests and benchmarks; every schedule writes the same h / h_act / g_h bits (K-split tail tiles: up to the fp32
  * summation order) and colpart rows whose column sums agree to the summation order. */
 int xq_gemm_fused_schedule(int impl);
 int xq_gemm_bf16_nn_gelu_bwd(const void *g_y, const void *w, const void *h, int64_t M, int64_t N, int64_t K, void *g_h, float *colpart,
+                             int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
+int xq_gemm_bf16_nt_gelu_bwd(const void *g_y, const void *w_t, const void *h, int64_t M, int64_t N, int64_t K, void *g_h, float *colpart,
                              int approximate_tanh, void *workspace, size_t workspace_bytes, xq_stream_t stream);
 /* 3x3 convolution on the GEMM tile engine (implicit GEMM: the A operand is gathered from the NHWC image tap by tap by the
  * LDS-DMA, out-of-image taps read a zero page; csrc/xq_gemm.hip Stager<KMAJOR_CONV>).  x [B][Hi][Wi][Cin] bf16, w_packed

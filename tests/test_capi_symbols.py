@@ -33,6 +33,13 @@ def test_python_binding_covers_header():
     assert l.xq_assign_workspace_bytes(1024, 64, 4096) > 4096 * 64 * 4
 
 
+def test_driver_build_entry_point_passes():
+    """__graft_entry__.build() is the driver's "does it build" check: make (a no-op when up to date) + the ABI assertion, which must follow
+    the header (round 6 bumped XQ_ABI_VERSION while build() still compared against the literal 1)"""
+    import __graft_entry__
+    __graft_entry__.build()
+
+
 def test_product_has_no_cpu_fallback():
     import pytest
     import torch
