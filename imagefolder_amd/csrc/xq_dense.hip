@@ -163,6 +163,117 @@ __global__ __launch_bounds__(ROW_THREADS) void res_ln_bwd_kernel(const T *__rest
     }
 }
 
+// Round 6: the same backward with the COLUMNS of a row split over the waves of a block (wave w owns chunk w = 64 * VEC columns) and R rows per
+// iteration.  What it removes from the kernel above: 3/4 of the column-partial registers (4 * VEC instead of 4 * NV * VEC per lane: every row a wave
+// touches adds into the same columns), the per-row reloads of lnw / gamma (a wave's columns never change: loaded once), the 48 KiB LDS combine of
+// the four waves' partials (a wave owns its columns: it writes them straight to the partial row), and the second memory round trip per row (all
+// four tensors of the R rows are requested up front).  What it adds: the two row sums c1, c2 are per-chunk partial sums that the NV waves exchange
+// through 2 * R floats of LDS each and one __syncthreads per iteration (slots alternate, so one barrier orders both the reads and the reuse).
+// 168 -> 64 VGPRs at R = 2 (five blocks of three waves per CU at D = 768).  Same partials layout [block][4][D]; the grid is exactly the resident
+// number of blocks.  profiles/r06_res_ln_bwd_cols.txt.
+template <typename T, int NV, int VEC, int R, int MINW = 1>
+__global__ __launch_bounds__(NV * 64, MINW) void res_ln_bwd_cols_kernel(const T *__restrict__ g_a, const float *__restrict__ g_xnew,
+                                                                  const float *__restrict__ x_new, const float *__restrict__ mean,
+                                                                  const float *__restrict__ rstd, const float *__restrict__ lnw,
+                                                                  const T *__restrict__ y, const float *__restrict__ gamma,
+                                                                  const float *__restrict__ mask, long rows, int rows_per_sample,
+                                                                  float *__restrict__ g_x, T *__restrict__ g_y,
+                                                                  float *__restrict__ partials) {
+    constexpr int D = NV * VEC * 64;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = wave * 64 * VEC + lane * VEC;
+    __shared__ float xch[2][NV][2 * R];
+    float ww[VEC], gg[VEC];
+    load_vec<float, VEC>(lnw + c, ww);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) gg[j] = 1.0f;
+    if (y && gamma) load_vec<float, VEC>(gamma + c, gg);
+    float p_w[VEC], p_b[VEC], p_g[VEC], p_y[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { p_w[j] = 0.f; p_b[j] = 0.f; p_g[j] = 0.f; p_y[j] = 0.f; }
+    const long groups = (rows + R - 1) / R;
+    int slot = 0;
+    for (long grp = blockIdx.x; grp < groups; grp += gridDim.x, slot ^= 1) {
+        const long r0 = grp * R;
+        float xh[R][VEC], gxh[R][VEC], gin[R][VEC], yy[R][VEC], mu[R], rs[R], mk[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const long r = r0 + i;
+            const bool ok = r < rows;          // (uniform)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { xh[i][j] = 0.f; gxh[i][j] = 0.f; gin[i][j] = 0.f; yy[i][j] = 0.f; }
+            mu[i] = 0.f; rs[i] = 0.f; mk[i] = 0.f;
+            if (ok) {
+                load_vec<float, VEC>(x_new + r * D + c, xh[i]);
+                if (g_a) load_vec<T, VEC>(g_a + r * D + c, gxh[i]);
+                if (g_xnew) load_vec<float, VEC>(g_xnew + r * D + c, gin[i]);
+                if (y) load_vec<T, VEC>(y + r * D + c, yy[i]);
+                mu[i] = mean[r]; rs[i] = rstd[r];
+                mk[i] = mask ? mask[r / rows_per_sample] : 1.0f;
+            }
+        }
+        float cs[2 * R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                const float g = gxh[i][j];
+                const float xn = (xh[i][j] - mu[i]) * rs[i];
+                const float gw = g * ww[j];
+                xh[i][j] = xn;
+                gxh[i][j] = gw;
+                p_w[j] = __builtin_fmaf(g, xn, p_w[j]);
+                p_b[j] += g;
+                c1 += gw;
+                c2 = __builtin_fmaf(gw, xn, c2);
+            }
+            cs[2 * i] = wave_sum(c1);
+            cs[2 * i + 1] = wave_sum(c2);
+        }
+        if (NV > 1) {
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 2 * R; ++q) xch[slot][wave][q] = cs[q];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 2 * R; ++q) {
+                float t = xch[slot][0][q];
+#pragma unroll
+                for (int w = 1; w < NV; ++w) t += xch[slot][w][q];
+                cs[q] = t;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < R; ++i) {
+            const long r = r0 + i;
+            if (r < rows) {
+                const float c1 = cs[2 * i] * (1.0f / D), c2 = cs[2 * i + 1] * (1.0f / D);
+                float gt[VEC];
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) gt[j] = gin[i][j] + rs[i] * (gxh[i][j] - c1 - xh[i][j] * c2);
+                store_vec<float, VEC>(g_x + r * D + c, gt);
+                if (y) {
+                    float gy[VEC];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        gy[j] = mk[i] * gg[j] * gt[j];
+                        p_g[j] = __builtin_fmaf(mk[i] * yy[i][j], gt[j], p_g[j]);
+                        p_y[j] += to_f<T>(from_f<T>(gy[j]));  // the bias gradient sums the stored (rounded) g_y
+                    }
+                    store_vec<T, VEC>(g_y + r * D + c, gy);
+                }
+            }
+        }
+    }
+    float *pr = partials + (size_t)blockIdx.x * 4 * D + c;
+    store_vec<float, VEC>(pr, p_w);
+    store_vec<float, VEC>(pr + D, p_b);
+    store_vec<float, VEC>(pr + 2 * D, p_g);
+    store_vec<float, VEC>(pr + 3 * D, p_y);
+}
+
 // out[q][c] (+)= sum over blocks of partials[block][q][c] in a fixed order.  One 256-thread block per 16 columns:
 // 16 row lanes x 16 columns (64-byte segments), each lane strides over the partial rows (up to 32 independent loads in
 // flight per thread), then the 16 lanes are combined through LDS in a fixed order.  (The earlier 64-column x 4-lane shape
@@ -436,16 +547,34 @@ extern "C" int xq_res_ln_backward(const void *g_a, const float *g_xnew, const fl
     if (!x_new || !mean || !rstd || !lnw || !g_x || !partials) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     if (y && !g_y) return xq_set_error(XQ_EINVAL, "%s: g_y required when y is given", fn);
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = row_blocks(rows);
+    static const int impl = [] { const char *e = getenv("XQ_RES_LN_BWD"); return e ? atoi(e) : 1; }();        // >= 1: columns split over the waves (round 6); 0: one wave per row
+    static const int bpc_env = [] { const char *e = getenv("XQ_RES_LN_BWD_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();
+    int blocks = row_blocks(rows);
     const double asz = act_bf16 ? 2.0 : 4.0;
     const int pslot = xq::prof_begin(XQ_PROF_RES_LN_BWD, (double)rows * D * ((g_a ? asz : 0.0) + (g_xnew ? 4.0 : 0.0) + 4.0 + (y ? 2.0 * asz : 0.0) + 4.0), s);
-#define BWD_BF16(NV, VEC) hipLaunchKernelGGL((res_ln_bwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const bf16 *)g_a, g_xnew, \
-        x_new, mean, rstd, lnw, (const bf16 *)y, gamma, mask, (long)rows, rows_per_sample, g_x, (bf16 *)g_y, partials)
-#define BWD_F32(NV, VEC) hipLaunchKernelGGL((res_ln_bwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const float *)g_a, g_xnew, \
-        x_new, mean, rstd, lnw, (const float *)y, gamma, mask, (long)rows, rows_per_sample, g_x, (float *)g_y, partials)
+    // column-split kernel: exactly the resident number of blocks (a partial second round of blocks costs 20 %: profiles/r06_res_ln_bwd_cols.txt)
+#define COLS_LAUNCH(T, NV, VEC, RB, MINW) do { \
+        auto kfn = res_ln_bwd_cols_kernel<T, NV, VEC, RB, MINW>; \
+        static int occ = 0; \
+        if (!occ) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, NV * 64, 0) != hipSuccess || occ < 1) occ = 1; } \
+        long b = (rows + RB - 1) / RB; \
+        const long cap = (long)num_cus() * (bpc_env > 0 ? bpc_env : occ); \
+        if (b > cap) b = cap; \
+        if (b < blocks) blocks = (int)b;        /* (never more partial rows than xq_row_partials_blocks promised) */ \
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(NV * 64), 0, s, (const T *)g_a, g_xnew, x_new, mean, rstd, lnw, (const T *)y, gamma, mask, (long)rows, \
+                           rows_per_sample, g_x, (T *)g_y, partials); } while (0)
+    // R = 2 rows per iteration at >= 4 waves per SIMD (<= 128 VGPRs; 64 used): 65 664 x 768 0.200 -> 0.170 ms, x 384 0.122 -> 0.093 ms with the finalize;
+    // R = 4: 0.176 / 0.103 (146 VGPRs, 3 waves), R = 4 forced to 128 VGPRs or R = 8: slower than the one-wave-per-row kernel
+#define BWD_BF16(NV, VEC) do { if (impl >= 1) COLS_LAUNCH(bf16, NV, VEC, 2, 4); \
+    else hipLaunchKernelGGL((res_ln_bwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const bf16 *)g_a, g_xnew, \
+        x_new, mean, rstd, lnw, (const bf16 *)y, gamma, mask, (long)rows, rows_per_sample, g_x, (bf16 *)g_y, partials); } while (0)
+#define BWD_F32(NV, VEC) do { if (impl >= 1) COLS_LAUNCH(float, NV, VEC, 2, 1); \
+    else hipLaunchKernelGGL((res_ln_bwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, (const float *)g_a, g_xnew, \
+        x_new, mean, rstd, lnw, (const float *)y, gamma, mask, (long)rows, rows_per_sample, g_x, (float *)g_y, partials); } while (0)
     if (act_bf16) { DISPATCH_D(D, BWD_BF16) } else { DISPATCH_D(D, BWD_F32) }
 #undef BWD_BF16
 #undef BWD_F32
+#undef COLS_LAUNCH
     launch_finalize(partials, blocks, 4, D, g_lnw, g_lnb, g_gamma, g_ybias, accumulate, s);
     xq::prof_end(pslot, s);
     return xq_check_launch(fn);
