@@ -81,6 +81,7 @@ SIGNATURES = {
     "xq_lpips_level_backward": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_lpips_level_backward_fused": (ctypes.c_int, [vp, vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
     "xq_conv3x3_pack_weights": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp]),
+    "xq_conv3x3_pack_weights_batched": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int64, vp]),
     "xq_conv3x3_nhwc_bf16_takes_out_mask": (ctypes.c_int, [ctypes.c_int, ctypes.c_int]),
     "xq_conv3x3_nhwc_bf16": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                             ctypes.c_int, vp, vp, vp]),

@@ -210,6 +210,40 @@ extern "C" int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int fo
     return xq_check_launch("pack_conv3x3_weights_kernel");
 }
 
+// Every registered 3x3 weight of an arena in ONE launch behind the optimizer step (round 6: the CNN tokenizer repacked 69 weights x 2 layouts
+// with 138 launches of 8 us per train step).  table: DEVICE int64 [n][6] = {fp32 source W, forward pack or 0, data-gradient pack or 0 (device
+// addresses), Cout, Cin, first block}; a weight owns ceil(Cout * Cin * 9 / 256) consecutive blocks.
+__global__ __launch_bounds__(256) void pack_conv3x3_weights_batched_kernel(const long *__restrict__ table, int n) {
+    const long t = blockIdx.x;
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[6 * mid + 5] <= t) lo = mid; else hi = mid - 1;
+    }
+    const long *e = table + 6 * lo;
+    const float *W = reinterpret_cast<const float *>(e[0]);
+    __hip_bfloat16 *Wf = reinterpret_cast<__hip_bfloat16 *>(e[1]), *Wd = reinterpret_cast<__hip_bfloat16 *>(e[2]);
+    const int Cout = (int)e[3], Cin = (int)e[4];
+    const long i = (t - e[5]) * 256 + threadIdx.x;
+    if (i >= (long)Cout * Cin * 9) return;
+    const int kx = (int)(i % 3), ky = (int)((i / 3) % 3);
+    const int c = (int)((i / 9) % Cin), nn = (int)(i / (9L * Cin));
+    const __hip_bfloat16 v = __float2bfloat16(W[i]);
+    if (Wf) Wf[(long)nn * 9 * Cin + (ky * 3 + kx) * Cin + c] = v;
+    if (Wd) Wd[(long)c * 9 * Cout + ((2 - ky) * 3 + (2 - kx)) * Cout + nn] = v;
+}
+
+extern "C" int xq_conv3x3_pack_weights_batched(const int64_t *table, int n_weights, int64_t blocks, xq_stream_t stream) {
+    const char *fn = "xq_conv3x3_pack_weights_batched";
+    if (n_weights < 0 || blocks < 0) return xq_set_error(XQ_EINVAL, "%s: negative count", fn);
+    if (n_weights == 0 || blocks == 0) return XQ_OK;
+    if (!table) return xq_set_error(XQ_EINVAL, "%s: null table", fn);
+    if (blocks > 0x7fffffffL) return xq_set_error(XQ_EINVAL, "%s: %ld blocks exceed the grid", fn, (long)blocks);
+    static_assert(sizeof(long) == sizeof(int64_t), "table entries are read as long");
+    hipLaunchKernelGGL(pack_conv3x3_weights_batched_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const long *)table, n_weights);
+    return xq_check_launch("pack_conv3x3_weights_batched_kernel");
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // 64 -> 64 channels (conv1_2 of the LPIPS VGG16 trunk at 256^2 x 128 images, forward and data gradient: 4.3 GB of activations per
 // call against 0.6 TFLOP — the layer is HBM-bound on paper, 0.45 ms at 5 TB/s, and took 1.47 ms on the 128-pixel kernel above, which

@@ -783,13 +783,19 @@ def _packed_conv_weight(weight, for_data_grad: bool):
         return cache[1]
     Cout, Cin = weight.shape[0], weight.shape[1]
     w32 = weight.detach().float().contiguous()
-    if for_data_grad:  # rows = input channels, padded with zero rows to the kernel's 64-channel output tile
-        wp = torch.zeros(((Cin + 63) // 64 * 64, 9 * Cout), dtype=torch.bfloat16, device=weight.device)
-    else:
-        wp = torch.empty((Cout, 9 * Cin), dtype=torch.bfloat16, device=weight.device)
+    wp = None if arena is None else arena.conv_pack_buffer(weight, for_data_grad)    # (a registered buffer is repacked in place)
+    if wp is not None and wp.device != weight.device:
+        wp = None
+    if wp is None:
+        if for_data_grad:  # rows = input channels, padded with zero rows to the kernel's 64-channel output tile
+            wp = torch.zeros(((Cin + 63) // 64 * 64, 9 * Cout), dtype=torch.bfloat16, device=weight.device)
+        else:
+            wp = torch.empty((Cout, 9 * Cin), dtype=torch.bfloat16, device=weight.device)
     with torch.cuda.device(weight.device):
         rc = _lib.lib().xq_conv3x3_pack_weights(ptr(w32), Cout, Cin, int(for_data_grad), ptr(wp), _stream(weight))
     check(rc, "xq_conv3x3_pack_weights")
+    if arena is not None and w32.data_ptr() == weight.data_ptr():
+        arena.register_conv_pack(weight, for_data_grad, wp)     # the optimizer step keeps it current from now on (one batched launch)
     setattr(weight, key, (stamp, wp))
     return wp
 

@@ -27,6 +27,8 @@ from ._lib import marker as _marker
 
 # round 6: [in][out] bf16 copies of the Linear weights for the data gradients (FlatArena._init_transposed_shadows); 0 = the NN products on W as stored
 TRANSPOSED_SHADOWS = os.environ.get("XQ_DGRAD_NT", "1") == "1"
+# round 6: the packed 3x3 conv weights of an arena refreshed by one launch behind the optimizer step; 0 = repacked per weight on the next use
+CONV_PACKS_BATCHED = os.environ.get("XQ_CONV_PACKS_BATCHED", "1") == "1"
 
 
 def get_random_ratio(randomness_anneal_start, randomness_anneal_end, end_ratio, cur_step):
@@ -71,6 +73,9 @@ class FlatArena:
                 for p, o in zip(self.params, self.offsets):
                     p._xq_w16 = self.p16[o:o + p.numel()].view(p.shape)
         self._init_transposed_shadows()
+        # packed bf16 layouts of the 3x3 conv weights (ops_dense._packed_conv_weight registers them on first use): refreshed in one launch
+        # behind the optimizer step instead of one launch per weight and layout on the next forward / backward
+        self._conv_packs, self._conv_table, self._conv_blocks = {}, None, 0
         self.step_count = 0
         # `epoch` counts the updates that reach the masters through raw pointers (the optimizer kernel, resync): those never
         # bump torch's per-tensor version counter, so every cache derived from a parameter (packed conv weights, ...) keys
@@ -113,6 +118,43 @@ class FlatArena:
             stream = ctypes.c_void_p(torch.cuda.current_stream(self.p16.device).cuda_stream)
             rc = _lib.lib().xq_transpose_bf16_batched(ptr(self.p16), ptr(self.p16t), ptr(self._t_table), self._t_count, self._t_tiles, stream)
         check(rc, "xq_transpose_bf16_batched")
+
+    def register_conv_pack(self, p, for_data_grad: bool, wp):
+        """ops_dense._packed_conv_weight packed `p` on its own (first use, or after a resync): from now on the optimizer step refreshes `wp`"""
+        if not CONV_PACKS_BATCHED or p.dim() != 4 or tuple(p.shape[2:]) != (3, 3):
+            return
+        e = self._conv_packs.setdefault(id(p), [p, None, None])
+        if e[1 + int(for_data_grad)] is not wp:
+            e[1 + int(for_data_grad)] = wp
+            self._conv_table = None
+
+    def conv_pack_buffer(self, p, for_data_grad: bool):
+        """the registered pack buffer of `p` (reused in place by a lazy repack), or None"""
+        e = self._conv_packs.get(id(p))
+        return None if e is None else e[1 + int(for_data_grad)]
+
+    def refresh_conv_packs(self):
+        """repack every registered 3x3 weight from the fp32 masters (one xq_conv3x3_pack_weights_batched launch) and stamp the caches current"""
+        if not self._conv_packs:
+            return
+        dev = self.p.device
+        if self._conv_table is None:
+            rows, blocks = [], 0
+            for p, wf, wd in self._conv_packs.values():
+                rows.append((p.data_ptr(), 0 if wf is None else wf.data_ptr(), 0 if wd is None else wd.data_ptr(), p.shape[0], p.shape[1], blocks))
+                blocks += (p.numel() + 255) // 256
+            self._conv_table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self._conv_blocks = blocks
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            rc = _lib.lib().xq_conv3x3_pack_weights_batched(ptr(self._conv_table), len(self._conv_packs), self._conv_blocks, stream)
+        check(rc, "xq_conv3x3_pack_weights_batched")
+        for p, wf, wd in self._conv_packs.values():
+            stamp = (p._version, self.epoch)
+            if wf is not None:
+                p._xq_pack_fwd = (stamp, wf)
+            if wd is not None:
+                p._xq_pack_dgrad = (stamp, wd)
 
     @torch.no_grad()
     def resync(self, ema: bool = False):
@@ -463,6 +505,7 @@ class ArenaOptimizer:
                                                          ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
                     check(rc, "xq_adamw_ema_step_ex")
                     a.refresh_transposed_shadows()
+                    a.refresh_conv_packs()
                     return
                 rc = _lib.lib().xq_adamw_ema_step_ex(ptr(a.p), ptr(a.g), ptr(a.m), ptr(a.v), ptr(a.ema), ptr(a.p16), a.numel,
                                                      ctypes.c_float(self.lr), ctypes.c_float(self.betas[0]),
@@ -471,6 +514,7 @@ class ArenaOptimizer:
                                                      ctypes.c_float(self.ema_decay), ctypes.c_float(1.0 / self.world), 1, stream)
             check(rc, "xq_adamw_ema_step_ex")
             a.refresh_transposed_shadows()
+            a.refresh_conv_packs()
         else:
             self._step_host()
 

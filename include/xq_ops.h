@@ -26,7 +26,7 @@ extern "C" {
 
 #define XQ_ABI_VERSION 3      /* 2: round 5's entry points (xq_adamw_ema_step_ex, xq_grad_norm_clip, xq_sn_batched_*, xq_token_assemble_*, ...);
                                   3: round 6 (xq_gemm_fused_schedule, XQ_GEMM_DUO / _PDUO, xq_gemm_colpart_rows = 2 * ceil(M / 128) + _rows_written,
-                                     xq_gemm_bf16_nt_gelu_bwd, xq_transpose_bf16_batched) */
+                                     xq_gemm_bf16_nt_gelu_bwd, xq_transpose_bf16_batched, xq_conv3x3_pack_weights_batched) */
 
 #define XQ_OK 0
 #define XQ_EINVAL (-1)   /* bad shape / null pointer / unsupported size */
@@ -254,6 +254,10 @@ int xq_lpips_level_backward_fused(const void *f0, const void *f1, const float *w
 /* W [Cout][Cin][3][3] fp32 (device) -> Wp bf16 [Cout][9*Cin] with k = (ky*3+kx)*Cin + c (for_data_grad = 0), or the
  * rotated/transposed pack [Cin][9*Cout] that turns the same kernel into the data-gradient conv (for_data_grad = 1). */
 int xq_conv3x3_pack_weights(const float *W, int Cout, int Cin, int for_data_grad, void *Wp, xq_stream_t stream);
+/* the same for every registered weight of an arena in one launch (round 6).  table: DEVICE int64 [n_weights][6] = {fp32 source W (device address),
+ * forward pack [Cout][9 Cin] or 0, data-gradient pack [Cin rounded up to 64][9 Cout] or 0 (pad rows stay as the caller zeroed them), Cout, Cin,
+ * first block}; a weight owns ceil(Cout * Cin * 9 / 256) consecutive blocks, `blocks` = their total. */
+int xq_conv3x3_pack_weights_batched(const int64_t *table, int n_weights, int64_t blocks, xq_stream_t stream);
 
 /* Y[b,y,x,n] = act(bias[n] + sum_{ky,kx,c} X[b,y+ky-1,x+kx-1,c] * W[n][c][ky][kx]); X [B][H][W][Cin], Y [B][H][W][Cout]
  * bf16 NHWC (= torch channels_last); bias fp32 [Cout] nullable; relu != 0 fuses ReLU.  Cin % 64 == 0, Cout % 64 == 0.

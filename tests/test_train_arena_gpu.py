@@ -44,6 +44,50 @@ def test_packed_conv_weights_follow_the_optimizer():
     assert (xg.grad.float() - xr.grad).abs().max().item() <= 2e-2 * xr.grad.abs().max().item()
 
 
+def test_optimizer_step_refreshes_the_registered_conv_packs_in_one_launch():
+    """round 6: after the first use, the packed layouts of an arena's 3x3 weights are rewritten by ONE xq_conv3x3_pack_weights_batched launch behind
+    the optimizer kernel and stamped current — the next forward / backward finds them, and they equal a fresh per-weight pack of the new masters"""
+    from imagefolder_amd import _lib, nn_ops, ops_dense
+    from imagefolder_amd._lib import ptr
+    from imagefolder_amd.train import ArenaOptimizer
+    torch.manual_seed(0)
+    convs = [torch.nn.Conv2d(64, 128, 3, padding=1).cuda(), torch.nn.Conv2d(128, 64, 3, padding=1).cuda(), torch.nn.Conv2d(192, 64, 3, padding=1).cuda()]
+    opt = ArenaOptimizer([p for c in convs for p in c.parameters()], lr=0.05, weight_decay=0.0, use_ema=False)
+    a = opt.arena
+    for c in convs[:2]:                                  # the third weight is never used: never registered
+        ops_dense._packed_conv_weight(c.weight, False)
+    ops_dense._packed_conv_weight(convs[0].weight, True)
+    assert len(a._conv_packs) == 2
+    bufs = {id(c.weight): (c.weight._xq_pack_fwd[1], getattr(c.weight, "_xq_pack_dgrad", (None, None))[1]) for c in convs[:2]}
+    before = bufs[id(convs[0].weight)][0].clone()
+    for _ in range(2):
+        a.g.normal_()
+        opt.step()
+    for c in convs[:2]:
+        w = c.weight
+        stamp = (w._version, a.epoch)
+        assert w._xq_pack_fwd[0] == stamp and w._xq_pack_fwd[1] is bufs[id(w)][0], "not stamped current / buffer replaced"
+        assert ops_dense._packed_conv_weight(w, False) is bufs[id(w)][0]        # a hit: no repack
+        for kind, buf in ((0, bufs[id(w)][0]), (1, bufs[id(w)][1])):
+            if buf is None:
+                continue
+            ref = torch.zeros_like(buf)
+            st = torch.cuda.current_stream().cuda_stream
+            import ctypes
+            assert _lib.lib().xq_conv3x3_pack_weights(ptr(w.detach().float().contiguous()), w.shape[0], w.shape[1], kind, ptr(ref), ctypes.c_void_p(st)) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(buf, ref), ("fwd", "dgrad")[kind]
+    assert not torch.equal(before, bufs[id(convs[0].weight)][0]), "the steps did not move the weights: test is vacuous"
+    assert not hasattr(convs[2].weight, "_xq_pack_fwd")
+    # a resync (checkpoint load) invalidates the stamps; the lazy repack reuses the registered buffer in place
+    with torch.no_grad():
+        a.p.mul_(0.5)
+    a.resync()
+    w = convs[0].weight
+    assert ops_dense._packed_conv_weight(w, False) is bufs[id(w)][0]
+    assert torch.equal(bufs[id(w)][0].view(128, 9, 64).permute(0, 2, 1).reshape(128, 64, 3, 3), w.detach().to(torch.bfloat16))
+
+
 def test_gradient_clipping_on_the_device_matches_clip_grad_norm_then_adamw():
     """xq_grad_norm_clip + xq_adamw_ema_step_ex (no host read between them) == torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW
     (xqgan_train.py:456-459) on the same gradients: ragged tensor sizes (the arena's tail path), a clip that bites, one that does not,
