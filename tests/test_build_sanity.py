@@ -78,4 +78,4 @@ def test_k_loop_of_the_persistent_gemm_kernels_is_clean(tmp_path):
         assert not [o for o in ops if o.startswith("scratch_") or o in ("v_readlane_b32", "v_writelane_b32")], f"spill traffic inside the K loop of {name}"
         assert sum(o == "s_barrier" for o in ops) == 4, name
         checked += 1
-    assert checked == 5, f"{checked} persistent kernels found (NT, NN, TN, NT + GELU, NN + GELU')"
+    assert checked == 6, f"{checked} persistent kernels found (NT, NN, TN, NT + GELU, NN + GELU', NT + GELU' on the transposed weight)"
