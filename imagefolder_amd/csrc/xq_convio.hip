@@ -194,6 +194,75 @@ __global__ __launch_bounds__(256) void conv3x3_to3_kernel(const __hip_bfloat16 *
     }
 }
 
+// Round 6: the same convolution on 2-D tiles with the input halo in LDS.  The kernel above re-reads every input pixel nine times through L1 / L2
+// (its 32-pixel row segments share nothing between grid-stride passes): 9.7 GB of L2 -> L1 traffic for the 1.07 GB gradient of VGG conv1_1, 855 us
+// against 0.21 ms of HBM traffic.  Here a block owns TH x 32 output pixels: the (TH + 2) x 34 halo goes global -> registers -> LDS once (16-byte
+// chunks, out-of-image pixels as zeros), then the LPP chunk lanes of a pixel read their nine taps from LDS.  Same arithmetic per lane, same fold
+// over the chunk lanes, same rounding: bit-identical outputs.  Pixel slots of C * 2 + 16 bytes (the pad keeps the 16-byte reads of neighbouring
+// pixels on different banks).
+template <int LPP, int TH>
+__global__ __launch_bounds__(256) void conv3x3_to3_tiled_kernel(const __hip_bfloat16 *__restrict__ X, const unsigned *__restrict__ Wq,
+                                                                const float *__restrict__ bias, int B, int H, int W, int tiles_y, int tiles_x,
+                                                                long ntiles, __hip_bfloat16 *__restrict__ Y) {
+    constexpr int C = LPP * 8, C2 = C / 2, TW = 32, HW = TW + 2, SLOTS = (TH + 2) * HW, PITCH = C * 2 + 16, PPP = 256 / LPP;   // pixels per pass
+    extern __shared__ __attribute__((aligned(16))) char to3_smem[];
+    const int chunk = threadIdx.x % LPP, pl = threadIdx.x / LPP;
+    unsigned w[3][9][4];
+#pragma unroll
+    for (int co = 0; co < 3; ++co)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) w[co][tap][q] = Wq[(co * 9 + tap) * C2 + chunk * 4 + q];
+    const float b0 = bias ? bias[0] : 0.0f, b1 = bias ? bias[1] : 0.0f, b2 = bias ? bias[2] : 0.0f;
+    const long plane = (long)H * W;
+    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int tx = (int)(t % tiles_x), ty = (int)((t / tiles_x) % tiles_y);
+        const long b = t / ((long)tiles_x * tiles_y);
+        const int y0 = ty * TH, x0 = tx * TW;
+        __syncthreads();                                   // the previous tile's reads are done
+        for (int i = threadIdx.x; i < SLOTS * LPP; i += 256) {
+            const int slot = i / LPP, ch = i % LPP;
+            const int yy = y0 + slot / HW - 1, xx = x0 + slot % HW - 1;
+            const bool ok = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (ok) v = *reinterpret_cast<const uint4 *>(X + ((b * H + yy) * (long)W + xx) * C + ch * 8);
+            *reinterpret_cast<uint4 *>(to3_smem + slot * PITCH + ch * 16) = v;
+        }
+        __syncthreads();
+#pragma unroll 1
+        for (int pass = 0; pass < TH * TW / PPP; ++pass) {
+            const int idx = pass * PPP + pl, py = idx / TW, px = idx % TW;
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f;
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(to3_smem + ((py + tap / 3) * HW + px + tap % 3) * PITCH + chunk * 16);
+                const unsigned e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bf2 xv = __builtin_bit_cast(bf2, e[q]);
+                    a0 = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(bf2, w[0][tap][q]), a0, false);
+                    a1 = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(bf2, w[1][tap][q]), a1, false);
+                    a2 = __builtin_amdgcn_fdot2_f32_bf16(xv, __builtin_bit_cast(bf2, w[2][tap][q]), a2, false);
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < LPP; o <<= 1) {
+                a0 += __shfl_xor(a0, o);
+                a1 += __shfl_xor(a1, o);
+                a2 += __shfl_xor(a2, o);
+            }
+            const int y = y0 + py, x = x0 + px;
+            if (chunk == 0 && y < H && x < W) {
+                const long o = b * 3 * plane + (long)y * W + x;
+                Y[o] = __float2bfloat16(a0 + b0);
+                Y[o + plane] = __float2bfloat16(a1 + b1);
+                Y[o + 2 * plane] = __float2bfloat16(a2 + b2);
+            }
+        }
+    }
+}
+
 // cols[p][k] (bf16, k = (ky*3+kx)*3+ci for k < 27, zero for 27..31)
 template <typename TIN>
 __global__ __launch_bounds__(256) void im2col27_kernel(const TIN *__restrict__ X, int B, int H, int W, __hip_bfloat16 *__restrict__ cols) {
@@ -384,6 +453,26 @@ extern "C" int xq_conv3x3_to3_forward(const void *x_nhwc, const void *w_pairs, c
     // weight operand and per-lane 16-byte gathers of the pixels — 1040 us against this kernel's 874 us at 64 channels, 745 against 425 at 128:
     // a lane-per-pixel gather touches 64 cache lines per load instruction where the 8-lanes-per-pixel form below touches 8,
     // profiles/r04_conv_to3_mfma_rejected.txt)
+    static const int tiled = [] { const char *e = getenv("XQ_TO3_TILED"); return e ? atoi(e) : 1; }();      // 1: 2-D tiles with the halo in LDS at 64 channels (round 6); 0: row segments
+    if (tiled && C == 64) {
+        // 8 x 32 output pixels per tile: 10 x 34 halo slots of 144 B = 47.8 KiB, three blocks per CU.  128 x 65 536 pixels x 64 channels (the data
+        // gradient of VGG conv1_1): 0.868 -> 0.572 ms, bit-identical (tools/bench_to3.py, profiles/r06_conv_to3_tiled.txt).  At 128 channels the form
+        // with 4-row tiles (54 KiB) measured 0.496 against 0.456 ms for the row-segment kernel: kept on the latter.
+        constexpr int TH = 8;
+        const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + 31) / 32;
+        const long ntiles = (long)B * tiles_y * tiles_x;
+        const int lds = (TH + 2) * 34 * (64 * 2 + 16);
+        long blocks = ntiles;
+        const long cap = (long)num_cus() * 3;
+        if (blocks > cap) blocks = cap;
+        auto k = conv3x3_to3_tiled_kernel<8, TH>;
+        static unsigned long long devs = 0;
+        if (first_call_on_this_device(&devs) && hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return xq_set_error(XQ_ELAUNCH, "%s: cannot reserve %d bytes of LDS", fn, lds);
+        hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(256), lds, s, (const __hip_bfloat16 *)x_nhwc, (const unsigned *)w_pairs, bias, B, H, W, tiles_y,
+                           tiles_x, ntiles, (__hip_bfloat16 *)y_planar);
+        return xq_check_launch(fn);
+    }
     const int ppb = 256 / (C / 8);
     long blocks = (total + ppb - 1) / ppb;
     const long cap = (long)num_cus() * 16;
