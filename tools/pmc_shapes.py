@@ -37,6 +37,8 @@ def cases():
         bias = torch.randn(N, device=dev)
         out.append((f"gemm nt {name} M{M} N{N} K{K}", ("gemm_",), 2 * (M * K + N * K + M * N) + 4 * N, lambda x=x, w=w, b=bias: od.gemm_nt(x, w, b)))
         out.append((f"gemm nn {name} M{M} N{K} K{N}", ("gemm_",), 2 * (M * N + N * K + M * K), lambda g=g, w=w: od.gemm_nn(g, w)))
+        wt = w.t().contiguous()     # round 6: the data gradient as the step runs it — NT on the transposed weight shadow
+        out.append((f"gemm nt-dgrad {name} M{M} N{K} K{N}", ("gemm_",), 2 * (M * N + N * K + M * K), lambda g=g, wt=wt: od.gemm_nt(g, wt, None)))
         out.append((f"gemm tn {name} R{M} P{N} Q{K}", ("gemm_", "slab_reduce"), 2 * (M * N + M * K) + 4 * N * K, lambda g=g, x=x: od.gemm_tn(g, x)))
     B, Ntok, H = 128, 513, 12
     qkv = torch.randn(B, Ntok, 3 * H * 64, device=dev).to(torch.bfloat16).requires_grad_(True)

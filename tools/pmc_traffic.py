@@ -16,7 +16,7 @@ def per_kernel(path, counter):
 
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 groups = {"conv3x3_kernel": "conv3x3", "attn_fwd_kernel": "attn_fwd", "attn_bwd_dkdv_kernel": "attn_bwd_dkdv", "attn_bwd_dq_kernel": "attn_bwd_dq",
-          "assign_kernel": "assign", "gemm_": "gemm", "gelu_fwd": "gelu_fwd", "gelu_bwd": "gelu_bwd", "conv3x3_wgrad": "conv3x3_wgrad", "res_ln_bwd_kernel": "res_ln_bwd", "res_ln_fwd_kernel": "res_ln_fwd", "adamw_ema_kernel": "adamw_ema",
+          "assign_kernel": "assign", "gemm_": "gemm", "gelu_fwd": "gelu_fwd", "gelu_bwd": "gelu_bwd", "conv3x3_wgrad": "conv3x3_wgrad", "res_ln_bwd_kernel|res_ln_bwd_cols_kernel": "res_ln_bwd", "res_ln_fwd_kernel": "res_ln_fwd", "adamw_ema_kernel": "adamw_ema",
           # round 6: every HBM-bound roofline entry of bench.py has its own row (bench.py TRAFFIC_KEYS)
           "conv3x3_from3": "conv3x3_from3", "gn_reduce|gn_apply|gn_finalize": "gn", "vq_finish_kernel|vq_backward_kernel|vq_codebook_grad_kernel": "vq_elem"}
 out = {}
