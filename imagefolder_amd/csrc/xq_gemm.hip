@@ -1693,14 +1693,17 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float *__restric
 
 // ACT_GELU_BWD tail tiles: g_h = (sum of the splits' slabs, rounded to bf16) * gelu'(H), and the column sums of g_h over each 128-row
 // half of the tile -> colpart[2 * row_tile + half][N], exactly the rows the whole-tile epilogue writes for its tiles.
-// grid (tail tiles, 2 halves), 1024 threads: thread = (row lane 0..31, 8-column group 0..31), 4 rows each; fixed-order LDS reduction.
+// grid (tail tiles, 2 halves, 4 column quarters), 1024 threads: thread = (row of the half 0..127, 8-column group 0..7) — ONE row per thread.
+// (Until round 6: grid (tail tiles, 2) with four rows per thread — the tail tiles of M = 65 664 are the half-empty last tile row, so 12 of the
+// 24 blocks did all the work on 12 of 256 CUs: 18.7 us per launch.)  The column sums keep the order of that kernel — per 32-row lane the rows
+// r, r + 32, r + 64, r + 96, then the 32 lanes ascending — so colpart is unchanged bit for bit.
 __global__ __launch_bounds__(1024) void slab_reduce_gelu_bwd_kernel(const float *__restrict__ slabs, int nsplit, long first_tile, int tiles_n,
                                                                     long M, long N, long ldc, const __hip_bfloat16 *__restrict__ H,
                                                                     __hip_bfloat16 *__restrict__ out16, float *__restrict__ colpart, int gelu_tanh,
                                                                     int tile_rows, int move_back) {
     // tile_rows = 256: colpart row (m0 / 128) + half, 128 rows per half;  tile_rows = 128 (persistent duo schedule): colpart row 2 * tile row +
     // half, 64 rows per half, edge tiles moved back inside the matrix (their rows above the tile row's own first row are not summed again)
-    __shared__ float red[32][257];
+    __shared__ float red[128][65];
     const long t = blockIdx.x;
     const long tile = first_tile + t;
     const long trow = tile / tiles_n;
@@ -1711,13 +1714,11 @@ __global__ __launch_bounds__(1024) void slab_reduce_gelu_bwd_kernel(const float 
         if (n0 > N - 256) n0 = N - 256;
     }
     const int half_rows = tile_rows / 2;
-    const int half = blockIdx.y, rl0 = threadIdx.x >> 5, cl = (threadIdx.x & 31) * 8;
-    const long gc = n0 + cl;
+    const int half = blockIdx.y, quarter = blockIdx.z, rh = threadIdx.x >> 3, cq = (threadIdx.x & 7) * 8;
+    const int rl = half_rows * half + rh, cl = 64 * quarter + cq;
+    const long gr = m0 + rl, gc = n0 + cl;
     float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < half_rows / 32; ++i) {
-        const int rl = half_rows * half + 32 * i + rl0;
-        const long gr = m0 + rl;
-        if (gr >= M || gc + 8 > N) continue;
+    if (rh < half_rows && gr < M && gc + 8 <= N) {
         float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const uint4 hq = *reinterpret_cast<const uint4 *>(H + gr * ldc + gc);
         const float *sp0 = slabs + ((size_t)(t * nsplit) * tile_rows + rl) * 256 + cl;
@@ -1752,20 +1753,27 @@ __global__ __launch_bounds__(1024) void slab_reduce_gelu_bwd_kernel(const float 
             const act_f2 d2 = act_f2{bf16_lo(vr), bf16_hi(vr)} * (gelu_tanh ? gelu_grad2<true>(h2) : gelu_grad2<false>(h2));
             o[e] = pack_bf16(d2.x, d2.y);
             if (gr >= m_lo) {
-                cs[2 * e] += bf16_lo(o[e]);
-                cs[2 * e + 1] += bf16_hi(o[e]);
+                cs[2 * e] = bf16_lo(o[e]);
+                cs[2 * e + 1] = bf16_hi(o[e]);
             }
         }
         *reinterpret_cast<uint4 *>(out16 + gr * ldc + gc) = make_uint4(o[0], o[1], o[2], o[3]);
     }
+    if (rh < 128) {
 #pragma unroll
-    for (int e = 0; e < 8; ++e) red[rl0][cl + e] = cs[e];
+        for (int e = 0; e < 8; ++e) red[rh][cq + e] = cs[e];
+    }
     __syncthreads();
-    if (colpart && threadIdx.x < 256) {
-        const long c = n0 + threadIdx.x;
+    if (colpart && threadIdx.x < 64) {
+        const long c = n0 + 64 * quarter + threadIdx.x;
         if (c < N) {
             float tsum = 0.f;
-            for (int r = 0; r < 32; ++r) tsum += red[r][threadIdx.x];
+            const int groups = half_rows / 32;       // 4 (256-row tiles) or 2 (128-row tiles): rows r, r + 32, ... of one 32-row lane first
+            for (int r = 0; r < 32; ++r) {
+                float lane_sum = 0.f;
+                for (int i = 0; i < groups; ++i) lane_sum += red[32 * i + r][threadIdx.x];
+                tsum += lane_sum;
+            }
             colpart[(tile_rows == 256 ? (m0 / 128) + half : 2 * trow + half) * N + c] = tsum;
         }
     }
@@ -1906,7 +1914,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
         // tail tiles: sum of the K-range slabs (+ bias / + the fused activation of the whole-tile epilogue)
         if (EPI == EPI_BF16 && pl.tail_tiles) {
             if (ACT == ACT_GELU_BWD)
-                hipLaunchKernelGGL(slab_reduce_gelu_bwd_kernel, dim3((unsigned)pl.tail_tiles, 2), dim3(1024), 0, s, (const float *)ws, pl.tail_splits,
+                hipLaunchKernelGGL(slab_reduce_gelu_bwd_kernel, dim3((unsigned)pl.tail_tiles, 2, 4), dim3(1024), 0, s, (const float *)ws, pl.tail_splits,
                                    pl.main_items, g.tiles_n, g.M, g.N, g.ldc, (const __hip_bfloat16 *)g.H, (__hip_bfloat16 *)g.C, g.colpart, g.gelu_tanh, 256, 0);
             else
                 hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)pl.tail_tiles, 32), dim3(256), 0, s, (const float *)ws, pl.tail_splits,
@@ -1939,7 +1947,7 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
             }
             if (pl.tail_tiles) {
                 if (ACT == ACT_GELU_BWD)
-                    hipLaunchKernelGGL(slab_reduce_gelu_bwd_kernel, dim3((unsigned)pl.tail_tiles, 2), dim3(1024), 0, s, (const float *)ws, pl.tail_splits,
+                    hipLaunchKernelGGL(slab_reduce_gelu_bwd_kernel, dim3((unsigned)pl.tail_tiles, 2, 4), dim3(1024), 0, s, (const float *)ws, pl.tail_splits,
                                        pl.main_items, g.tiles_n, g.M, g.N, g.ldc, (const __hip_bfloat16 *)g.H, (__hip_bfloat16 *)g.C, g.colpart, g.gelu_tanh,
                                        gm::BM_DUO, 1);
                 else
