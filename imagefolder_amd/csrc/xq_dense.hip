@@ -525,15 +525,25 @@ extern "C" int xq_res_ln_forward(const float *x, const void *y, const float *gam
     if (!x || !lnw || !lnb || !a || !mean || !rstd) return xq_set_error(XQ_EINVAL, "%s: null pointer", fn);
     if (rows < 0 || rows_per_sample < 1) return xq_set_error(XQ_EINVAL, "%s: bad rows", fn);
     hipStream_t s = (hipStream_t)stream;
-    const int blocks = row_blocks_fwd(rows);
+    int blocks = row_blocks_fwd(rows);
+    static const int fwd_bpc = [] { const char *e = getenv("XQ_RES_LN_FWD_BLOCKS_PER_CU"); return e ? atoi(e) : 0; }();      // 0: the resident count
     const int pslot = xq::prof_begin(XQ_PROF_RES_LN_FWD, (double)rows * D * (4.0 + (y ? (act_bf16 ? 2.0 : 4.0) : 0.0) + (x_new ? 4.0 : 0.0) + (act_bf16 ? 2.0 : 4.0)), s);
-#define FWD_BF16(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<bf16, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const bf16 *)y, \
-        gamma, mask, (long)rows, rows_per_sample, lnw, lnb, eps, x_new, (bf16 *)a, mean, rstd)
-#define FWD_F32(NV, VEC) hipLaunchKernelGGL((res_ln_fwd_kernel<float, NV, VEC>), dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const float *)y, \
-        gamma, mask, (long)rows, rows_per_sample, lnw, lnb, eps, x_new, (float *)a, mean, rstd)
+    // grid = exactly the blocks the chip holds at once (76 VGPRs at D = 768: six blocks of four waves per CU, not the eight of XQ_FWD_BLOCKS_PER_CU —
+    // a partial second round of blocks cost the backward kernel 20 %, profiles/r06_res_ln_bwd_cols.txt)
+#define FWD_LAUNCH(T, NV, VEC) do { \
+        auto kfn = res_ln_fwd_kernel<T, NV, VEC>; \
+        static int occ = 0; \
+        if (!occ) { if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kfn, ROW_THREADS, 0) != hipSuccess || occ < 1) occ = XQ_FWD_BLOCKS_PER_CU; } \
+        const long cap = (long)num_cus() * (fwd_bpc > 0 ? fwd_bpc : occ); \
+        if (blocks > cap) blocks = (int)cap; \
+        hipLaunchKernelGGL(kfn, dim3(blocks), dim3(ROW_THREADS), 0, s, x, (const T *)y, gamma, mask, (long)rows, rows_per_sample, lnw, lnb, eps, x_new, \
+                           (T *)a, mean, rstd); } while (0)
+#define FWD_BF16(NV, VEC) FWD_LAUNCH(bf16, NV, VEC)
+#define FWD_F32(NV, VEC) FWD_LAUNCH(float, NV, VEC)
     if (act_bf16) { DISPATCH_D(D, FWD_BF16) } else { DISPATCH_D(D, FWD_F32) }
 #undef FWD_BF16
 #undef FWD_F32
+#undef FWD_LAUNCH
     xq::prof_end(pslot, s);
     return xq_check_launch(fn);
 }

@@ -72,6 +72,33 @@ def main():
             ms = statistics.median(t)
             nbytes = rows * D * (2 + 4 + 4 + 2 + 4 + 2)
             emit(f"{tag} res_ln_bwd rows {rows} D {D}: {ms:.4f} ms (incl. finalize) {nbytes / ms / 1e6:7.0f} GB/s  checksums " + " ".join(f"{v:.9e}" for v in sums))
+            # forward: x_new = x + mask * gamma * y; a = LayerNorm(x_new)
+            xin = torch.randn(rows, D, device="cuda")
+            xo = torch.empty_like(xin)
+            ao = torch.empty_like(y)
+            mo, ro = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+            lnb = torch.randn(D, device="cuda")
+
+            def fwd():
+                rc = lib.xq_res_ln_forward(ptr(xin), ptr(y), ptr(gamma), ptr(mask), rows, D, N, ptr(lnw), ptr(lnb), ctypes.c_float(1e-6), 1, ptr(xo), ptr(ao),
+                                           ptr(mo), ptr(ro), st)
+                assert rc == 0, rc
+
+            fwd()
+            torch.cuda.synchronize()
+            fsum = [xo.double().abs().sum().item(), ao.double().abs().sum().item(), mo.double().abs().sum().item(), ro.double().sum().item()]
+            t = []
+            for _ in range(a.rounds):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    fwd()
+                e1.record()
+                torch.cuda.synchronize()
+                t.append(e0.elapsed_time(e1) / a.iters)
+            ms = statistics.median(t)
+            tagf = f"XQ_RES_LN_FWD_BLOCKS_PER_CU={os.environ.get('XQ_RES_LN_FWD_BLOCKS_PER_CU', '(resident)')}"
+            emit(f"{tagf} res_ln_fwd rows {rows} D {D}: {ms:.4f} ms {rows * D * 12 / ms / 1e6:7.0f} GB/s  checksums " + " ".join(f"{v:.9e}" for v in fsum))
     if a.out:
         os.makedirs(os.path.dirname(a.out) or ".", exist_ok=True)
         with open(a.out, "a") as f:
