@@ -537,7 +537,14 @@ class DinoDisc(nn.Module):
         a fresh registration) is noticed by its data pointer and the stack is rebuilt."""
         st = self._sn_stacks.get(slot)
         if st is None or any(c._buffers[name].data_ptr() != st[i].data_ptr() or c._buffers[name].device != st.device for i, c in enumerate(convs)):
-            st = torch.stack([c._buffers[name].detach().float() for c in convs]).contiguous()
+            # (re)build: allocates and re-points the modules' buffers — never inside a stream capture (a graph would replay the power iteration
+            # on the old storage), and only for fp32 buffers (the caller falls back to the per-weight path otherwise: no silent dtype change).
+            # Note: the H rows of one stack alias ONE storage; state_dict() returns views of it (values and keys unchanged).
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("DinoDisc: the spectral-norm buffers were re-homed (.to() / re-registration) since the last forward; run one eager "
+                                   "forward before capturing so that the stacked buffers are rebuilt outside the capture")
+            assert all(c._buffers[name].dtype == torch.float32 for c in convs), "stacked spectral-norm buffers are fp32"
+            st = torch.stack([c._buffers[name].detach() for c in convs]).contiguous()
             for i, c in enumerate(convs):
                 c._buffers[name] = st[i]
             self._sn_stacks[slot] = st
@@ -555,6 +562,8 @@ class DinoDisc(nn.Module):
         for grp in groups:
             if any(tuple(c.weight_orig.shape) != tuple(grp[0].weight_orig.shape) or not c.training for c in grp):
                 return None
+            if any(c._buffers[n].dtype != torch.float32 for c in grp for n in ("weight_u", "weight_v")):
+                return None      # (e.g. after .half() / .double(): the per-weight path keeps the buffers' dtype)
         from . import ops_dense
         if not hasattr(self, "_sn_stacks"):
             self._sn_stacks = {}
