@@ -122,3 +122,35 @@ def test_round2_entry_points_validate_their_arguments_without_a_gpu():
     assert l.xq_adamw_ema_step_dev(one, one, one, one, None, None, 64, f(1e-3), f(0.9), f(0.95), f(1e-8), f(0.0), None, f(0.999), f(1.0), 1,
                                    None) != 0 and "coefficient" in err()
     assert l.xq_adamw_ema_step(one, one, one, one, None, None, 64, f(1e-3), f(0.9), f(0.95), f(1e-8), f(0.0), 0, f(0.999), f(1.0), 1, None) != 0
+
+
+def test_round6_entry_points_validate_their_arguments_without_a_gpu():
+    """the entry points added in round 6 (transposed weight shadows, the fused fc2 data gradient on them, batched conv weight packs, the schedule
+    switch): error codes before any device access, empty problems are no-ops, the row counts follow the schedule in force"""
+    from imagefolder_amd import _lib
+    l = _lib.lib()
+    one = ctypes.c_void_p(16)
+
+    def err():
+        return l.xq_last_error().decode()
+
+    assert l.xq_transpose_bf16_batched(None, one, one, 1, 1, None) != 0 and "null" in err()
+    assert l.xq_transpose_bf16_batched(one, one, one, -1, 1, None) != 0
+    assert l.xq_transpose_bf16_batched(None, None, None, 0, 0, None) == 0
+    assert l.xq_conv3x3_pack_weights_batched(None, 3, 12, None) != 0 and "null" in err()
+    assert l.xq_conv3x3_pack_weights_batched(None, 0, 0, None) == 0
+    # the fused fc2 data gradient on the transposed weight: same contract as the NN form
+    assert l.xq_gemm_bf16_nt_gelu_bwd(one, one, None, 512, 1024, 256, one, None, 0, None, 0, None) != 0 and "null" in err()
+    assert l.xq_gemm_bf16_nt_gelu_bwd(one, one, one, 512, 128, 256, one, None, 0, None, 0, None) != 0 and "N >= 256" in err()
+    assert l.xq_gemm_bf16_nt_gelu_bwd(None, None, None, 0, 1024, 256, None, None, 0, None, 0, None) == 0
+    # column-partial rows: allocation bound vs the rows the schedule in force writes
+    assert l.xq_gemm_colpart_rows(0) == 0 and l.xq_gemm_colpart_rows(65664) == 2 * 513
+    prev = l.xq_gemm_fused_schedule(3)
+    try:
+        assert l.xq_gemm_colpart_rows_written(65664, 3072) == 2 * 257
+        l.xq_gemm_fused_schedule(4)
+        assert l.xq_gemm_colpart_rows_written(65664, 3072) == 2 * 513
+        assert l.xq_gemm_colpart_rows_written(64, 3072) == 2          # below one duo tile: the persistent schedule runs
+        assert l.xq_gemm_colpart_rows_written(0, 3072) == 0
+    finally:
+        l.xq_gemm_fused_schedule(prev)
