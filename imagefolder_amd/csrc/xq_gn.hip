@@ -143,34 +143,40 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
 
 // one-pass statistics (gn_reduce_kernel<3>): S1_c = sum (x - K_c), S2_c = sum (x - K_c)^2 over the sample's HW pixels, fixed-order sums over the
 // slabs; mean = sum_c (S1_c + HW K_c) / n;  sum (x - mean)^2 = sum_c [S2_c - 2 (mean - K_c) S1_c + HW (mean - K_c)^2]   (fp64: B x G threads)
-__global__ __launch_bounds__(64) void gn_finalize_onepass_kernel(const float *__restrict__ part_c, const bf16 *__restrict__ x, int nslab, int HW, int C,
-                                                                 int G, float eps, float *__restrict__ mean, float *__restrict__ rstd) {
-    const int b = blockIdx.x, g = threadIdx.x;
+// Round 6: one WAVE per (sample, group) — the 64 lanes split the slabs of every channel and meet in a xor butterfly (fp64, fixed order), instead of
+// one THREAD per group walking cg x nslab x 2 strided loads one after the other (28 us per call at 256 slabs, 67 calls per step of the CNN config).
+__global__ __launch_bounds__(256) void gn_finalize_onepass_kernel(const float *__restrict__ part_c, const bf16 *__restrict__ x, int nslab, int HW, int C,
+                                                                  int G, float eps, float *__restrict__ mean, float *__restrict__ rstd) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    const int g = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (g >= G) return;
     const int cg = C / G;
     const double n = (double)HW * cg;
-    double tot = 0.0;
-    double s1[32], s2[32], kc[32];          // cg <= 32 (checked by the launcher)
+    // lane i (< cg <= 32) keeps channel i's S1, S2, K; every lane knows the group total
+    double tot = 0.0, my_a = 0.0, my_q = 0.0, my_k = 0.0;
     for (int i = 0; i < cg; ++i) {
         const int c = g * cg + i;
         double a = 0.0, q = 0.0;
-        for (int s = 0; s < nslab; ++s) {
+        for (int s = lane; s < nslab; s += 64) {
             a += (double)part_c[(((long)b * nslab + s) * 2 + 0) * C + c];
             q += (double)part_c[(((long)b * nslab + s) * 2 + 1) * C + c];
         }
-        s1[i] = a; s2[i] = q;
-        kc[i] = (double)__bfloat162float(x[((long)b * HW) * C + c]);
-        tot += a + (double)HW * kc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+        const double kc = (double)__bfloat162float(x[((long)b * HW) * C + c]);
+        tot += a + (double)HW * kc;
+        if (lane == i) { my_a = a; my_q = q; my_k = kc; }
     }
     const double mu = tot / n;
-    double m2 = 0.0;
-    for (int i = 0; i < cg; ++i) {
-        const double d = mu - kc[i];
-        m2 += s2[i] - 2.0 * d * s1[i] + (double)HW * d * d;
-    }
+    const double d = mu - my_k;
+    double m2 = lane < cg ? my_q - 2.0 * d * my_a + (double)HW * d * d : 0.0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
     if (m2 < 0.0) m2 = 0.0;
-    mean[b * G + g] = (float)mu;
-    rstd[b * G + g] = (float)(1.0 / sqrt(m2 / n + (double)eps));
+    if (lane == 0) {
+        mean[b * G + g] = (float)mu;
+        rstd[b * G + g] = (float)(1.0 / sqrt(m2 / n + (double)eps));
+    }
 }
 
 // element-wise passes: block (slab, sample); a thread keeps its 8 channels for the whole slab (as in gn_reduce_kernel), so the
@@ -294,7 +300,7 @@ extern "C" int xq_groupnorm_silu_forward(const void *x, const float *w, const fl
         float *part_c = workspace + (size_t)B * ns * G * 2;
         hipLaunchKernelGGL((gn_reduce_kernel<3>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
                            workspace, part_c);
-        hipLaunchKernelGGL(gn_finalize_onepass_kernel, dim3(B), dim3(64), 0, s, (const float *)part_c, xp, ns, HW, C, G, eps, mean, rstd);
+        hipLaunchKernelGGL(gn_finalize_onepass_kernel, dim3(B, (G + 3) / 4), dim3(256), 0, s, (const float *)part_c, xp, ns, HW, C, G, eps, mean, rstd);
     } else {
         hipLaunchKernelGGL((gn_reduce_kernel<0>), dim3(ns, B), dim3(256), 0, s, xp, (const bf16 *)nullptr, w, bias, mean, rstd, HW, C, G, silu, spx,
                            workspace, (float *)nullptr);
