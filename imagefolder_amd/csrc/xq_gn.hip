@@ -132,9 +132,19 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float *__restrict
     const int b = blockIdx.x, g = threadIdx.x;
     if (g >= G) return;
     float s1 = 0.0f, s2 = 0.0f;
-    for (int s = 0; s < nslab; ++s) {
-        s1 += part_g[(((long)b * nslab + s) * G + g) * 2 + 0];
-        s2 += part_g[(((long)b * nslab + s) * G + g) * 2 + 1];
+    const float2 *pg = reinterpret_cast<const float2 *>(part_g) + (long)b * nslab * G + g;
+    int s = 0;
+    for (; s + 8 <= nslab; s += 8) {      // eight slabs requested before any is added, added in ascending order (same bits as one at a time; the
+        float2 v[8];                      // one-at-a-time walk was a chain of 256 dependent round trips: 11 us per call)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = pg[(long)(s + u) * G];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += v[u].x; s2 += v[u].y; }
+    }
+    for (; s < nslab; ++s) {
+        const float2 v = pg[(long)s * G];
+        s1 += v.x;
+        s2 += v.y;
     }
     if (what == 0) out0[b * G + g] = s1 / n;
     else if (what == 1) out0[b * G + g] = 1.0f / sqrtf(s1 / n + eps);
