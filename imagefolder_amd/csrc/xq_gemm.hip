@@ -1177,6 +1177,11 @@ __device__ __forceinline__ void duo_epilogue(const f32x16 (&acc)[2][2], const Ge
                     if (gr >= m_lo) { csum[2 * e] += bf16_lo(o[e]); csum[2 * e + 1] += bf16_hi(o[e]); }
                 }
             }
+            if (ACT == ACT_NONE && g.H && ok) {      // out_mask of a convolution's data gradient (gemm_w64x64_kernel; the duo products have no H)
+                const u32x4 mk = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const __hip_bfloat16 *>(g.H) + gr * g.ldc + gc);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = keep_where_positive(v[e], mk[e]);
+            }
             if (ok && (ACT != ACT_GELU_FWD || g.C != nullptr)) {
                 u32x4 *p1 = reinterpret_cast<u32x4 *>(C + gr * g.ldc + gc);
                 if (g.nt_store) __builtin_nontemporal_store(o, p1); else *p1 = o;
@@ -1804,6 +1809,69 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
     *reinterpret_cast<float4 *>(out + e) = s;
 }
 
+// 256 x 128 tiles with the eight waves as 4 x 2, 64 x 64 outputs each (round 6).  gemm_simple_kernel<.., 128, ..> runs them as 2 x 4 waves of
+// 128 rows x 32 columns: 4 A + 1 B fragment reads per 4 MFMAs = 160 KiB of LDS reads per K tile, 1274 LDS cycles against 1024 matrix-pipe cycles —
+// the 128-channel convolutions (LPIPS conv2_x, the CNN tokenizer's 128-channel levels) were LDS-read-bound at 600-700 TF/s.  64 x 64 per wave reads
+// 2 A + 2 B fragments per 4 MFMAs (128 KiB per K tile).  Same staging, same LDS pieces, same fragment maps (wave row wr -> A piece wr & 1, half wr >> 1;
+// wave column wc -> B fragments 2 wc, 2 wc + 1 of the one B piece), same k order per output element: bit-identical to the simple schedule.
+template <int AK, int BK>
+__global__ __launch_bounds__(GT) void gemm_w64x64_kernel(const GemmArgs g0) {
+    constexpr int BN = 128, WTN = 32, NPB = 3, BUF = NPB * gm::PIECE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;      // 4 x 2
+    long m0, n0, split;
+    if (!tile_of_block(g0, BN, m0, n0, split)) return;
+    const GemmArgs &g = g0;
+    const int KT = g.ktiles;
+
+    Stager<AK, true> sa;
+    Stager<BK, false> sb;
+    sa.bind(g);
+    sa.init(g.A, g.lda, m0, g.M, 0, wave, lane, WTN, 2);
+    sb.init(g.B, g.ldb, n0, g.N, 0, wave, lane, WTN, 1);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    auto stage_tile = [&](long kt, int buf) {
+        char *b = smem + buf * BUF;
+        sa.issue(0, kt, b, wave);
+        sa.issue(1, kt, b + gm::PIECE_BYTES, wave);
+        sb.issue(0, kt, b + 2 * gm::PIECE_BYTES, wave);
+    };
+
+    stage_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < KT; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < KT) stage_tile(t + 1, cur ^ 1);
+        const char *b = smem + cur * BUF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 bf[2], af[2];
+#pragma unroll
+            for (int fj = 0; fj < 2; ++fj) bf[fj] = read_frag<BK, false>(b + 2 * gm::PIECE_BYTES, 2 * wc + fj, 0, s, lane);
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi) af[fi] = read_frag<AK, true>(b + (wr & 1) * gm::PIECE_BYTES, wr >> 1, fi, s, lane);
+#pragma unroll
+            for (int fi = 0; fi < 2; ++fi)
+#pragma unroll
+                for (int fj = 0; fj < 2; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[fj], af[fi], acc[fi][fj], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    duo_epilogue<BK, ACT_NONE>(acc, g, smem + wave * 4096, m0, n0, m0, 0, wr, wc, lane);
+}
+
 template <void (*KERNEL)(const GemmArgs)>
 int set_lds(int bytes) {
     static unsigned long long devs = 0;   // one static per kernel instantiation; one bit per device
@@ -1989,8 +2057,20 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
             hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 256, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
         } else {
             const int lds = 6 * gm::PIECE_BYTES;
-            if (set_lds<gemm_simple_kernel<AK, BK, 128, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-            hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 128, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+            static const int w64 = [] { const char *e = getenv("XQ_GEMM_W64X64"); return e ? atoi(e) : 1; }();      // 0: the 2 x 4-wave form of the simple schedule
+            bool done = false;
+            if constexpr (EPI == EPI_BF16 && ACT == ACT_NONE) {
+                // whole-K products of one matrix with the bf16 epilogue (every 128-column convolution and Linear): the 4 x 2-wave kernel
+                if (w64 && g.splits == 1 && g.batch_a == 0 && g.batch_b == 0 && g.batch_c == 0) {
+                    if (set_lds<gemm_w64x64_kernel<AK, BK>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+                    hipLaunchKernelGGL((gemm_w64x64_kernel<AK, BK>), dim3((unsigned)total), dim3(GT), lds, s, g);
+                    done = true;
+                }
+            }
+            if (!done) {
+                if (set_lds<gemm_simple_kernel<AK, BK, 128, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+                hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 128, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
+            }
         }
     }
     prof_end(pslot, s);
