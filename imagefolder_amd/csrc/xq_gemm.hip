@@ -1817,7 +1817,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float *__restr
 template <int AK, int BK>
 __global__ __launch_bounds__(GT) void gemm_w64x64_kernel(const GemmArgs g0) {
     constexpr int BN = 128, WTN = 32, NPB = 3, BUF = NPB * gm::PIECE_BYTES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+    extern __shared__ __attribute__((aligned(16))) char smem[];      // THREE tile buffers of 48 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;      // 4 x 2
@@ -1840,6 +1840,7 @@ __global__ __launch_bounds__(GT) void gemm_w64x64_kernel(const GemmArgs g0) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    // 6 LDS-DMA instructions per wave and K tile (3 pieces x 2)
     auto stage_tile = [&](long kt, int buf) {
         char *b = smem + buf * BUF;
         sa.issue(0, kt, b, wave);
@@ -1847,12 +1848,16 @@ __global__ __launch_bounds__(GT) void gemm_w64x64_kernel(const GemmArgs g0) {
         sb.issue(0, kt, b + 2 * gm::PIECE_BYTES, wave);
     };
 
+    // K tiles t + 1 and t + 2 are in flight while tile t is multiplied: ONE barrier per K tile, behind a counted wait — vmcnt(6): everything but the
+    // six instructions of tile t + 1 has landed (in-order retirement) — instead of the simple schedule's vmcnt(0) + barrier with nothing in flight.
+    // The barrier also says every wave has finished reading tile t - 1, whose buffer tile t + 2 is then staged into.
     stage_tile(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (KT > 1) stage_tile(1, 1);
+    int cur = 0, nxt2 = 2;
     for (int t = 0; t < KT; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < KT) stage_tile(t + 1, cur ^ 1);
+        if (t + 1 < KT) GR_VMCNT(6); else GR_VMCNT(0);
+        GR_BARRIER();
+        if (t + 2 < KT) stage_tile(t + 2, nxt2);
         const char *b = smem + cur * BUF;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -1866,9 +1871,10 @@ __global__ __launch_bounds__(GT) void gemm_w64x64_kernel(const GemmArgs g0) {
 #pragma unroll
                 for (int fj = 0; fj < 2; ++fj) acc[fi][fj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[fj], af[fi], acc[fi][fj], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
     }
+    GR_BARRIER();      // every wave is past its last fragment read: the buffers become the epilogue's staging regions
     duo_epilogue<BK, ACT_NONE>(acc, g, smem + wave * 4096, m0, n0, m0, 0, wr, wc, lane);
 }
 
@@ -2056,14 +2062,14 @@ int launch_gemm(GemmArgs g, int BN, int impl, void *ws, size_t ws_bytes, hipStre
             if (set_lds<gemm_simple_kernel<AK, BK, 256, EPI>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
             hipLaunchKernelGGL((gemm_simple_kernel<AK, BK, 256, EPI>), dim3((unsigned)total), dim3(GT), lds, s, g);
         } else {
-            const int lds = 6 * gm::PIECE_BYTES;
+            const int lds = 6 * gm::PIECE_BYTES, lds3 = 9 * gm::PIECE_BYTES;
             static const int w64 = [] { const char *e = getenv("XQ_GEMM_W64X64"); return e ? atoi(e) : 1; }();      // 0: the 2 x 4-wave form of the simple schedule
             bool done = false;
             if constexpr (EPI == EPI_BF16 && ACT == ACT_NONE) {
                 // whole-K products of one matrix with the bf16 epilogue (every 128-column convolution and Linear): the 4 x 2-wave kernel
                 if (w64 && g.splits == 1 && g.batch_a == 0 && g.batch_b == 0 && g.batch_c == 0) {
-                    if (set_lds<gemm_w64x64_kernel<AK, BK>>(lds)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
-                    hipLaunchKernelGGL((gemm_w64x64_kernel<AK, BK>), dim3((unsigned)total), dim3(GT), lds, s, g);
+                    if (set_lds<gemm_w64x64_kernel<AK, BK>>(lds3)) return xq_set_error(XQ_ELAUNCH, "%s: hipFuncSetAttribute failed", fn);
+                    hipLaunchKernelGGL((gemm_w64x64_kernel<AK, BK>), dim3((unsigned)total), dim3(GT), lds3, s, g);
                     done = true;
                 }
             }
