@@ -139,6 +139,9 @@ class FlatArena:
             return
         dev = self.p.device
         if self._conv_table is None:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatArena.refresh_conv_packs: a conv weight was packed for the first time inside a stream capture; run one eager "
+                                   "step first (CapturedStep's warm-up does) so that the pack table is built outside the capture")
             rows, blocks = [], 0
             for p, wf, wd in self._conv_packs.values():
                 rows.append((p.data_ptr(), 0 if wf is None else wf.data_ptr(), 0 if wd is None else wd.data_ptr(), p.shape[0], p.shape[1], blocks))
