@@ -10,6 +10,13 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _needs_the_switch_on():
+    from imagefolder_amd import train
+    if not train.TRANSPOSED_SHADOWS:
+        pytest.skip("XQ_DGRAD_NT=0: the NN data gradients on W as stored are in force")
+
+
 def _transposes_current(arena):
     n = 0
     for p in arena.params:

@@ -47,9 +47,11 @@ def test_packed_conv_weights_follow_the_optimizer():
 def test_optimizer_step_refreshes_the_registered_conv_packs_in_one_launch():
     """round 6: after the first use, the packed layouts of an arena's 3x3 weights are rewritten by ONE xq_conv3x3_pack_weights_batched launch behind
     the optimizer kernel and stamped current — the next forward / backward finds them, and they equal a fresh per-weight pack of the new masters"""
-    from imagefolder_amd import _lib, nn_ops, ops_dense
+    from imagefolder_amd import _lib, nn_ops, ops_dense, train
     from imagefolder_amd._lib import ptr
     from imagefolder_amd.train import ArenaOptimizer
+    if not train.CONV_PACKS_BATCHED:
+        pytest.skip("XQ_CONV_PACKS_BATCHED=0: the per-weight repack path is in force")
     torch.manual_seed(0)
     convs = [torch.nn.Conv2d(64, 128, 3, padding=1).cuda(), torch.nn.Conv2d(128, 64, 3, padding=1).cuda(), torch.nn.Conv2d(192, 64, 3, padding=1).cuda()]
     opt = ArenaOptimizer([p for c in convs for p in c.parameters()], lr=0.05, weight_decay=0.0, use_ema=False)
